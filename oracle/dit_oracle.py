@@ -1,0 +1,368 @@
+"""CPU oracle for the MaP-DiT network (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+A functional, state-dict-driven restatement of the reference network in plain
+PyTorch (any float dtype, CPU).  Gradients come from torch autograd over this
+restatement.  Every function cites the reference file:line it follows
+(paths relative to /root/reference).
+
+The state-dict key names are the reference's so that one seeded
+state dict can be loaded into the reference (golden generation), this oracle,
+and the HIP product alike.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+MP_SILU_DIV = 0.596          # src/basic/mp_silu.py:7
+NORM_EPS = 1e-4              # src/utils.py:19
+RESIDUAL_T = 0.3             # src/blocks/dit_block.py:35-36
+EMBED_T = 0.5                # src/dit.py:84,88
+FOURIER_DIM = 256            # src/blocks/timestep_embedder.py:30
+SCALE_DIM = 8                # src/blocks/final_layer.py:13
+
+
+@dataclass(frozen=True)
+class DiTConfig:
+    """Constructor arguments of the reference DiT (src/dit.py:15-27)."""
+    depth: int
+    hidden_size: int
+    patch_size: int
+    input_size: int = 32
+    in_channels: int = 3
+    num_heads: int = 16
+    mlp_ratio: float = 4.0
+    class_dropout_prob: float = 0.1
+    num_classes: int = 1000
+    learn_sigma: bool = True
+
+    @property
+    def grid(self) -> int:
+        return self.input_size // self.patch_size
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def patch_dim(self) -> int:
+        return self.patch_size * self.patch_size * self.in_channels
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @property
+    def mlp_hidden(self) -> int:
+        return int(self.hidden_size * self.mlp_ratio)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+# name -> (depth, hidden, heads); src/models.py:4-47
+_FAMILIES = {"XL": (28, 1152, 16), "L": (24, 1024, 16), "B": (12, 768, 12),
+             "S": (12, 384, 6), "XS": (6, 256, 4)}
+
+
+def model_config(name: str, **kwargs) -> DiTConfig:
+    """'DiT-B/2' -> DiTConfig, mirroring src/models.py:50-56."""
+    fam, patch = name[len("DiT-"):].split("/")
+    depth, hidden, heads = _FAMILIES[fam]
+    return DiTConfig(depth=depth, hidden_size=hidden, patch_size=int(patch), num_heads=heads, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------
+# MP primitives
+# ----------------------------------------------------------------------------------------------
+
+def normalize(x: Tensor, eps: float = NORM_EPS) -> Tensor:
+    """src/utils.py:19-23 (and chunk_normalize :26-34, which is identical per row)."""
+    norm = torch.linalg.vector_norm(x, dim=-1, keepdim=True)
+    return x * math.sqrt(x.shape[-1]) / (norm + eps)
+
+
+def mp_sum(a: Tensor, b: Tensor, t) -> Tensor:
+    """src/utils.py:15-16.  For a tensor ``t`` the denominator goes through math.sqrt and is
+    therefore a detached Python float."""
+    if isinstance(t, Tensor):
+        den = math.sqrt(float(((1 - t) ** 2 + t ** 2).detach()))
+    else:
+        den = math.sqrt((1 - t) ** 2 + t ** 2)
+    return a.lerp(b, t) / den
+
+
+def modulate(x: Tensor, shift: Tensor, scale: Tensor, t) -> Tensor:
+    """src/utils.py:11-12."""
+    return mp_sum(x * scale.unsqueeze(1), shift.unsqueeze(1), t)
+
+
+def mp_silu(x: Tensor) -> Tensor:
+    """src/basic/mp_silu.py:5-7."""
+    return torch.nn.functional.silu(x) / MP_SILU_DIV
+
+
+def patchify(x: Tensor, p: int) -> Tensor:
+    """src/utils.py:37-46: b c (h p1) (w p2) -> b (h w) (p1 p2 c)."""
+    b, c, hh, ww = x.shape
+    h, w = hh // p, ww // p
+    return x.reshape(b, c, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(b, h * w, p * p * c)
+
+
+def unpatchify(x: Tensor, input_size: int, p: int) -> Tensor:
+    """src/utils.py:49-59: b (h w) (p1 p2 c) -> b c (h p1) (w p2)."""
+    b = x.shape[0]
+    h = w = input_size // p
+    c = x.shape[-1] // (p * p)
+    return x.reshape(b, h, w, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(b, c, h * p, w * p)
+
+
+def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
+    """MPLinear / MPLinearChunk forward (src/basic/mp_linear.py:31-46, 67-75), gain == 1.
+    Training forward first overwrites the stored weight with its normalised value (F9)."""
+    w = sd[key]
+    if train:
+        with torch.no_grad():
+            w.copy_(normalize(w))
+    w_eff = normalize(w) / math.sqrt(w.shape[1])
+    return torch.nn.functional.linear(x, w_eff)
+
+
+def mp_embedding(idx: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
+    """src/basic/mp_embedding.py:15-24."""
+    w = sd[key]
+    if train:
+        with torch.no_grad():
+            w.copy_(normalize(w))
+    return normalize(w)[idx]
+
+
+def sincos_pos_embed(dim: int, grid: int) -> np.ndarray:
+    """src/pos_embed.py:4-60 (MAE table, float64).  First half of ``dim`` encodes the w index
+    ("w goes first", pos_embed.py:15), second half the h index; each half is [sin | cos]."""
+    gw, gh = np.meshgrid(np.arange(grid, dtype=np.float32), np.arange(grid, dtype=np.float32))
+
+    def one_d(d, pos):
+        omega = np.arange(d // 2, dtype=np.float64) / (d / 2.0)
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    return np.concatenate([one_d(dim // 2, gw), one_d(dim // 2, gh)], axis=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# State dict
+# ----------------------------------------------------------------------------------------------
+
+def param_shapes(cfg: DiTConfig) -> Dict[str, tuple]:
+    """Every state_dict entry of the reference model and its shape, in the
+    order nn.Module.state_dict() yields them."""
+    D, P, Hm = cfg.hidden_size, cfg.patch_dim, cfg.mlp_hidden
+    nch = 2 if cfg.learn_sigma else 1
+    use_cfg_emb = 1 if cfg.class_dropout_prob > 0 else 0
+    s: Dict[str, tuple] = {}
+    s["pos_embed"] = (1, cfg.tokens, D)
+    s["x_embedder.weight"] = (D, P + 1)
+    s["t_embedder.mlp.net.0.weight"] = (D, FOURIER_DIM)
+    s["t_embedder.mlp.net.2.weight"] = (D, D)
+    s["t_embedder.embedding.scale"] = (FOURIER_DIM,)
+    s["t_embedder.embedding.shift"] = (FOURIER_DIM,)
+    s["y_embedder.embedding.weight"] = (cfg.num_classes + use_cfg_emb, D)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        s[b + "gain_msa"] = ()
+        s[b + "gain_mlp"] = ()
+        s[b + "attn.qkv_proj.weight"] = (3 * D, D)
+        s[b + "attn.out_proj.weight"] = (D, D)
+        s[b + "mlp.net.0.weight"] = (Hm, D)
+        s[b + "mlp.net.2.weight"] = (D, Hm)
+        s[b + "modulation.1.weight"] = (6 * D, D)
+    s["final_layer.gain_mod"] = ()
+    s["final_layer.linear.weight"] = (nch * cfg.patch_size ** 2 * cfg.in_channels, D)
+    s["final_layer.modulation.1.weight"] = (2 * D, D)
+    s["final_layer.mean_scale.linear.weight"] = (SCALE_DIM, D)
+    s["final_layer.mean_scale.reference"] = (SCALE_DIM,)
+    if cfg.learn_sigma:
+        s["final_layer.sigma_scale.linear.weight"] = (SCALE_DIM, D)
+        s["final_layer.sigma_scale.reference"] = (SCALE_DIM,)
+    return s
+
+
+BUFFER_KEYS = ("pos_embed", "t_embedder.embedding.scale", "t_embedder.embedding.shift")
+
+
+def init_state_dict(cfg: DiTConfig, seed: int = 0, gains: Optional[float] = None,
+                    perturb_reference: float = 0.0, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Seeded state dict with the reference's init distributions (SURVEY §8c recipe step 1):
+    weights N(0,1) (mp_linear.py:23,63; mp_embedding.py:13), gains 0 (dit_block.py:28-29,
+    final_layer.py:47), mean_scale.reference 1 / sigma_scale.reference 0 (final_layer.py:18,50-51),
+    Fourier scale 2pi*N(0,1), shift 2pi*U(0,1) (timestep_embedder.py:12-16), pos_embed the
+    normalised sin-cos table (dit.py:46-48).  ``gains`` / ``perturb_reference`` give the
+    non-default fixtures that exercise the shift path and F8."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    for k, shp in param_shapes(cfg).items():
+        if k == "pos_embed":
+            pe = torch.from_numpy(sincos_pos_embed(cfg.hidden_size, cfg.grid)).float().unsqueeze(0)
+            sd[k] = normalize(pe)
+        elif k.endswith("embedding.scale"):
+            sd[k] = (2 * math.pi * torch.randn(shp, generator=g)).float()
+        elif k.endswith("embedding.shift"):
+            sd[k] = (2 * math.pi * torch.rand(shp, generator=g)).float()
+        elif k.endswith("mean_scale.reference"):
+            sd[k] = torch.ones(shp) + perturb_reference * torch.randn(shp, generator=g)
+        elif k.endswith("sigma_scale.reference"):
+            sd[k] = torch.zeros(shp) + perturb_reference * torch.randn(shp, generator=g)
+        elif "gain_" in k:
+            if gains is None:
+                sd[k] = torch.zeros(shp)
+            else:
+                sd[k] = gains * (0.5 + torch.rand(shp, generator=g))
+        else:
+            sd[k] = torch.randn(shp, generator=g)
+    return {k: v.to(dtype).clone() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# Network
+# ----------------------------------------------------------------------------------------------
+
+def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool) -> Tensor:
+    """src/layers/attention.py:29-51: cosine attention, logits = sqrt(hd)*cos(q,k)."""
+    B, T, D = x.shape
+    H, hd = cfg.num_heads, cfg.head_dim
+    q, k, v = mp_linear(x, sd, prefix + "qkv_proj.weight", train).chunk(3, dim=-1)
+    q = q.view(B, T, H, hd).transpose(1, 2)
+    k = k.view(B, T, H, hd).transpose(1, 2)
+    v = v.view(B, T, H, hd).transpose(1, 2)
+    q, k = normalize(q), normalize(k)
+    logits = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+    out = torch.softmax(logits, dim=-1) @ v
+    out = out.transpose(1, 2).reshape(B, T, D)
+    return mp_linear(out, sd, prefix + "out_proj.weight", train)
+
+
+def mlp(x: Tensor, sd, prefix: str, train: bool) -> Tensor:
+    """src/layers/mlp.py:16-25."""
+    h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train))
+    return mp_linear(h, sd, prefix + "net.2.weight", train)
+
+
+def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool) -> Tensor:
+    """src/blocks/dit_block.py:32-37."""
+    p = f"blocks.{i}."
+    mod = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train)
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
+    x = mp_sum(x, g_a.unsqueeze(1) * attention(modulate(x, sh_a, sc_a, sd[p + "gain_msa"]), sd, p + "attn.", cfg, train), RESIDUAL_T)
+    x = mp_sum(x, g_m.unsqueeze(1) * mlp(modulate(x, sh_m, sc_m, sd[p + "gain_mlp"]), sd, p + "mlp.", train), RESIDUAL_T)
+    return x
+
+
+def mp_scale(c: Tensor, sd, prefix: str, train: bool) -> Tensor:
+    """src/blocks/final_layer.py:20-22."""
+    angle = torch.matmul(mp_linear(c, sd, prefix + "linear.weight", train), sd[prefix + "reference"]) / math.sqrt(SCALE_DIM)
+    return torch.sigmoid(angle)
+
+
+def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool):
+    """src/blocks/final_layer.py:53-61.  Call order of the MPLinears follows the reference
+    (modulation, linear, mean_scale, sigma_scale) — it matters only for forced-WN side effects,
+    which are per-weight and order independent."""
+    p = "final_layer."
+    shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train).chunk(2, dim=-1)
+    x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
+    out = mp_linear(x_mod, sd, p + "linear.weight", train)
+    if cfg.learn_sigma:
+        mean, sigma = out.chunk(2, dim=-1)
+        return (mean * mp_scale(c, sd, p + "mean_scale.", train).view(-1, 1, 1),
+                sigma * mp_scale(c, sd, p + "sigma_scale.", train).view(-1, 1, 1))
+    return out * mp_scale(c, sd, p + "mean_scale.", train)
+
+
+def effective_labels(y: Tensor, cfg: DiTConfig, train: bool, drop: Optional[Tensor]) -> Tensor:
+    """src/blocks/label_embedder.py:19-34.  ``drop`` is the recorded mask ``rand(N) < p``
+    (RNG streams cannot be matched across back ends, so it is an explicit input)."""
+    if train and cfg.class_dropout_prob > 0:
+        assert drop is not None, "training forward needs the label-drop mask"
+        return torch.where(drop, torch.full_like(y, cfg.num_classes), y)
+    return y
+
+
+def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor,
+                train: bool = False, drop: Optional[Tensor] = None) -> Tensor:
+    """src/dit.py:70-105."""
+    dt = sd["x_embedder.weight"].dtype
+    h = patchify(x.to(dt), cfg.patch_size)
+    h = torch.cat([h, torch.ones_like(h[:, :, :1])], dim=-1)
+    h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)
+
+    four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
+    four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
+    temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train)
+    temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train)
+    yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train)
+    c = mp_sum(temb, yemb, EMBED_T)
+
+    for i in range(cfg.depth):
+        h = dit_block(h, c, sd, i, cfg, train)
+
+    if cfg.learn_sigma:
+        mean, sigma = final_layer(h, c, sd, cfg, train)
+        return torch.cat([unpatchify(mean, cfg.input_size, cfg.patch_size),
+                          unpatchify(sigma, cfg.input_size, cfg.patch_size)], dim=1)
+    return unpatchify(final_layer(h, c, sd, cfg, train), cfg.input_size, cfg.patch_size)
+
+
+def dit_forward_with_cfg(sd, cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor, cfg_scale: float,
+                         train: bool = False, drop: Optional[Tensor] = None) -> Tensor:
+    """src/dit.py:107-118."""
+    half = x[: len(x) // 2]
+    out = dit_forward(sd, cfg, torch.cat([half, half], dim=0), t, y, train, drop)
+    C = cfg.in_channels
+    eps, rest = out[:, :C], out[:, C:]
+    cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+    half_eps = uncond + cfg_scale * (cond - uncond)
+    return torch.cat([torch.cat([half_eps, half_eps], dim=0), rest], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# Optimiser / LR schedule / EMA  
+# ----------------------------------------------------------------------------------------------
+
+def lr_lambda(step: int, num_lin_warmup: int, start_decay: int) -> float:
+    """train.py:179-197."""
+    if step + 1 < num_lin_warmup:
+        return (step + 1) / num_lin_warmup
+    if step >= start_decay:
+        return 1.0 / math.sqrt(max(step / start_decay, 1))
+    return 1.0
+
+
+def std_to_gamma(std: float) -> float:
+    """src/ema.py:10-20: largest real root of g^3 + 7g^2 + (16 - s^-2) g + (12 - s^-2)."""
+    t = float(std) ** -2
+    return float(np.roots([1, 7, 16 - t, 12 - t]).real.max())
+
+
+def ema_beta(std: float, t: int) -> float:
+    """src/ema.py:33-40."""
+    return (1 - 1 / t) ** (std_to_gamma(std) + 1)
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+              beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8) -> None:
+    """torch.optim.Adam single-tensor update as configured at train.py:57 (no weight decay,
+    no amsgrad); ``step`` counts from 1."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)

@@ -1,0 +1,136 @@
+"""Pins the CPU oracle to the golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only; tolerances are fp32 round-off level."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, golden_state_dict, load_golden, rel_err, sub
+from oracle import dit_oracle as O
+from oracle.diffusion_oracle import DiffusionOracle, space_timesteps
+
+TOL = 5e-5          # fp32 restatement vs fp32 reference, norm-wise relative
+
+
+def _train(g, cfg, sd):
+    osd = {k: v.clone().requires_grad_(k not in O.BUFFER_KEYS) for k, v in sd.items()}
+    x, y, t = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), torch.from_numpy(g["t"])
+    noise, drop = torch.from_numpy(g["noise"]), torch.from_numpy(g["drop"])
+    d = DiffusionOracle("")
+    losses = d.training_losses(lambda xx, tt, **kw: O.dit_forward(osd, cfg, xx, tt, kw["y"], train=True, drop=drop),
+                               x, t, dict(y=y), noise=noise)
+    losses["loss"].mean().backward()
+    return osd, losses
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
+def test_tiny_fixture(name):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    x, y, t = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), torch.from_numpy(g["t"])
+    with torch.no_grad():
+        out = O.dit_forward({k: v.clone() for k, v in sd.items()}, cfg, x, t, y, train=False)
+    assert rel_err(out.numpy(), g["eval_out"]) < TOL
+    osd, losses = _train(g, cfg, sd)
+    for k in ("loss", "mse", "vb"):
+        assert rel_err(losses[k].detach().numpy(), g["train_" + k]) < TOL
+    for k in osd:
+        if k in O.BUFFER_KEYS:
+            continue
+        assert rel_err(sub(osd[k].grad), g["grad/" + k]) < 1e-3, k
+        if "postw/" + k in g:
+            assert rel_err(sub(osd[k].detach()), g["postw/" + k]) < 1e-6, k
+
+
+def test_label_drop_recorded():
+    g = load_golden("tiny_b")
+    y_eff = np.where(g["drop"], int(g["cfg_num_classes"]), g["y"])
+    assert (y_eff == g["y_eff"]).all()
+
+
+def test_sampler_fixture():
+    g = load_golden("tiny_b")
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    d = DiffusionOracle("250")
+    assert d.timestep_map == g["timestep_map_250"].tolist()
+    assert DiffusionOracle("5").timestep_map == g["timestep_map_5"].tolist() == [0, 250, 500, 749, 999]
+    fn = lambda xx, tt, **kw: O.dit_forward_with_cfg(sd, cfg, xx, tt, kw["y"], kw["cfg_scale"])
+    z, yy = torch.from_numpy(g["ps_z"]), torch.from_numpy(g["ps_y"])
+    kw = dict(y=yy, cfg_scale=1.5)
+    with torch.no_grad():
+        r = d.p_sample(fn, z, torch.from_numpy(g["ps_t"]), torch.from_numpy(g["ps_noise"]), False, kw)
+    assert rel_err(r["sample"].numpy(), g["ps_sample"]) < TOL
+    assert rel_err(r["pred_xstart"].numpy(), g["ps_xstart"]) < TOL
+    traj = d.p_sample_loop(fn, z.shape, z, list(torch.from_numpy(g["loop_noise"])), False, kw, max_steps=3)
+    for k in range(3):
+        assert rel_err(traj[k].numpy(), g["loop_traj"][k]) < 20 * TOL
+
+
+def test_tables():
+    g = load_golden("tables")
+    for tag, rs in (("1000", ""), ("250", "250")):
+        d = DiffusionOracle(rs)
+        for k in ("betas", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                  "posterior_mean_coef2"):
+            np.testing.assert_allclose(getattr(d, k), g[f"{tag}/{k}"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose([O.std_to_gamma(0.05), O.std_to_gamma(0.1)], g["ema_gamma"], rtol=1e-12)
+    np.testing.assert_allclose([O.ema_beta(0.05, 100), O.ema_beta(0.1, 100)], g["ema_beta_t100"], rtol=1e-12)
+
+
+def test_space_timesteps_errors():
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    assert space_timesteps(300, [10, 15, 20])[:3] == [0, 11, 22]
+
+
+def test_s4_known_answers():
+    """DiT-S/4, batch 8 (BASELINE configs[0]) — eval logits and training losses."""
+    g = load_golden("s4_n8")
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    x, y, t = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), torch.from_numpy(g["t"])
+    with torch.no_grad():
+        out = O.dit_forward({k: v.clone() for k, v in sd.items()}, cfg, x, t, y, train=False)
+    assert rel_err(out.numpy(), g["eval_out"]) < TOL
+    osd, losses = _train(g, cfg, sd)
+    assert rel_err(losses["loss"].detach().numpy(), g["train_loss"]) < TOL
+    for k in ("blocks.0.attn.qkv_proj.weight", "x_embedder.weight", "blocks.0.gain_msa", "final_layer.linear.weight",
+              "y_embedder.embedding.weight", "blocks.11.mlp.net.2.weight"):
+        assert abs(float(osd[k].grad.double().norm()) / float(g["gradnorm/" + k]) - 1) < 1e-3, k
+        assert rel_err(sub(osd[k].grad, stride=4099), g["grad/" + k]) < 1e-3, k
+
+
+def test_optimizer_fixture():
+    """Three Adam(lr 1e-2, betas (0.9, 0.99)) + power-EMA steps."""
+    g = load_golden("optim3")
+    cfg = golden_cfg(g)
+    sd = O.init_state_dict(cfg, seed=5, gains=0.2, perturb_reference=0.3)
+    params = {k: v for k, v in sd.items() if k not in O.BUFFER_KEYS}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    emas = {s: {k: v.clone() for k, v in params.items()} for s in (0.05, 0.1)}
+    d = DiffusionOracle("")
+    keys = [k[len("s1/w/"):] for k in g if k.startswith("s1/w/")]
+    for step in range(1, 4):
+        osd = {k: (v.clone().requires_grad_(True) if k in params else v) for k, v in sd.items()}
+        drop = torch.from_numpy(g[f"s{step}/drop"])
+        x, y, t = (torch.from_numpy(g[f"s{step}/{n}"]) for n in ("x", "y", "t"))
+        noise = torch.from_numpy(g[f"s{step}/noise"])
+        loss = d.training_losses(lambda xx, tt, **kw: O.dit_forward(osd, cfg, xx, tt, kw["y"], train=True, drop=drop),
+                                 x, t, dict(y=y), noise=noise)["loss"].mean()
+        loss.backward()
+        assert abs(loss.item() - float(g[f"s{step}/loss"])) < 1e-4 * abs(float(g[f"s{step}/loss"]))
+        with torch.no_grad():
+            for k in params:
+                sd[k] = osd[k].detach().clone()           # forced-WN-mutated weight
+                O.adam_step(sd[k], osd[k].grad, m[k], v2[k], step, lr=1e-2)
+                for s in emas:
+                    emas[s][k].lerp_(sd[k], O.ema_beta(s, step))
+        for k in keys:
+            assert rel_err(sub(sd[k]), g[f"s{step}/w/{k}"]) < 2e-4, (step, k)
+            assert rel_err(sub(emas[0.05][k]), g[f"s{step}/ema0.05/{k}"]) < 2e-4, (step, k)
+            assert rel_err(sub(emas[0.1][k]), g[f"s{step}/ema0.1/{k}"]) < 2e-4, (step, k)
