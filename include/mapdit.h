@@ -1,0 +1,211 @@
+/*
+ * mapdit.h — C ABI of the MI355X-native MaP-DiT hot path (libmapdit_hip.so).
+ *
+ * The reference (ericbill21/map-dit) is pure Python/PyTorch and has no FFI; its drop-in boundary is the
+ * Python object protocol DIT_MODELS[name](...) / create_diffusion(...).  This header is
+ * the C-ABI *beneath* that protocol: plain device pointers, sizes and a hipStream_t (passed as void*),
+ * int status return (0 = ok), no ownership transfer, no hidden device allocation (workspaces are passed
+ * in).  Each entry point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * All pointers are DEVICE pointers unless a name ends in _host.  bf16 tensors are raw uint16_t bits.
+ * Every kernel entry point is asynchronous on `stream` and safe to capture into a hipGraph.
+ */
+#ifndef MAPDIT_H
+#define MAPDIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPDIT_OK 0
+#define MAPDIT_ERR_ARG 1 /* shape / argument the kernels do not support (message in mapdit_last_error) */
+#define MAPDIT_ERR_HIP 2 /* a HIP runtime call failed */
+
+/* Thread-local message of the last non-zero status returned on this thread. */
+const char* mapdit_last_error(void);
+int mapdit_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM on bf16 MFMA with fused epilogues — F.linear and its autograd (src/basic/mp_linear.py:46,75).
+ *   NT: A[M,K] rows, B[N,K] rows      y  = x W^T
+ *   NN: A[M,K] rows, B[K,N] rows      dx = dy W
+ *   TN: A[K,M] rows, B[K,N] rows      dW = dy^T x
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { MAPDIT_NT = 0, MAPDIT_NN = 1, MAPDIT_TN = 2 };
+
+enum {
+    MAPDIT_EPI_STORE_BF16 = 0, /* out[m,n] = bf16(alpha*acc)                                                        */
+    MAPDIT_EPI_STORE_F32 = 1,  /* out[m,n] = alpha*acc (+ out[m,n] if accumulate)                                   */
+    MAPDIT_EPI_SILU2 = 2,      /* out = bf16(acc) [optional]; out2 = bf16(silu(acc)/0.596)   (mlp.py:18-20, mp_silu.py:7) */
+    MAPDIT_EPI_RESID = 3,      /* out = bf16(acc) [optional]; out2[m,n] = alpha*aux[m,n] + beta*gate[m/rows,n]*acc
+                                  = mp_sum(x, gate*y, 0.3) of dit_block.py:35-36; aux/out2: fp32 residual stream       */
+    MAPDIT_EPI_DSILU = 4       /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
+};
+
+typedef struct {
+    int kind;
+    void* out;
+    int ldo; /* row stride (elements) of out, out2, aux */
+    void* out2;
+    const void* aux;
+    const float* gate;
+    int ldg;
+    int rows_per_sample;
+    float alpha, beta;
+    int accumulate;
+} mapdit_epilogue_t;
+
+int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
+                     const mapdit_epilogue_t* epi, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight normalisation of MPLinear / MPLinearChunk / MPEmbedding (src/utils.py:19-34, mp_linear.py:38-44,66-74,
+ * mp_embedding.py:17-22).  One pass over W[rows,cols] (fp32 master): if forced, W <- W*sqrt(cols)/(|row|+eps) in
+ * place (training-mode forced weight norm); then the effective weight w = out_scale * W/(|W row|+eps) is written
+ * as bf16 (w_bf16) and/or fp32 (w_f32) — either may be NULL — and inv[row] = 1/(|W row|+eps) (may be NULL).
+ * out_scale = 1 for linears (normalize(W)/sqrt(in)), sqrt(cols) for the embedding table (normalize(W)).
+ * ------------------------------------------------------------------------------------------------------------ */
+int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16, float* w_f32,
+                          float* inv, void* stream);
+/* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)), G rows have stride ldg. */
+int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, float* dW, int rows, int cols, float out_scale,
+                          int accumulate, void* stream);
+
+/* torch.optim.Adam (train.py:57) fused with the two power-function EMA copies (src/ema.py:135-140) over flat
+ * fp32 buffers.  hyper (device, 5 floats): lr/(1-b1^t), 1/sqrt(1-b2^t), ema beta a, ema beta b, grad scale. */
+int mapdit_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
+                         float* ema_b, long n, const float* hyper, float beta1, float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Token-stream kernels of the DiT block (src/utils.py:11-16, src/blocks/dit_block.py:33-36).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* out = bf16(modulate(x, shift, scale, *gain)); x fp32 [n_samples*T, D]; shift/scale fp32 rows of stride ldmod. */
+int mapdit_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
+                        uint16_t* out, int n_samples, int T, int D, void* stream);
+
+/* Fused backward of  x' = mp_sum(x_up, g_up*y_up, 0.3)  followed by  u = modulate(x', shift, scale, gain):
+ * see map-dit_amd/csrc/pointwise.hip for the formulas.  NULL pointers switch the corresponding part off. */
+typedef struct {
+    const float* dxo;      /* grad wrt x' from downstream (fp32) or NULL */
+    const uint16_t* dxm;   /* grad wrt u (bf16) or NULL */
+    const float* x;        /* x' (fp32) */
+    const float* shift;
+    const float* scale;
+    const float* gain;
+    const uint16_t* y_up;  /* residual branch output that produced x' (bf16) or NULL */
+    const float* g_up;     /* its gate rows */
+    float* dx;             /* out: grad wrt x' (fp32) or NULL */
+    uint16_t* dx_bf;       /* out: same as bf16 or NULL */
+    float* dshift;
+    float* dscale;
+    float* dgain_part;     /* out: n_samples*(D/128) partial sums */
+    uint16_t* dy_up;       /* out: grad wrt y_up (bf16) */
+    float* dg_up;          /* out: grad wrt g_up rows */
+    int ldmod, ldg_up, ldd, ldd_up;
+    int n_samples, T, D;
+    float ca, cb;          /* 0.7/sqrt(0.58), 0.3/sqrt(0.58) for t = 0.3 */
+} mapdit_resid_mod_bwd_t;
+int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
+int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream);
+
+int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream);          /* mp_silu.py:7 */
+int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Cosine attention (src/layers/attention.py:37-51).  head_dim must be 64; T in {64, 128, 256}.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* qkv [B*T, 3*H*64] -> qn, kn (cosine-normalised), v as [B*H][T][64]; optional transposes [B*H][64][T]. */
+int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
+                     uint16_t* qt, uint16_t* kt, uint16_t* vt, void* stream);
+int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+                         const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
+/* o [B*T, H*64] = softmax(qn kn^T / 8) v ; lse [B*H][T] */
+int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* vt, uint16_t* o, float* lse, int B,
+                        int T, int H, int head_dim, void* stream);
+/* dO [B*T, H*64] -> doT [B*H][64][T], delta [B*H][T] = rowsum(dO*O) */
+int mapdit_attn_do_prep(const uint16_t* dO, const uint16_t* O, int B, int T, int H, int head_dim, uint16_t* doT,
+                        float* delta, void* stream);
+int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* qt,
+                        const uint16_t* kt, const uint16_t* dO, const uint16_t* doT, const float* lse,
+                        const float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+                        int head_dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Embedding / conditioning / output side (src/dit.py:81-101, timestep_embedder.py, label_embedder.py, final_layer.py).
+ * ------------------------------------------------------------------------------------------------------------ */
+int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
+                           int ldp, int N, int C, int S, int p, int D, void* stream);
+int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift, uint16_t* out, int n, int F,
+                       void* stream);
+int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
+                            uint16_t* c_bf, int n, int D, void* stream);
+int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
+                            float* dtable, int n, int D, void* stream);
+int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
+                         const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream);
+int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
+                         const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
+                         float* dref_mean, float* dref_sigma, int N, int C, int S, int p, void* stream);
+/* DiT.forward_with_cfg tail (src/dit.py:113-118). */
+int mapdit_cfg_combine(const float* model_out, float* out, int n_total, int C, int HW, float cfg_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gaussian diffusion pointwise math (diffusion/gaussian_diffusion.py, diffusion/diffusion_utils.py).
+ * `tab` = 8 x nsteps fp32 table: sqrt_acp, sqrt_1m_acp, sqrt_recip_acp, sqrt_recipm1_acp,
+ * posterior_log_variance_clipped, log(betas), posterior_mean_coef1, posterior_mean_coef2.
+ * ------------------------------------------------------------------------------------------------------------ */
+int mapdit_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int nsteps, float* xt,
+                    int N, int per_sample, void* stream);                       /* gaussian_diffusion.py:215-230 */
+/* training_losses, MSE + learned-range vb (:715-787): mse, vb, loss [N]; G [N,2C,H,W] = d mse/d eps | d vb/d v. */
+int mapdit_loss_fwd(const float* model_out, const float* x0, const float* xt, const float* noise, const int64_t* t,
+                    const float* tab, int nsteps, float* mse, float* vb, float* loss, float* G, int N, int per_sample,
+                    void* stream);
+int mapdit_loss_bwd(const float* G, const float* g_loss, const float* g_mse, const float* g_vb, float* dout, int N,
+                    int per_sample, void* stream);
+/* p_mean_variance + p_sample (:254-332, 376-417). */
+int mapdit_psample_step(const float* model_out, const float* x, const float* noise, const int64_t* t, const float* tab,
+                        int nsteps, int clip_denoised, float* sample, float* pred_xstart, int N, int per_sample,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
+    int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
+    int max_batch;
+} mapdit_config_t;
+
+/* Parameter pointer table: MAPDIT_NUM_GLOBAL global entries followed by MAPDIT_NUM_BLOCK entries per block. */
+enum {
+    MAPDIT_P_X_EMB = 0, MAPDIT_P_T0, MAPDIT_P_T2, MAPDIT_P_Y_EMB, MAPDIT_P_F_LIN, MAPDIT_P_F_MOD, MAPDIT_P_MS_LIN,
+    MAPDIT_P_MS_REF, MAPDIT_P_SS_LIN, MAPDIT_P_SS_REF, MAPDIT_P_F_GAIN, MAPDIT_P_FOURIER_SCALE, MAPDIT_P_FOURIER_SHIFT,
+    MAPDIT_P_POS_EMBED, MAPDIT_NUM_GLOBAL
+};
+enum { MAPDIT_B_QKV = 0, MAPDIT_B_PROJ, MAPDIT_B_FC1, MAPDIT_B_FC2, MAPDIT_B_MOD, MAPDIT_B_GAIN_MSA, MAPDIT_B_GAIN_MLP, MAPDIT_NUM_BLOCK };
+
+typedef struct mapdit_engine mapdit_engine_t;
+
+/* Bytes of device workspace the engine needs (train != 0: activations of every block are kept for backward). */
+size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int train);
+/* `workspace` must stay alive and 256-byte aligned; the engine zero-fills the parts it relies on being zero. */
+int mapdit_engine_create(const mapdit_config_t* cfg, int train, void* workspace, size_t workspace_bytes, void* stream,
+                         mapdit_engine_t** out);
+void mapdit_engine_destroy(mapdit_engine_t* e);
+/* params_host / grads_host: host arrays of MAPDIT_NUM_GLOBAL + depth*MAPDIT_NUM_BLOCK device pointers (grads may be NULL). */
+int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host, float* const* grads_host);
+/* Weight pass: (forced != 0: rewrite master weights = training-mode forced WN) and refresh the bf16 weight images. */
+int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, void* stream);
+/* out [N, 2C, S, S] = DiT(x, t, y_eff); y_eff already has label drop applied.  save != 0 keeps activations. */
+int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const int64_t* t, const int64_t* y_eff, int N, int save,
+                          float* out, void* stream);
+/* Backward of the last saved forward: writes d loss / d parameter into every bound grad pointer (overwrite). */
+int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPDIT_H */

@@ -1,0 +1,145 @@
+"""ctypes binding of ``libmapdit_hip.so`` (C ABI declared in ``include/mapdit.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a call returns a
+non-zero status, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmapdit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+
+class MapditError(RuntimeError):
+    pass
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("kind", ci), ("out", vp), ("ldo", ci), ("out2", vp), ("aux", vp), ("gate", vp), ("ldg", ci),
+                ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci)]
+
+
+class ResidModBwd(C.Structure):
+    _fields_ = [("dxo", vp), ("dxm", vp), ("x", vp), ("shift", vp), ("scale", vp), ("gain", vp), ("y_up", vp),
+                ("g_up", vp), ("dx", vp), ("dx_bf", vp), ("dshift", vp), ("dscale", vp), ("dgain_part", vp),
+                ("dy_up", vp), ("dg_up", vp), ("ldmod", ci), ("ldg_up", ci), ("ldd", ci), ("ldd_up", ci),
+                ("n_samples", ci), ("T", ci), ("D", ci), ("ca", cf), ("cb", cf)]
+
+
+class Config(C.Structure):
+    _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
+                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci)]
+
+
+NT, NN, TN = 0, 1, 2
+EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU = range(5)
+
+# parameter-table indices (mapdit.h)
+(P_X_EMB, P_T0, P_T2, P_Y_EMB, P_F_LIN, P_F_MOD, P_MS_LIN, P_MS_REF, P_SS_LIN, P_SS_REF, P_F_GAIN, P_FOURIER_SCALE,
+ P_FOURIER_SHIFT, P_POS_EMBED, NUM_GLOBAL) = range(15)
+(B_QKV, B_PROJ, B_FC1, B_FC2, B_MOD, B_GAIN_MSA, B_GAIN_MLP, NUM_BLOCK) = range(8)
+
+# name -> argtypes for every status-returning entry point of include/mapdit.h
+_SIGS = {
+    "mapdit_gemm_bf16": [ci, ci, ci, ci, vp, ci, vp, ci, C.POINTER(Epilogue), vp],
+    "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
+    "mapdit_weightnorm_bwd": [vp, vp, ci, vp, ci, ci, cf, ci, vp],
+    "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
+    "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
+    "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
+    "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
+    "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],
+    "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
+    "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+    "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
+    "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_attn_do_prep": [vp, vp, ci, ci, ci, ci, vp, vp, vp],
+    "mapdit_attn_cos_bwd": [vp] * 12 + [ci, ci, ci, ci, vp],
+    "mapdit_patch_embed_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "mapdit_fourier_fwd": [vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_final_out_fwd": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_cfg_combine": [vp, vp, ci, ci, ci, cf, vp],
+    "mapdit_q_sample": [vp, vp, vp, vp, ci, vp, ci, ci, vp],
+    "mapdit_loss_fwd": [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_loss_bwd": [vp, vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_psample_step": [vp, vp, vp, vp, vp, ci, ci, vp, vp, ci, ci, vp],
+    "mapdit_engine_create": [C.POINTER(Config), ci, vp, C.c_size_t, vp, C.POINTER(vp)],
+    "mapdit_engine_bind": [vp, C.POINTER(vp), C.POINTER(vp)],
+    "mapdit_engine_prepare_weights": [vp, ci, vp],
+    "mapdit_engine_forward": [vp, vp, vp, vp, ci, ci, vp, vp],
+    "mapdit_engine_backward": [vp, vp, vp],
+}
+# entry points that do not return a status
+_OTHER = {
+    "mapdit_last_error": (C.c_char_p, []),
+    "mapdit_abi_version": (ci, []),
+    "mapdit_engine_workspace_bytes": (C.c_size_t, [C.POINTER(Config), ci]),
+    "mapdit_engine_destroy": (None, [vp]),
+}
+EXPORTS = sorted(list(_SIGS) + list(_OTHER))
+
+_lock = threading.Lock()
+_handle = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-j8"])
+    return LIB_PATH
+
+
+class _Lib:
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, argtypes in _SIGS.items():
+            fn = getattr(cdll, name)
+            fn.argtypes = argtypes
+            fn.restype = ci
+            setattr(self, name[len("mapdit_"):], self._wrap(name, fn))
+        for name, (res, argtypes) in _OTHER.items():
+            fn = getattr(cdll, name)
+            fn.argtypes = argtypes
+            fn.restype = res
+            setattr(self, name[len("mapdit_"):], fn)
+
+    def _wrap(self, name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise MapditError(f"{name} failed ({rc}): {self._cdll.mapdit_last_error().decode()}")
+        call.__name__ = name
+        return call
+
+
+def lib() -> _Lib:
+    """The loaded library; raises if it has not been built (no fallback path exists)."""
+    global _handle
+    with _lock:
+        if _handle is None:
+            if not os.path.exists(LIB_PATH):
+                raise MapditError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  f"or `make -C {CSRC}`; there is no CPU fallback")
+            _handle = _Lib(C.CDLL(LIB_PATH))
+        return _handle
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,299 @@
+// Cosine attention forward/backward on v_mfma_f32_32x32x16_bf16.
+// Replaces F.scaled_dot_product_attention(q^, k^, v, scale=1/sqrt(hd)) of reference src/layers/attention.py:47
+// and its autograd.  q^, k^ are already cosine-normalised (qkv_split_kernel), so logits lie in [-sqrt(hd), sqrt(hd)]
+// and the softmax needs no running maximum: the whole key range of a head (T <= 256 tokens) is processed in one
+// sweep with S kept in registers.
+//
+// All products are arranged so that the reduction index of the *next* product is the register (row) index of
+// the previous accumulator tile, which lets an accumulator be re-used as an MFMA A operand with no LDS round
+// trip (guide §3 "An accumulator tile as the next MFMA's operand"):
+//   forward      S^T = K Q^T (key on rows, query on lanes) -> P^T -> O = (P^T)^T V         needs V^T  [d][key]
+//   backward dQ  S^T, dP^T = V dO^T -> dS^T -> dQ = (dS^T)^T K                              needs K^T  [d][key]
+//   backward dKV S = Q K^T (query on rows, key on lanes), dP = dO V^T -> dV = P^T dO, dK = dS^T Q
+//                                                                                  needs dO^T, Q^T [d][query]
+// Every operand is therefore read K-contiguous; the transposed images come from the head-split kernels.
+// The backward is two passes (7 products instead of 5) so no cross-wave reduction and no atomics are needed:
+// attention is ~5 % of the block's FLOPs.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
+    union { uint32_t u[4]; bf16x8_t v; } r;
+    r.u[0] = pack2bf(a[base + 0], a[base + 1]);
+    r.u[1] = pack2bf(a[base + 2], a[base + 3]);
+    r.u[2] = pack2bf(a[base + 4], a[base + 5]);
+    r.u[3] = pack2bf(a[base + 6], a[base + 7]);
+    return r.v;
+}
+
+// Row-major [rows][64] bf16 tile in LDS, 128-B rows, 16-B chunks XOR-swizzled by (row & 7).
+template <int NTHREADS>
+__device__ __forceinline__ void stage_rows(char* tile, const bf16_t* __restrict__ src, long ld, int rows, int tid) {
+    for (int i = tid; i < rows * 8; i += NTHREADS) {
+        const int row = i >> 3, c = i & 7;
+        uint4 v = *(const uint4*)(src + (size_t)row * ld + c * 8);
+        *(uint4*)(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+}
+// A-operand fragment of 32x32x16: lane (r, h) holds [row0 + r][16 ks + 8 h + 0..7].
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
+    return *(const bf16x8_t*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+}
+// Transposed image [64 d][T] bf16 in LDS with rows padded to 2T+8 bytes (conflict-free 8-byte column reads).
+template <int T, int NTHREADS>
+__device__ __forceinline__ void stage_tr(char* tile, const bf16_t* __restrict__ src, int tid) {
+    constexpr int VLD = 2 * T + 8, VC = T / 8;
+    for (int i = tid; i < 64 * VC; i += NTHREADS) {
+        const int row = i / VC, c = i % VC;
+        uint4 v = *(const uint4*)(src + (size_t)row * T + c * 8);
+        uint2* d = (uint2*)(tile + row * VLD + c * 16);
+        d[0] = make_uint2(v.x, v.y);
+        d[1] = make_uint2(v.z, v.w);
+    }
+}
+// B-operand fragment whose k order matches pack8() of an accumulator tile:
+// element j of lane (r, h) is [d = d0 + r][k = kbase + 8 (j >> 2) + 4 h + (j & 3)].
+template <int T>
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int d0, int kbase, int lane) {
+    constexpr int VLD = 2 * T + 8;
+    const char* p = tile + (d0 + (lane & 31)) * VLD + (kbase + 4 * (lane >> 5)) * 2;
+    union { uint2 u[2]; bf16x8_t v; } r;
+    r.u[0] = *(const uint2*)p;
+    r.u[1] = *(const uint2*)(p + 16);
+    return r.v;
+}
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+template <int T> struct Geo {
+    static constexpr int NW = T >= 128 ? 4 : T / 32;   // waves per workgroup, 32 owner rows each
+    static constexpr int NTH = NW * 64;
+    static constexpr int NT = T / 32;
+    static constexpr int VLD = 2 * T + 8;
+};
+
+// ---- forward -----------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                              const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
+                                                              float* __restrict__ lse, int H, float scale) {
+    using G = Geo<T>;
+    __shared__ __attribute__((aligned(16))) char smem[T * 128 + 64 * G::VLD];
+    char* ks_ = smem;
+    char* vs_ = smem + T * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.y;
+    const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
+    stage_rows<G::NTH>(ks_, kn + bh * T * 64, 64, T, tid);
+    stage_tr<T, G::NTH>(vs_, vt + bh * 64 * T, tid);
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
+    __syncthreads();
+
+    f32x16_t s[G::NT];
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < G::NT; ++kt) {
+        f32x16_t a = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
+        s[kt] = a;
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+
+    f32x16_t oa[2] = {};
+#pragma unroll
+    for (int kt = 0; kt < G::NT; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pa = pack8(s[kt], 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
+        }
+    const int b = (int)(bh / H), hh = (int)(bh % H);
+    const int D = H * 64;
+    const float inv_l = 1.f / lsum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int qr = acc_row(i, lane);
+        const float il = __shfl(inv_l, qr, 64);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[((size_t)b * T + q0 + qr) * D + hh * 64 + 32 * dt + r] = f2bf(oa[dt][i] * il);
+    }
+    if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
+}
+
+// ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                 const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt_,
+                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, bf16_t* __restrict__ dqn,
+                                                                 int H, float scale) {
+    using G = Geo<T>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 64 * G::VLD];
+    char* ks_ = smem;
+    char* vs_ = smem + T * 128;
+    char* kts_ = smem + 2 * T * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.y;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
+    const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
+    stage_rows<G::NTH>(ks_, kn + bh * T * 64, 64, T, tid);
+    stage_rows<G::NTH>(vs_, v + bh * T * 64, 64, T, tid);
+    stage_tr<T, G::NTH>(kts_, kt_ + bh * 64 * T, tid);
+    bf16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
+        dof[ks] = *(const bf16x8_t*)(dO + ((size_t)b * T + q0 + r) * D + hh * 64 + 16 * ks + 8 * h2);
+    }
+    const float lse_q = lse[bh * T + q0 + r], del_q = delta[bh * T + q0 + r];
+    __syncthreads();
+
+    f32x16_t dq[2] = {};
+#pragma unroll 1
+    for (int kt = 0; kt < G::NT; ++kt) {
+        f32x16_t st = {}, dp = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __expf(st[i] * scale - lse_q);
+            st[i] = p * (dp[i] - del_q) * scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t a = pack8(st, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int qr = acc_row(i, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dqn[(bh * T + q0 + qr) * 64 + 32 * dt + r] = f2bf(dq[dt][i]);
+    }
+}
+
+// ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ qt_,
+                                                                  const bf16_t* __restrict__ dO, const bf16_t* __restrict__ doT,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
+                                                                  float scale) {
+    using G = Geo<T>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 2 * 64 * G::VLD + 2 * T * 4];
+    char* qs_ = smem;
+    char* dos_ = smem + T * 128;
+    char* qts_ = smem + 2 * T * 128;
+    char* dots_ = qts_ + 64 * G::VLD;
+    float* lse_s = (float*)(dots_ + 64 * G::VLD);
+    float* del_s = lse_s + T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.y;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
+    const int k0 = blockIdx.x * 32 * G::NW + wave * 32;
+    stage_rows<G::NTH>(qs_, qn + bh * T * 64, 64, T, tid);
+    stage_rows<G::NTH>(dos_, dO + (size_t)b * T * D + hh * 64, D, T, tid);
+    stage_tr<T, G::NTH>(qts_, qt_ + bh * 64 * T, tid);
+    stage_tr<T, G::NTH>(dots_, doT + bh * 64 * T, tid);
+    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *(const bf16x8_t*)(kn + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+        vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+    }
+    __syncthreads();
+
+    f32x16_t dk[2] = {}, dvv[2] = {};
+#pragma unroll 1
+    for (int qt = 0; qt < G::NT; ++qt) {
+        f32x16_t s = {}, dp = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = 32 * qt + acc_row(i, lane);
+            const float p = __expf(s[i] * scale - lse_s[qr]);
+            s[i] = p;
+            dp[i] = p * (dp[i] - del_s[qr]) * scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(dots_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<T>(qts_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kr = acc_row(i, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dkn[(bh * T + k0 + kr) * 64 + 32 * dt + r] = f2bf(dk[dt][i]);
+            dv[(bh * T + k0 + kr) * 64 + 32 * dt + r] = f2bf(dvv[dt][i]);
+        }
+    }
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(T_, CALL)                                                         \
+    switch (T_) {                                                                       \
+        case 64: { constexpr int TT = 64; CALL; break; }                                \
+        case 128: { constexpr int TT = 128; CALL; break; }                              \
+        case 256: { constexpr int TT = 256; CALL; break; }                              \
+        default: mapdit_set_error("attention: T=%d unsupported (64, 128, 256)", T_); return MAPDIT_ERR_ARG; \
+    }
+
+extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* vt, uint16_t* o, float* lse,
+                                   int B, int T, int H, int head_dim, void* stream) {
+    MD_CHECK(qn && kn && vt && o && lse, "attn_cos_fwd: null argument");
+    MD_CHECK(head_dim == 64, "attn_cos_fwd: head_dim=%d unsupported (64 only: DiT-XS/S/B/L)", head_dim);
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, vt, o, lse, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* qt,
+                                   const uint16_t* kt, const uint16_t* dO, const uint16_t* doT, const float* lse,
+                                   const float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+                                   int head_dim, void* stream) {
+    MD_CHECK(qn && kn && v && qt && kt && dO && doT && lse && delta && dqn && dkn && dv, "attn_cos_bwd: null argument");
+    MD_CHECK(head_dim == 64, "attn_cos_bwd: head_dim=%d unsupported (64 only)", head_dim);
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, kt, dO, lse, delta, dqn, H, scale));
+    MD_LAUNCH_CHECK();
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, qt, dO, doT, lse, delta, dkn, dv, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}

@@ -1,0 +1,239 @@
+// Input / conditioning / output-side kernels of DiT (SURVEY.md K9, K10, K11 and their backward).
+// All are small or HBM-bound; the FLOP-carrying parts go through mapdit_gemm_bf16.
+#include "common.h"
+
+namespace {
+
+#define C5 0.70710678118654752f   // mp_sum(a, b, 0.5) = (a + b) * 0.5 / sqrt(0.5)   (src/utils.py:15-16, dit.py:84,88)
+
+// ---- patchify + ones column + x_embedder + mp_sum with pos_embed (reference src/dit.py:81-84) --------------------
+// x [N,C,S,S] fp32, w [D][P+1] fp32 effective weight, pos [T][D]; out x0 [M,D] fp32; patches [M][ldp] bf16
+// (zero padded to ldp, ones column at index P) kept for the dW GEMM.  Block = 64 tokens x 128 features.
+__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ pos, float* __restrict__ out,
+                                                            bf16_t* __restrict__ patches, int ldp, int C, int S, int p,
+                                                            int D, long M) {
+    extern __shared__ float sm[];
+    const int P = p * p * C, P1 = P + 1, grid = S / p, T = grid * grid;
+    float* ws = sm;                    // [P1][128]
+    float* ps = sm + P1 * 128;         // [64][P1]
+    const long m0 = (long)blockIdx.x * 64;
+    const int d0 = blockIdx.y * 128;
+    for (int i = threadIdx.x; i < P1 * 128; i += 256) {
+        const int j = i / 128, d = i % 128;
+        ws[i] = w[(size_t)(d0 + d) * P1 + j];
+    }
+    for (int i = threadIdx.x; i < 64 * P1; i += 256) {
+        const int tok = i / P1, j = i % P1;
+        const long m = m0 + tok;
+        float v = 0.f;
+        if (m < M) {
+            if (j == P) v = 1.f;
+            else {
+                const int n = (int)(m / T), t = (int)(m % T), hy = t / grid, wx = t % grid;
+                const int c = j % C, p2 = (j / C) % p, p1 = j / (C * p);
+                v = x[(((size_t)n * C + c) * S + hy * p + p1) * S + wx * p + p2];
+            }
+        }
+        ps[i] = v;
+    }
+    __syncthreads();
+    if (patches && blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < 64 * ldp; i += 256) {
+            const int tok = i / ldp, j = i % ldp;
+            if (m0 + tok < M) patches[(m0 + tok) * ldp + j] = f2bf(j < P1 ? ps[tok * P1 + j] : 0.f);
+        }
+    }
+    const int d = threadIdx.x & 127;
+    for (int tok = threadIdx.x >> 7; tok < 64; tok += 2) {
+        const long m = m0 + tok;
+        if (m >= M) break;
+        float a = 0.f;
+        for (int j = 0; j < P1; ++j) a += ps[tok * P1 + j] * ws[j * 128 + d];
+        out[m * D + d0 + d] = (a + pos[(size_t)(m % T) * D + d0 + d]) * C5;
+    }
+}
+
+// ---- timestep Fourier features (reference src/blocks/timestep_embedder.py:18-21) ---------------------------------
+__global__ void fourier_kernel(const long* __restrict__ t, const float* __restrict__ scale, const float* __restrict__ shift,
+                               bf16_t* __restrict__ out, int n, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * F) return;
+    const int b = i / F, f = i % F;
+    const float arg = (float)t[b] * scale[f] + shift[f];
+    out[i] = f2bf(1.41421356237309515f * cosf(arg));
+}
+
+// ---- c = mp_sum(t_emb, y_emb, 0.5); also MPSiLU(c) and c as bf16 GEMM operands (dit.py:86-88) ------------------------
+__global__ void cond_combine_kernel(const float* __restrict__ temb, const float* __restrict__ table, const long* __restrict__ y,
+                                    float* __restrict__ c, bf16_t* __restrict__ c_silu, bf16_t* __restrict__ c_bf, int n, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int b = i / D, d = i % D;
+    const float v = (temb[i] + table[(size_t)y[b] * D + d]) * C5;
+    c[i] = v;
+    c_silu[i] = f2bf(silu_f(v) * (1.f / MP_SILU_DIV));
+    c_bf[i] = f2bf(v);
+}
+
+// Backward of the above: dc = dcs * dmpsilu(c) + dc_direct;  dtemb = C5*dc (bf16 operand);  dtable[y] += C5*dc.
+__global__ void cond_combine_bwd_kernel(const float* __restrict__ c, const float* __restrict__ dcs, const float* __restrict__ dcd,
+                                        const long* __restrict__ y, bf16_t* __restrict__ dtemb, float* __restrict__ dtable,
+                                        int n, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int b = i / D, d = i % D;
+    const float dc = (dcs[i] * dmpsilu_f(c[i]) + dcd[i]) * C5;
+    dtemb[i] = f2bf(dc);
+    atomicAdd(dtable + (size_t)y[b] * D + d, dc);
+}
+
+// ---- final layer tail: MPScale gates + unpatchify + concat (final_layer.py:20-22,57-59; dit.py:96-101) ---------------
+// lin [M][ldl] fp32 (mean chunk at columns 0..P-1, sigma chunk at P..2P-1); a_* [N][8] fp32; out [N,2C,S,S].
+__device__ __forceinline__ float gate_of(const float* a, const float* ref) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j] * ref[j];
+    s *= 0.35355339059327379f;   // 1/sqrt(8)
+    return 1.f / (1.f + __expf(-s));
+}
+__global__ void final_out_kernel(const float* __restrict__ lin, int ldl, const float* __restrict__ a_mean,
+                                 const float* __restrict__ a_sigma, const float* __restrict__ ref_mean,
+                                 const float* __restrict__ ref_sigma, float* __restrict__ out, int N, int C, int S, int p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * 2 * C * S * S;
+    if (i >= total) return;
+    const int xx = (int)(i % S), yy = (int)((i / S) % S), ch = (int)((i / ((long)S * S)) % (2 * C)), n = (int)(i / ((long)S * S * 2 * C));
+    const int grid = S / p, P = p * p * C;
+    const int t = (yy / p) * grid + xx / p;
+    const int c = ch % C, chunk = ch / C;
+    const int j = ((yy % p) * p + (xx % p)) * C + c;
+    const float g = chunk == 0 ? gate_of(a_mean + n * 8, ref_mean) : gate_of(a_sigma + n * 8, ref_sigma);
+    out[i] = lin[((size_t)n * grid * grid + t) * ldl + chunk * P + j] * g;
+}
+
+// Backward: one block per sample.  dlin [M][ldd] bf16 = dout*gate (patchified; columns >= 2P stay zero),
+// da_*[n][8] (bf16 operand + fp32), dref_* accumulated atomically over samples.
+__global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ lin, int ldl,
+                                                          const float* __restrict__ a_mean, const float* __restrict__ a_sigma,
+                                                          const float* __restrict__ ref_mean, const float* __restrict__ ref_sigma,
+                                                          bf16_t* __restrict__ dlin, int ldd, bf16_t* __restrict__ da_bf,
+                                                          float* __restrict__ dref_mean, float* __restrict__ dref_sigma,
+                                                          int C, int S, int p) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    const int grid = S / p, P = p * p * C, T = grid * grid;
+    const float gm = gate_of(a_mean + n * 8, ref_mean), gs = gate_of(a_sigma + n * 8, ref_sigma);
+    float sm = 0.f, ss = 0.f;
+    const int per = 2 * C * S * S;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int xx = e % S, yy = (e / S) % S, ch = e / (S * S);
+        const int t = (yy / p) * grid + xx / p, c = ch % C, chunk = ch / C;
+        const int j = ((yy % p) * p + (xx % p)) * C + c;
+        const float go = dout[(size_t)n * per + e];
+        const float l = lin[((size_t)n * T + t) * ldl + chunk * P + j];
+        if (chunk == 0) sm += go * l; else ss += go * l;
+        dlin[((size_t)n * T + t) * ldd + chunk * P + j] = f2bf(go * (chunk == 0 ? gm : gs));
+    }
+    sm = wave_sum(sm);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int which = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const float dg = red[which][0] + red[which][1] + red[which][2] + red[which][3];
+        const float g = which == 0 ? gm : gs;
+        const float dang = dg * g * (1.f - g) * 0.35355339059327379f;
+        const float* ref = which == 0 ? ref_mean : ref_sigma;
+        const float* a = (which == 0 ? a_mean : a_sigma) + n * 8;
+        da_bf[((size_t)which * gridDim.x + n) * 8 + j] = f2bf(dang * ref[j]);
+        atomicAdd((which == 0 ? dref_mean : dref_sigma) + j, dang * a[j]);
+    }
+}
+
+// forward_with_cfg tail (reference src/dit.py:113-118): eps = u + s (c - u) on the first C channels, both halves.
+__global__ void cfg_combine_kernel(const float* __restrict__ in, float* __restrict__ out, int n_total, int C, int HW, float s) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)2 * C * HW;
+    if (i >= (long)n_total * per) return;
+    const int n = (int)(i / per);
+    const long e = i % per;
+    if (e >= (long)C * HW) { out[i] = in[i]; return; }
+    const int half = n_total / 2, nc = n % half;
+    const float cond = in[(long)nc * per + e], unc = in[(long)(nc + half) * per + e];
+    out[i] = unc + s * (cond - unc);
+}
+
+}  // namespace
+
+extern "C" int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
+                                      int ldp, int N, int C, int S, int p, int D, void* stream) {
+    MD_CHECK(x && w_eff && pos && out, "patch_embed_fwd: null argument");
+    MD_CHECK(S % p == 0 && D % 128 == 0, "patch_embed_fwd: S=%d p=%d D=%d unsupported", S, p, D);
+    const int P1 = p * p * C + 1, T = (S / p) * (S / p);
+    MD_CHECK(!patches || ldp >= P1, "patch_embed_fwd: ldp=%d too small", ldp);
+    const long M = (long)N * T;
+    const size_t shm = (size_t)(P1 * 128 + 64 * P1) * 4;
+    MD_CHECK(shm <= 64 * 1024, "patch_embed_fwd: patch dim %d too large", P1 - 1);
+    hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv(M, 64), D / 128), dim3(256), shm, (hipStream_t)stream, x, w_eff, pos,
+                       out, patches, ldp, C, S, p, D, M);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift, uint16_t* out, int n, int F,
+                                  void* stream) {
+    MD_CHECK(t && scale && shift && out && n > 0, "fourier_fwd: null/empty argument");
+    hipLaunchKernelGGL(fourier_kernel, dim3(cdiv((long)n * F, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)t, scale,
+                       shift, out, n, F);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
+                                       uint16_t* c_bf, int n, int D, void* stream) {
+    MD_CHECK(temb && table && y && c && c_silu && c_bf && n > 0, "cond_combine_fwd: null/empty argument");
+    hipLaunchKernelGGL(cond_combine_kernel, dim3(cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, temb, table,
+                       (const long*)y, c, c_silu, c_bf, n, D);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
+                                       float* dtable, int n, int D, void* stream) {
+    MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0, "cond_combine_bwd: null/empty argument");
+    hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3(cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd,
+                       (const long*)y, dtemb, dtable, n, D);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
+                                    const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream) {
+    MD_CHECK(lin && a_mean && a_sigma && ref_mean && ref_sigma && out, "final_out_fwd: null argument");
+    const long total = (long)N * 2 * C * S * S;
+    hipLaunchKernelGGL(final_out_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, lin, ldl, a_mean, a_sigma,
+                       ref_mean, ref_sigma, out, N, C, S, p);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
+                                    const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
+                                    float* dref_mean, float* dref_sigma, int N, int C, int S, int p, void* stream) {
+    MD_CHECK(dout && lin && a_mean && a_sigma && ref_mean && ref_sigma && dlin && da_bf && dref_mean && dref_sigma,
+             "final_out_bwd: null argument");
+    hipLaunchKernelGGL(final_out_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dout, lin, ldl, a_mean, a_sigma,
+                       ref_mean, ref_sigma, dlin, ldd, da_bf, dref_mean, dref_sigma, C, S, p);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_cfg_combine(const float* model_out, float* out, int n_total, int C, int HW, float cfg_scale, void* stream) {
+    MD_CHECK(model_out && out && n_total > 0 && n_total % 2 == 0, "cfg_combine: batch must be even and non-empty");
+    const long total = (long)n_total * 2 * C * HW;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, model_out, out, n_total, C,
+                       HW, cfg_scale);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}

@@ -1,0 +1,485 @@
+// The DiT engine: sequences the whole network forward and backward from C++ on one HIP stream
+// (reference src/dit.py:70-105, src/blocks/dit_block.py:32-37, src/blocks/final_layer.py:53-61 and their autograd).
+// No device allocation happens here: every buffer is carved out of the caller's workspace, so a forward or a
+// backward is a pure sequence of kernel launches and can be captured into a hipGraph.
+//
+// Precision plan: master weights fp32; GEMM operands bf16 (weights re-imaged from the masters every training step by
+// the weight-norm pass); accumulation fp32; residual stream and per-sample conditioning vectors fp32.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int FOURIER = 256;
+constexpr int NSCALE = 8;
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <class T> T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct BlockBufs {
+    // saved for backward (train) / scratch (eval)
+    float* mod;       // [N][6D]
+    bf16_t *xm, *qkv, *qn, *kn, *v, *qt, *kt, *o, *y, *xm2, *hpre, *hact, *y2;
+    float* lse;       // [N*H][T]
+};
+
+struct WeightImg {
+    bf16_t* img = nullptr;   // bf16 effective weight [rows_alloc][cols]
+    int rows = 0, cols = 0;
+};
+
+}  // namespace
+
+struct mapdit_engine {
+    mapdit_config_t cfg;
+    int train;
+    int T, P, P1, ldp, D, Hm, heads, M_max;
+    int last_N = 0;
+    bool have_saved = false;
+    std::vector<float*> params, grads;
+    // weight images
+    std::vector<WeightImg> wimg;          // indexed like the parameter table (linears only)
+    float* wx_eff;                        // x_embedder effective weight fp32 [D][P1]
+    float* table_eff;                     // normalised label table fp32 [rows][D]
+    // conditioning
+    bf16_t *four, *h1_pre, *h1_act, *c_silu, *c_bf;
+    float *temb, *c;
+    const int64_t* y_saved = nullptr;
+    int64_t* y_copy;
+    // residual stream checkpoints
+    std::vector<float*> X;
+    std::vector<BlockBufs> blk;
+    bf16_t* vt;                           // scratch V^T
+    bf16_t* patches;
+    // final layer
+    float *fmod, *lin, *a_mean, *a_sigma;
+    bf16_t* xmodf;
+    // backward scratch
+    float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
+    bf16_t *dy, *dh, *dxm, *dO, *doT, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
+    size_t zero_bytes_dlin;
+};
+
+namespace {
+
+int pidx_block(int i, int which) { return MAPDIT_NUM_GLOBAL + i * MAPDIT_NUM_BLOCK + which; }
+
+// Lay out every buffer; with base == nullptr this only measures.
+size_t carve(mapdit_engine* e, void* base) {
+    const mapdit_config_t& c = e->cfg;
+    const int D = c.hidden, L = c.depth, N = c.max_batch, T = e->T, Hm = c.mlp_hidden;
+    const size_t M = (size_t)N * T;
+    Carver cv(base);
+    const int np = MAPDIT_NUM_GLOBAL + L * MAPDIT_NUM_BLOCK;
+    e->wimg.assign(np, WeightImg());
+    auto img = [&](int idx, int rows, int cols, int rows_alloc) {
+        e->wimg[idx].img = cv.take<bf16_t>((size_t)rows_alloc * cols);
+        e->wimg[idx].rows = rows;
+        e->wimg[idx].cols = cols;
+    };
+    img(MAPDIT_P_T0, D, FOURIER, D);
+    img(MAPDIT_P_T2, D, D, D);
+    img(MAPDIT_P_F_LIN, 2 * e->P, D, 64 > 2 * e->P ? 64 : 2 * e->P);
+    img(MAPDIT_P_F_MOD, 2 * D, D, 2 * D);
+    img(MAPDIT_P_MS_LIN, NSCALE, D, NSCALE);
+    img(MAPDIT_P_SS_LIN, NSCALE, D, NSCALE);
+    for (int i = 0; i < L; ++i) {
+        img(pidx_block(i, MAPDIT_B_QKV), 3 * D, D, 3 * D);
+        img(pidx_block(i, MAPDIT_B_PROJ), D, D, D);
+        img(pidx_block(i, MAPDIT_B_FC1), Hm, D, Hm);
+        img(pidx_block(i, MAPDIT_B_FC2), D, Hm, D);
+        img(pidx_block(i, MAPDIT_B_MOD), 6 * D, D, 6 * D);
+    }
+    e->wx_eff = cv.take<float>((size_t)D * e->P1);
+    e->table_eff = cv.take<float>((size_t)c.table_rows * D);
+    e->four = cv.take<bf16_t>((size_t)N * FOURIER);
+    e->h1_pre = cv.take<bf16_t>((size_t)N * D);
+    e->h1_act = cv.take<bf16_t>((size_t)N * D);
+    e->c_silu = cv.take<bf16_t>((size_t)N * D);
+    e->c_bf = cv.take<bf16_t>((size_t)N * D);
+    e->temb = cv.take<float>((size_t)N * D);
+    e->c = cv.take<float>((size_t)N * D);
+    e->y_copy = cv.take<int64_t>(N);
+    const int nx = e->train ? 2 * L + 1 : 3;
+    e->X.assign(nx, nullptr);
+    for (int i = 0; i < nx; ++i) e->X[i] = cv.take<float>(M * D);
+    const int nb = e->train ? L : 1;
+    e->blk.assign(nb, BlockBufs());
+    for (int i = 0; i < nb; ++i) {
+        BlockBufs& b = e->blk[i];
+        b.mod = cv.take<float>((size_t)N * 6 * D);
+        b.xm = cv.take<bf16_t>(M * D);
+        b.qkv = cv.take<bf16_t>(M * 3 * D);
+        b.qn = cv.take<bf16_t>(M * D);
+        b.kn = cv.take<bf16_t>(M * D);
+        b.v = cv.take<bf16_t>(M * D);
+        b.qt = e->train ? cv.take<bf16_t>(M * D) : nullptr;
+        b.kt = e->train ? cv.take<bf16_t>(M * D) : nullptr;
+        b.o = cv.take<bf16_t>(M * D);
+        b.y = e->train ? cv.take<bf16_t>(M * D) : nullptr;
+        b.xm2 = cv.take<bf16_t>(M * D);
+        b.hpre = e->train ? cv.take<bf16_t>(M * Hm) : nullptr;
+        b.hact = cv.take<bf16_t>(M * Hm);
+        b.y2 = e->train ? cv.take<bf16_t>(M * D) : nullptr;
+        b.lse = cv.take<float>((size_t)N * c.num_heads * T);
+    }
+    e->vt = cv.take<bf16_t>(M * D);
+    e->patches = e->train ? cv.take<bf16_t>(M * e->ldp) : nullptr;
+    e->fmod = cv.take<float>((size_t)N * 2 * D);
+    e->lin = cv.take<float>(M * 2 * e->P);
+    e->a_mean = cv.take<float>((size_t)N * NSCALE);
+    e->a_sigma = cv.take<float>((size_t)N * NSCALE);
+    e->xmodf = cv.take<bf16_t>(M * D);
+    if (e->train) {
+        size_t gmax = (size_t)6 * D * D;
+        if ((size_t)Hm * D > gmax) gmax = (size_t)Hm * D;
+        if ((size_t)D * FOURIER > gmax) gmax = (size_t)D * FOURIER;
+        if ((size_t)D * e->ldp > gmax) gmax = (size_t)D * e->ldp;
+        e->G = cv.take<float>(gmax);
+        e->DXa = cv.take<float>(M * D);
+        e->DXb = cv.take<float>(M * D);
+        e->dmod = cv.take<float>((size_t)L * N * 6 * D);
+        e->dfmod = cv.take<float>((size_t)N * 2 * D);
+        e->dcs = cv.take<float>((size_t)N * D);
+        e->dcd = cv.take<float>((size_t)N * D);
+        e->dtable = cv.take<float>((size_t)c.table_rows * D);
+        e->delta = cv.take<float>((size_t)N * c.num_heads * T);
+        e->gain_part = cv.take<float>((size_t)N * (D / 128));
+        e->dy = cv.take<bf16_t>(M * D);
+        e->dh = cv.take<bf16_t>(M * Hm);
+        e->dxm = cv.take<bf16_t>(M * D);
+        e->dO = cv.take<bf16_t>(M * D);
+        e->doT = cv.take<bf16_t>(M * D);
+        e->dqn = cv.take<bf16_t>(M * D);
+        e->dkn = cv.take<bf16_t>(M * D);
+        e->dv = cv.take<bf16_t>(M * D);
+        e->dqkv = cv.take<bf16_t>(M * 3 * D);
+        e->dlin = cv.take<bf16_t>(M * 64);
+        e->zero_bytes_dlin = M * 64 * sizeof(bf16_t);
+        e->da_bf = cv.take<bf16_t>((size_t)2 * N * NSCALE);
+        e->dmod_bf = cv.take<bf16_t>((size_t)N * 6 * D);
+        e->dx0_bf = cv.take<bf16_t>(M * D);
+        e->dtemb_bf = cv.take<bf16_t>((size_t)N * D);
+        e->dh1_bf = cv.take<bf16_t>((size_t)N * D);
+    }
+    return (cv.off + 255) & ~(size_t)255;
+}
+
+int check_cfg(const mapdit_config_t* c) {
+    MD_CHECK(c, "engine: null config");
+    MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
+    MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
+    MD_CHECK(c->hidden % c->num_heads == 0 && c->hidden / c->num_heads == 64,
+             "engine: head_dim=%d unsupported (64 only: DiT-XS/S/B/L; XL has 72)", c->hidden / (c->num_heads ? c->num_heads : 1));
+    MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
+    const int g = c->input_size / c->patch, T = g * g;
+    MD_CHECK(T == 64 || T == 128 || T == 256, "engine: %d tokens per sample unsupported (64, 128, 256)", T);
+    MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
+    MD_CHECK(2 * c->patch * c->patch * c->in_channels <= 64 && (c->patch * c->patch * c->in_channels) % 4 == 0,
+             "engine: patch dim %d unsupported", c->patch * c->patch * c->in_channels);
+    return MAPDIT_OK;
+}
+
+void init_dims(mapdit_engine* e) {
+    const mapdit_config_t& c = e->cfg;
+    const int g = c.input_size / c.patch;
+    e->T = g * g;
+    e->P = c.patch * c.patch * c.in_channels;
+    e->P1 = e->P + 1;
+    e->ldp = (e->P1 + 7) & ~7;
+    e->D = c.hidden;
+    e->Hm = c.mlp_hidden;
+    e->heads = c.num_heads;
+    e->M_max = c.max_batch * e->T;
+}
+
+#define TRY(call)                    \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != MAPDIT_OK) return rc_; \
+    } while (0)
+
+int gemm(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, const mapdit_epilogue_t& ep, void* st) {
+    return mapdit_gemm_bf16(layout, M, N, K, A, lda, B, ldb, &ep, st);
+}
+mapdit_epilogue_t epi_bf16(bf16_t* out, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_STORE_BF16; e.out = out; e.ldo = ldo; e.alpha = 1.f; return e;
+}
+mapdit_epilogue_t epi_f32(float* out, int ldo, float alpha = 1.f, int acc = 0) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_STORE_F32; e.out = out; e.ldo = ldo; e.alpha = alpha; e.accumulate = acc; return e;
+}
+mapdit_epilogue_t epi_silu2(bf16_t* pre, bf16_t* act, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_SILU2; e.out = pre; e.out2 = act; e.ldo = ldo; return e;
+}
+mapdit_epilogue_t epi_dsilu(bf16_t* out, const bf16_t* pre, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_DSILU; e.out = out; e.aux = pre; e.ldo = ldo; return e;
+}
+const float CA = 0.7f / sqrtf(0.58f), CB = 0.3f / sqrtf(0.58f);   // mp_sum(x, y, 0.3): src/utils.py:15-16
+mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_RESID; e.out = y; e.out2 = xout; e.aux = xin; e.gate = gate; e.ldg = ldg; e.rows_per_sample = rows;
+    e.ldo = ldo; e.alpha = CA; e.beta = CB; return e;
+}
+
+// dW for one linear: G = dy^T x (TN GEMM into scratch), then the weight-norm Jacobian into the bound grad.
+int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf16_t* x, int ld_x, int K, float alpha, void* st) {
+    const WeightImg& w = e->wimg[pidx];
+    TRY(gemm(MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, epi_f32(e->G, w.cols, alpha), st));
+    if (e->grads[pidx]) TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
+    return MAPDIT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int train) {
+    if (check_cfg(cfg) != MAPDIT_OK) return 0;
+    mapdit_engine tmp;
+    tmp.cfg = *cfg;
+    tmp.train = train;
+    init_dims(&tmp);
+    return carve(&tmp, nullptr);
+}
+
+extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void* workspace, size_t workspace_bytes, void* stream,
+                                    mapdit_engine_t** out) {
+    TRY(check_cfg(cfg));
+    MD_CHECK(workspace && out, "engine_create: null argument");
+    MD_CHECK(((uintptr_t)workspace & 255) == 0, "engine_create: workspace must be 256-byte aligned");
+    mapdit_engine* e = new mapdit_engine();
+    e->cfg = *cfg;
+    e->train = train;
+    init_dims(e);
+    const size_t need = carve(e, workspace);
+    if (need > workspace_bytes) {
+        delete e;
+        mapdit_set_error("engine_create: workspace %zu B < required %zu B", workspace_bytes, need);
+        return MAPDIT_ERR_ARG;
+    }
+    const int np = MAPDIT_NUM_GLOBAL + cfg->depth * MAPDIT_NUM_BLOCK;
+    e->params.assign(np, nullptr);
+    e->grads.assign(np, nullptr);
+    // Padding rows of the final-linear image and padding columns of dlin must be (and stay) zero.
+    const WeightImg& fl = e->wimg[MAPDIT_P_F_LIN];
+    hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)(64 > fl.rows ? 64 : fl.rows) * fl.cols * sizeof(bf16_t), (hipStream_t)stream);
+    if (he == hipSuccess && train) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
+    if (he != hipSuccess) {
+        delete e;
+        mapdit_set_error("engine_create: memset failed: %s", hipGetErrorString(he));
+        return MAPDIT_ERR_HIP;
+    }
+    *out = e;
+    return MAPDIT_OK;
+}
+
+extern "C" void mapdit_engine_destroy(mapdit_engine_t* e) { delete e; }
+
+extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host, float* const* grads_host) {
+    MD_CHECK(e && params_host, "engine_bind: null argument");
+    const size_t np = e->params.size();
+    for (size_t i = 0; i < np; ++i) {
+        MD_CHECK(params_host[i], "engine_bind: parameter %zu is null", i);
+        e->params[i] = params_host[i];
+        e->grads[i] = grads_host ? grads_host[i] : nullptr;
+    }
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, void* st) {
+    MD_CHECK(e && e->params[0], "engine_prepare_weights: parameters not bound");
+    const mapdit_config_t& c = e->cfg;
+    for (size_t i = 0; i < e->wimg.size(); ++i) {
+        const WeightImg& w = e->wimg[i];
+        if (!w.img) continue;
+        TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, w.img, nullptr, nullptr, st));
+    }
+    TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_X_EMB], e->D, e->P1, forced, 1.f, nullptr, e->wx_eff, nullptr, st));
+    TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_Y_EMB], c.table_rows, e->D, forced, sqrtf((float)e->D), nullptr, e->table_eff,
+                              nullptr, st));
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const int64_t* t, const int64_t* y_eff, int N, int save,
+                                     float* out, void* st) {
+    MD_CHECK(e && x && t && y_eff && out, "engine_forward: null argument");
+    MD_CHECK(N > 0 && N <= e->cfg.max_batch, "engine_forward: batch %d outside 1..%d", N, e->cfg.max_batch);
+    MD_CHECK(!save || e->train, "engine_forward: save requested on an inference-only engine");
+    const mapdit_config_t& c = e->cfg;
+    const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads;
+    const int M = N * T;
+    auto W = [&](int idx) { return e->wimg[idx].img; };
+
+    // conditioning: c = mp_sum(t_embedder(t), y_embedder(y), 0.5)        (dit.py:86-88)
+    TRY(mapdit_fourier_fwd(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], e->four, N, FOURIER, st));
+    TRY(gemm(MAPDIT_NT, N, D, FOURIER, e->four, FOURIER, W(MAPDIT_P_T0), FOURIER, epi_silu2(e->h1_pre, e->h1_act, D), st));
+    TRY(gemm(MAPDIT_NT, N, D, D, e->h1_act, D, W(MAPDIT_P_T2), D, epi_f32(e->temb, D), st));
+    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));
+    if (save) {
+        hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
+        MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
+    }
+    // patch embedding                                                  (dit.py:81-84)
+    TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], save ? e->patches : nullptr, e->ldp, N,
+                               c.in_channels, c.input_size, c.patch, D, st));
+    for (int i = 0; i < L; ++i) {
+        BlockBufs& b = e->blk[save ? i : 0];
+        float* xin = e->X[save ? 2 * i : (2 * i) % 3];
+        float* xmid = e->X[save ? 2 * i + 1 : (2 * i + 1) % 3];
+        float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
+        float* gmsa = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)];
+        float* gmlp = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
+        // (shift, scale, gate) x 2 = MPLinearChunk(MPSiLU(c))            (dit_block.py:33)
+        TRY(gemm(MAPDIT_NT, N, 6 * D, D, e->c_silu, D, W(pidx_block(i, MAPDIT_B_MOD)), D, epi_f32(b.mod, 6 * D), st));
+        // attention branch                                              (dit_block.py:35)
+        TRY(mapdit_modulate_fwd(xin, b.mod, b.mod + D, 6 * D, gmsa, b.xm, N, T, D, st));
+        TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
+        TRY(mapdit_qkv_split(b.qkv, N, T, H, 64, b.qn, b.kn, b.v, save ? b.qt : nullptr, save ? b.kt : nullptr, e->vt, st));
+        TRY(mapdit_attn_cos_fwd(b.qn, b.kn, e->vt, b.o, b.lse, N, T, H, 64, st));
+        TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
+                 epi_resid(save ? b.y : nullptr, xin, xmid, b.mod + 2 * D, 6 * D, T, D), st));
+        // MLP branch                                                    (dit_block.py:36)
+        TRY(mapdit_modulate_fwd(xmid, b.mod + 3 * D, b.mod + 4 * D, 6 * D, gmlp, b.xm2, N, T, D, st));
+        TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2(save ? b.hpre : nullptr, b.hact, Hm), st));
+        TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
+                 epi_resid(save ? b.y2 : nullptr, xmid, xout, b.mod + 5 * D, 6 * D, T, D), st));
+    }
+    float* xL = e->X[save ? 2 * L : (2 * L) % 3];
+    // final layer                                                       (final_layer.py:53-59, dit.py:96-101)
+    TRY(gemm(MAPDIT_NT, N, 2 * D, D, e->c_silu, D, W(MAPDIT_P_F_MOD), D, epi_f32(e->fmod, 2 * D), st));
+    TRY(mapdit_modulate_fwd(xL, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], e->xmodf, N, T, D, st));
+    TRY(gemm(MAPDIT_NT, M, 2 * e->P, D, e->xmodf, D, W(MAPDIT_P_F_LIN), D, epi_f32(e->lin, 2 * e->P), st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_MS_LIN), D, epi_f32(e->a_mean, NSCALE), st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_SS_LIN), D, epi_f32(e->a_sigma, NSCALE), st));
+    TRY(mapdit_final_out_fwd(e->lin, 2 * e->P, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], out, N,
+                             c.in_channels, c.input_size, c.patch, st));
+    e->last_N = N;
+    e->have_saved = save != 0;
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* st) {
+    MD_CHECK(e && dout, "engine_backward: null argument");
+    MD_CHECK(e->train && e->have_saved, "engine_backward: no saved forward");
+    const mapdit_config_t& c = e->cfg;
+    const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, N = e->last_N;
+    const int M = N * T, P2 = 2 * e->P;
+    hipStream_t hs = (hipStream_t)st;
+    auto W = [&](int idx) { return e->wimg[idx].img; };
+    auto G = [&](int idx) { return e->grads[idx]; };
+    const int npart = N * (D / 128);
+
+    hipError_t he = hipMemsetAsync(e->dcs, 0, (size_t)N * D * 4, hs);
+    if (he == hipSuccess) he = hipMemsetAsync(e->dcd, 0, (size_t)N * D * 4, hs);
+    if (he == hipSuccess) he = hipMemsetAsync(e->dtable, 0, (size_t)c.table_rows * D * 4, hs);
+    if (he == hipSuccess && G(MAPDIT_P_MS_REF)) he = hipMemsetAsync(G(MAPDIT_P_MS_REF), 0, NSCALE * 4, hs);
+    if (he == hipSuccess && G(MAPDIT_P_SS_REF)) he = hipMemsetAsync(G(MAPDIT_P_SS_REF), 0, NSCALE * 4, hs);
+    MD_CHECK(he == hipSuccess, "engine_backward: memset failed: %s", hipGetErrorString(he));
+    MD_CHECK(G(MAPDIT_P_MS_REF) && G(MAPDIT_P_SS_REF), "engine_backward: gradient buffers not bound");
+
+    // ---- final layer ---------------------------------------------------------------------------------------
+    TRY(mapdit_final_out_bwd(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], e->dlin,
+                             64, e->da_bf, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size, c.patch, st));
+    for (int w = 0; w < 2; ++w) {
+        const int pi = w == 0 ? MAPDIT_P_MS_LIN : MAPDIT_P_SS_LIN;
+        const bf16_t* da = e->da_bf + (size_t)w * N * NSCALE;
+        TRY(gemm(MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
+        TRY(linear_dw(e, pi, da, NSCALE, e->c_bf, D, N, 1.f, st));
+    }
+    TRY(gemm(MAPDIT_NN, M, D, 64, e->dlin, 64, W(MAPDIT_P_F_LIN), D, epi_bf16(e->dxm, D), st));
+    TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, 64, e->xmodf, D, M, 1.f, st));
+    {
+        const BlockBufs& bl = e->blk[L - 1];
+        mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
+        a.dxm = e->dxm; a.x = e->X[2 * L]; a.shift = e->fmod; a.scale = e->fmod + D; a.gain = e->params[MAPDIT_P_F_GAIN];
+        a.ldmod = 2 * D; a.dshift = e->dfmod; a.dscale = e->dfmod + D; a.ldd = 2 * D; a.dgain_part = e->gain_part;
+        a.y_up = bl.y2; a.g_up = bl.mod + 5 * D; a.ldg_up = 6 * D; a.dy_up = e->dy;
+        a.dg_up = e->dmod + (size_t)(L - 1) * N * 6 * D + 5 * D; a.ldd_up = 6 * D;
+        a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+        TRY(mapdit_resid_mod_bwd(&a, st));
+        TRY(mapdit_reduce_partials(e->gain_part, npart, G(MAPDIT_P_F_GAIN), 0, st));
+    }
+    TRY(mapdit_f32_to_bf16(e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
+    TRY(gemm(MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
+    TRY(linear_dw(e, MAPDIT_P_F_MOD, e->dmod_bf, 2 * D, e->c_silu, D, N, 1.f, st));
+
+    // ---- blocks, last to first.  Invariant: DXa = d/d X[2i+2]; dy = grad of the MLP branch output y2_i. -----------
+    for (int i = L - 1; i >= 0; --i) {
+        const BlockBufs& b = e->blk[i];
+        float* dmod = e->dmod + (size_t)i * N * 6 * D;
+        // MLP branch
+        TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_dsilu(e->dh, b.hpre, Hm), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
+        TRY(gemm(MAPDIT_NN, M, D, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_bf16(e->dxm, D), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
+        {
+            mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
+            a.dxo = e->DXa; a.dxm = e->dxm; a.x = e->X[2 * i + 1]; a.shift = b.mod + 3 * D; a.scale = b.mod + 4 * D;
+            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = 6 * D;
+            a.dshift = dmod + 3 * D; a.dscale = dmod + 4 * D; a.ldd = 6 * D; a.dgain_part = e->gain_part;
+            a.y_up = b.y; a.g_up = b.mod + 2 * D; a.ldg_up = 6 * D; a.dy_up = e->dy; a.dg_up = dmod + 2 * D; a.ldd_up = 6 * D;
+            a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+            TRY(mapdit_resid_mod_bwd(&a, st));
+            TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), 0, st));
+        }
+        // attention branch: dy now holds the grad of the attention branch output y_i
+        TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
+        TRY(mapdit_attn_do_prep(e->dO, b.o, N, T, H, 64, e->doT, e->delta, st));
+        TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, b.qt, b.kt, e->dO, e->doT, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, 64, st));
+        TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, 64, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        TRY(gemm(MAPDIT_NN, M, D, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(e->dxm, D), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
+        {
+            mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
+            a.dxo = e->DXb; a.dxm = e->dxm; a.x = e->X[2 * i]; a.shift = b.mod; a.scale = b.mod + D;
+            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = 6 * D;
+            a.dshift = dmod; a.dscale = dmod + D; a.ldd = 6 * D; a.dgain_part = e->gain_part;
+            if (i > 0) {
+                const BlockBufs& bp = e->blk[i - 1];
+                a.y_up = bp.y2; a.g_up = bp.mod + 5 * D; a.ldg_up = 6 * D; a.dy_up = e->dy;
+                a.dg_up = e->dmod + (size_t)(i - 1) * N * 6 * D + 5 * D; a.ldd_up = 6 * D;
+                a.dx = e->DXa;
+            } else {
+                a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
+            }
+            a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+            TRY(mapdit_resid_mod_bwd(&a, st));
+            TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), 0, st));
+        }
+        // modulation linear of this block (all six gradient chunks are complete now)
+        TRY(mapdit_f32_to_bf16(dmod, e->dmod_bf, (long)N * 6 * D, 1.f, st));
+        TRY(gemm(MAPDIT_NN, N, D, 6 * D, e->dmod_bf, 6 * D, W(pidx_block(i, MAPDIT_B_MOD)), D, epi_f32(e->dcs, D, 1.f, 1), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf, 6 * D, e->c_silu, D, N, 1.f, st));
+    }
+
+    // ---- patch embedding: x0 = (x_embedder(patches) + pos) * C5 -----------------------------------------------------
+    {
+        const float c5 = 0.70710678118654752f;
+        TRY(gemm(MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, epi_f32(e->G, e->ldp, c5), st));
+        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
+    }
+    // ---- conditioning path ------------------------------------------------------------------------------------------
+    TRY(mapdit_cond_combine_bwd(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, st));
+    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
+    TRY(gemm(MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
+    TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));
+    TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));
+    e->have_saved = false;
+    return MAPDIT_OK;
+}

@@ -1,0 +1,324 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+// Replaces F.linear and its autograd (reference src/basic/mp_linear.py:46,75).  One kernel template
+// covers the three contractions of a linear layer:
+//   NT  y  = x  W^T      A rows [M][K], B rows [N][K]        (both operands K-contiguous)
+//   NN  dx = dy W        A rows [M][K], B K-major [K][N]
+//   TN  dW = dy^T x      A K-major [K][M], B K-major [K][N]
+//
+// Structure: 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16.  Operand tiles are staged HBM -> LDS with 16-byte global_load_lds
+// (LDS-DMA, no VGPR round trip) into two buffers, one barrier per K-tile, the next tile's DMA in flight
+// under the current tile's MFMAs.  The LDS image is lane-linear (a DMA constraint), so the bank-conflict
+// swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the fragment read:
+//   row-major operand  : [128 rows][128 B]  chunk16 ^= row & 7            read with ds_read_b128
+//   K-major operand    : [64 k][256 B]      chunk16 ^= (k & 7) << 1       read with ds_read_b64_tr_b16
+// The accumulators are produced transposed (MFMA "A" = the N-side operand) so that each lane owns four
+// consecutive columns of one output row; the tile is then bounced through LDS (aliasing the staging
+// buffers) so the epilogue runs on whole 8-column row chunks with fully coalesced 16/32-byte accesses.
+// Block ids are remapped so each XCD (private L2) works on a contiguous band of output tiles.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKT = 64;
+constexpr int TILE_BYTES = 16384;           // one operand tile, either layout
+constexpr int BUF_BYTES = 2 * TILE_BYTES;   // A + B
+constexpr int CS_LD = 132;                  // fp32 row stride of the epilogue tile (528 B, 16-B aligned)
+constexpr int SMEM_BYTES = BM * CS_LD * 4;  // 67,584 B >= 2 staging buffers (65,536 B)
+
+enum { OP_ROW = 0, OP_KMAJ = 1 };
+
+struct GemmP {
+    const bf16_t* A;
+    const bf16_t* B;
+    int lda, ldb;
+    int M, N, K;
+    int tiles_n;
+};
+
+// ---- staging: HBM -> LDS by LDS-DMA --------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0,
+                                           char* tile, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int seg = wave * 4 + j;                       // 1 KiB segment of the tile, wave-uniform
+        const bf16_t* src;
+        if (KIND == OP_ROW) {
+            const int row = seg * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            int grow = idx0 + row;
+            grow = grow < idx_max ? grow : idx_max - 1;     // ragged edge: re-read a valid row, result is masked
+            src = G + (size_t)grow * ld + k0 + c * 8;
+        } else {
+            const int krow = seg * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((krow & 7) << 1);
+            int col = idx0 + c * 8;
+            col = col < idx_max ? col : 0;
+            src = G + (size_t)(k0 + krow) * ld + col;
+        }
+        __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(tile + seg * 1024), 16, 0, 0);
+    }
+}
+
+// ---- fragment reads ---------------------------------------------------------------------------------
+// 16x16x32 operand fragment: lane l holds [idx = i0 + (l & 15)][k = 32 ks + 8 (l >> 4) + j], j = 0..7.
+template <int KIND>
+__device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, int lane) {
+    if (KIND == OP_ROW) {
+        const int row = i0 + (lane & 15);
+        const int c = 4 * ks + (lane >> 4);
+        return *(const bf16x8_t*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int k_a = 32 * ks + 8 * g + q, k_b = k_a + 4;
+        const int c = (i0 >> 3) + (pp >> 1);
+        const int sub = (pp & 1) << 3;
+        const int off_a = k_a * 256 + ((c ^ ((k_a & 7) << 1)) << 4) + sub;
+        const int off_b = k_b * 256 + ((c ^ ((k_b & 7) << 1)) << 4) + sub;
+        typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_a));
+        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_b));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+// ---- epilogues ----------------------------------------------------------------------------------------
+// operator()(m, n, v): v[0..7] are C[m][n..n+7]; n is a multiple of 8 and the chunk is fully in range.
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
+    uint4 u;
+    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    *(uint4*)p = u;
+}
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {
+    uint4 u = *(const uint4*)p;
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+struct EpiStoreBf16 {
+    bf16_t* out; int ldo; float alpha;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = alpha * v[i];
+        store8_bf16(out + (size_t)m * ldo + n, w);
+    }
+};
+struct EpiStoreF32 {
+    float* out; int ldo; float alpha; int accumulate;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+        float4* p = (float4*)(out + (size_t)m * ldo + n);
+        float4 a = make_float4(alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]);
+        float4 b = make_float4(alpha * v[4], alpha * v[5], alpha * v[6], alpha * v[7]);
+        if (accumulate) {
+            float4 x = p[0], y = p[1];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+        p[0] = a; p[1] = b;
+    }
+};
+struct EpiSilu2 {
+    bf16_t* pre; bf16_t* act; int ldo;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = silu_f(v[i]) * (1.f / MP_SILU_DIV);
+        if (pre) store8_bf16(pre + (size_t)m * ldo + n, v);
+        store8_bf16(act + (size_t)m * ldo + n, a);
+    }
+};
+struct EpiResid {
+    bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+        const float4* g = (const float4*)(gate + (size_t)(m / rows) * ldg + n);
+        const float4* xi = (const float4*)(xin + (size_t)m * ldo + n);
+        float4 g0 = g[0], g1 = g[1], x0 = xi[0], x1 = xi[1];
+        float4 o0, o1;
+        o0.x = ca * x0.x + cb * g0.x * v[0]; o0.y = ca * x0.y + cb * g0.y * v[1];
+        o0.z = ca * x0.z + cb * g0.z * v[2]; o0.w = ca * x0.w + cb * g0.w * v[3];
+        o1.x = ca * x1.x + cb * g1.x * v[4]; o1.y = ca * x1.y + cb * g1.y * v[5];
+        o1.z = ca * x1.z + cb * g1.z * v[6]; o1.w = ca * x1.w + cb * g1.w * v[7];
+        float4* xo = (float4*)(xout + (size_t)m * ldo + n);
+        xo[0] = o0; xo[1] = o1;
+        if (y) store8_bf16(y + (size_t)m * ldo + n, v);
+    }
+};
+struct EpiDSilu {
+    bf16_t* out; const bf16_t* pre; int ldo;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+        float h[8], w[8];
+        load8_bf16(pre + (size_t)m * ldo + n, h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = v[i] * dmpsilu_f(h[i]);
+        store8_bf16(out + (size_t)m * ldo + n, w);
+    }
+};
+
+// ---- the MFMA kernel -------------------------------------------------------------------------------------
+template <int AK, int BK, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous band of tiles.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (wg / p.tiles_n) * BM, n0 = (wg % p.tiles_n) * BN;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BKT;
+    stage_tile<AK>(p.A, p.lda, m0, p.M, 0, smem, wave, lane);
+    stage_tile<BK>(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();   // tile t has landed (vmcnt(0) + barrier); everyone is done with the other buffer
+        char* cur = smem + (t & 1) * BUF_BYTES;
+        if (t + 1 < nk) {
+            char* nxt = smem + ((t + 1) & 1) * BUF_BYTES;
+            stage_tile<AK>(p.A, p.lda, m0, p.M, (t + 1) * BKT, nxt, wave, lane);
+            stage_tile<BK>(p.B, p.ldb, n0, p.N, (t + 1) * BKT, nxt + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK>(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<BK>(cur + TILE_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();       // all fragment reads done: the staging buffers may be overwritten
+
+    // D = (N-side) x (M-side): lane holds C[m = .. + (lane & 15)][n = .. + 4 (lane >> 4) + 0..3].
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wm * 64 + i * 16 + (lane & 15);
+            const int n = wn * 64 + j * 16 + 4 * (lane >> 4);
+            *(f32x4_t*)(cs + m * CS_LD + n) = acc[i][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = (tid >> 4) + 16 * it, col = (tid & 15) * 8;
+        const int gm = m0 + row, gn = n0 + col;
+        if (gm < p.M && gn < p.N) {
+            float v[8];
+            *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS_LD + col);
+            *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS_LD + col + 4);
+            epi(gm, gn, v);
+        }
+    }
+}
+
+// ---- generic fallback for shapes the MFMA tiling does not take (K % 64 != 0: tiny conditioning GEMMs) --------
+// One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
+template <class Epi>
+__global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long sak, const bf16_t* __restrict__ B,
+                                   long sbn, long sbk, int M, int N, int K, Epi epi) {
+    const int chunks = N >> 3;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)M * chunks) return;
+    const int m = (int)(id / chunks), n = (int)(id % chunks) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+        const float a = bf2f(A[m * sam + k * sak]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += a * bf2f(B[(n + i) * sbn + k * sbk]);
+    }
+    epi(m, n, v);
+}
+
+template <class Epi>
+int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, Epi epi,
+           hipStream_t st) {
+    const bool a_kmaj = layout == MAPDIT_TN, b_kmaj = layout != MAPDIT_NT;
+    bool mfma = (K % BKT == 0) && (N % 8 == 0) && K > 0;
+    if (a_kmaj && (M % 8 != 0 || lda % 8 != 0)) mfma = false;
+    if (b_kmaj && (ldb % 8 != 0)) mfma = false;
+    if (!a_kmaj && lda % 8 != 0) mfma = false;
+    if (!b_kmaj && ldb % 8 != 0) mfma = false;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
+    if (mfma) {
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN)};
+        const int grid = cdiv(M, BM) * p.tiles_n;
+        if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+        else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+        else hipLaunchKernelGGL((gemm_mfma_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+    } else {
+        const long sam = a_kmaj ? 1 : lda, sak = a_kmaj ? lda : 1;
+        const long sbn = b_kmaj ? 1 : ldb, sbk = b_kmaj ? ldb : 1;
+        const long total = (long)M * (N >> 3);
+        hipLaunchKernelGGL((gemm_simple_kernel<Epi>), dim3(cdiv(total, 256)), dim3(256), 0, st, A, sam, sak, B, sbn, sbk, M, N, K, epi);
+    }
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+}  // namespace
+
+// ---- error plumbing (shared) ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void mapdit_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mapdit_last_error(void) { return g_err; }
+extern "C" int mapdit_abi_version(void) { return 1; }
+
+extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
+                                int ldb, const mapdit_epilogue_t* e, void* stream) {
+    MD_CHECK(layout >= MAPDIT_NT && layout <= MAPDIT_TN, "gemm: bad layout %d", layout);
+    MD_CHECK(M > 0 && N > 0 && K > 0 && A && B && e, "gemm: null/empty argument (M=%d N=%d K=%d)", M, N, K);
+    MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_RESID, "gemm: null output");
+    MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
+    MD_CHECK(e->ldo % 8 == 0, "gemm: ldo=%d must be a multiple of 8", e->ldo);
+    hipStream_t st = (hipStream_t)stream;
+    switch (e->kind) {
+        case MAPDIT_EPI_STORE_BF16:
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreBf16{(bf16_t*)e->out, e->ldo, e->alpha}, st);
+        case MAPDIT_EPI_STORE_F32:
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreF32{(float*)e->out, e->ldo, e->alpha, e->accumulate}, st);
+        case MAPDIT_EPI_SILU2:
+            MD_CHECK(e->out2, "gemm: SILU2 needs out2");
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+        case MAPDIT_EPI_RESID:
+            MD_CHECK(e->out2 && e->aux && e->gate && e->rows_per_sample > 0, "gemm: RESID needs out2, aux, gate, rows_per_sample");
+            MD_CHECK(e->ldg % 4 == 0, "gemm: ldg=%d must be a multiple of 4", e->ldg);
+            return launch(layout, M, N, K, A, lda, B, ldb,
+                          EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
+                                   e->rows_per_sample, e->alpha, e->beta}, st);
+        case MAPDIT_EPI_DSILU:
+            MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
+    }
+    mapdit_set_error("gemm: unknown epilogue kind %d", e->kind);
+    return MAPDIT_ERR_ARG;
+}

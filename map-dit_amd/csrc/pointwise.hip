@@ -1,0 +1,356 @@
+// HBM-bound token-stream kernels of the DiT block (SURVEY.md K4, K5, K7 and their backward):
+// modulate, the fused residual/modulate backward with its per-sample column reductions, and the
+// head split / cosine-normalise / transpose passes on either side of attention.
+// Residual stream is fp32 [M, D]; GEMM operands are bf16; per-sample conditioning vectors are fp32.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float mp_den(float t) { return sqrtf((1.f - t) * (1.f - t) + t * t); }
+
+// ---- modulate forward (reference src/utils.py:11-16 via dit_block.py:35-36, final_layer.py:55) -----------------
+// u = ((1-g) * x * scale[n] + g * shift[n]) / sqrt((1-g)^2 + g^2)   -> bf16 GEMM operand
+__global__ __launch_bounds__(256) void modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                         const float* __restrict__ scale, int ldmod,
+                                                         const float* __restrict__ gain, bf16_t* __restrict__ out,
+                                                         long total8, int D, int T) {
+    const float g = *gain, den = mp_den(g);
+    const float ka = (1.f - g) / den, kb = g / den;
+    const int d8 = D >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / d8;
+        const int d = (int)(i % d8) * 8;
+        const int n = (int)(m / T);
+        const float4* xp = (const float4*)(x + m * D + d);
+        const float4* sc = (const float4*)(scale + (size_t)n * ldmod + d);
+        const float4* sh = (const float4*)(shift + (size_t)n * ldmod + d);
+        float4 x0 = xp[0], x1 = xp[1], c0 = sc[0], c1 = sc[1], h0 = sh[0], h1 = sh[1];
+        uint4 u;
+        u.x = pack2bf(ka * x0.x * c0.x + kb * h0.x, ka * x0.y * c0.y + kb * h0.y);
+        u.y = pack2bf(ka * x0.z * c0.z + kb * h0.z, ka * x0.w * c0.w + kb * h0.w);
+        u.z = pack2bf(ka * x1.x * c1.x + kb * h1.x, ka * x1.y * c1.y + kb * h1.y);
+        u.w = pack2bf(ka * x1.z * c1.z + kb * h1.z, ka * x1.w * c1.w + kb * h1.w);
+        *(uint4*)(out + m * D + d) = u;
+    }
+}
+
+// ---- fused backward of  x' = mp_sum(x_up, g_up*y_up, 0.3)  ->  u = modulate(x', shift, scale, gain) -------------
+// Inputs : dxo  grad wrt the residual value x' arriving from downstream (fp32, may be null = 0), scaled by ca here
+//          dxm  grad wrt u (bf16, may be null)
+// Outputs: dx   = ca*dxo + k*scale*dxm                       (fp32, grad wrt x')
+//          dscale[n,d] = sum_t k*x*dxm ; dshift[n,d] = sum_t (g/den)*dxm ; dgain partial = sum dxm*(shift - x*scale)/den
+//          (mp_sum denominator is detached for the learnable gain: SURVEY F8)
+//          dy_up = cb*g_up*dx (bf16) ; dg_up[n,d] = sum_t cb*y_up*dx     (backward of the residual that produced x')
+//          dx_bf = bf16(dx) optionally (operand of the patch-embedding dW GEMM)
+// Block = one sample x 128 columns; 32 column-lanes (4 columns each) x 8 row groups; LDS reduce over row groups.
+struct RmbP {
+    const float* dxo; const bf16_t* dxm; const float* x; const float* shift; const float* scale; const float* gain;
+    const bf16_t* y_up; const float* g_up;
+    float* dx; bf16_t* dx_bf; float* dshift; float* dscale; float* dgain_part; bf16_t* dy_up; float* dg_up;
+    int ldmod, ldg_up, ldd, ldd_up;   // row strides of (shift,scale), g_up, dshift/dscale and dg_up
+    int T, D; float ca, cb;
+};
+
+__global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
+    __shared__ float red[8][32][13];
+    const int n = blockIdx.x, cb0 = blockIdx.y * 128;
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int d = cb0 + cl * 4;
+    float g = 0.f, den = 1.f;
+    if (p.dxm) { g = *p.gain; den = mp_den(g); }
+    const float k = (1.f - g) / den, kb = g / den, kd = 1.f / den;
+    float4 sc = make_float4(0, 0, 0, 0), sh = sc, gu = sc;
+    if (p.dxm) {
+        sc = *(const float4*)(p.scale + (size_t)n * p.ldmod + d);
+        sh = *(const float4*)(p.shift + (size_t)n * p.ldmod + d);
+    }
+    if (p.y_up) gu = *(const float4*)(p.g_up + (size_t)n * p.ldg_up + d);
+    float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0}, a_g[4] = {0, 0, 0, 0}, a_gain = 0.f;
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, guv[4] = {gu.x, gu.y, gu.z, gu.w};
+    for (int t = rg; t < p.T; t += 8) {
+        const size_t off = ((size_t)n * p.T + t) * p.D + d;
+        float dx[4] = {0, 0, 0, 0};
+        if (p.dxo) {
+            float4 v = *(const float4*)(p.dxo + off);
+            dx[0] = p.ca * v.x; dx[1] = p.ca * v.y; dx[2] = p.ca * v.z; dx[3] = p.ca * v.w;
+        }
+        if (p.dxm) {
+            uint2 u = *(const uint2*)(p.dxm + off);
+            const float dm[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            float4 xv = *(const float4*)(p.x + off);
+            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dx[i] += k * scv[i] * dm[i];
+                a_sc[i] += k * xx[i] * dm[i];
+                a_sh[i] += kb * dm[i];
+                a_gain += dm[i] * (shv[i] - xx[i] * scv[i]) * kd;
+            }
+        }
+        if (p.dx) *(float4*)(p.dx + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+        if (p.dx_bf) {
+            uint2 u; u.x = pack2bf(dx[0], dx[1]); u.y = pack2bf(dx[2], dx[3]);
+            *(uint2*)(p.dx_bf + off) = u;
+        }
+        if (p.y_up) {
+            uint2 u = *(const uint2*)(p.y_up + off);
+            const float yy[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            float dy[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dy[i] = p.cb * guv[i] * dx[i];
+                a_g[i] += p.cb * yy[i] * dx[i];
+            }
+            uint2 w; w.x = pack2bf(dy[0], dy[1]); w.y = pack2bf(dy[2], dy[3]);
+            *(uint2*)(p.dy_up + off) = w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[rg][cl][i] = a_sc[i]; red[rg][cl][4 + i] = a_sh[i]; red[rg][cl][8 + i] = a_g[i]; }
+    red[rg][cl][12] = a_gain;
+    __syncthreads();
+    if (rg == 0) {
+        float s[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a += red[r][cl][j];
+            s[j] = a;
+        }
+        if (p.dxm) {
+            *(float4*)(p.dscale + (size_t)n * p.ldd + d) = make_float4(s[0], s[1], s[2], s[3]);
+            *(float4*)(p.dshift + (size_t)n * p.ldd + d) = make_float4(s[4], s[5], s[6], s[7]);
+            float gsum = s[12];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
+            if (cl == 0) p.dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gsum;
+        }
+        if (p.y_up) *(float4*)(p.dg_up + (size_t)n * p.ldd_up + d) = make_float4(s[8], s[9], s[10], s[11]);
+    }
+}
+
+// Deterministic final reduction of per-block partials into a scalar gradient (gain_msa / gain_mlp / gain_mod).
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int count, float* __restrict__ out, int accumulate) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < count; i += 64) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) *out = accumulate ? *out + a : a;
+}
+
+// ---- head split + cosine normalise (+ transposed images) ---------------------------------------------------------
+// qkv [M, 3D] bf16 -> qn,kn,v [BH][T][64] and (optionally) their transposes [BH][64][T].
+// q^ = q*sqrt(hd)/(|q|+eps) (reference attention.py:44-45 via utils.py:19-23).  Block = (64 tokens, head, batch).
+__global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, int T, int H, bf16_t* __restrict__ qn,
+                                                      bf16_t* __restrict__ kn, bf16_t* __restrict__ v,
+                                                      bf16_t* __restrict__ qt, bf16_t* __restrict__ kt,
+                                                      bf16_t* __restrict__ vt) {
+    __shared__ bf16_t tile[64][72];
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+    const size_t bh = (size_t)b * H + h;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const bf16_t* src = qkv + ((size_t)b * T + t0 + row) * (3 * D) + which * D + h * 64 + qd * 16;
+        uint4 u0 = ((const uint4*)src)[0], u1 = ((const uint4*)src)[1];
+        uint32_t w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        float f[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        if (which < 2) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ss += f[i] * f[i];
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const float s = 8.f / (sqrtf(ss) + NORM_EPS);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] *= s;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+        }
+        bf16_t* dst = (which == 0 ? qn : which == 1 ? kn : v) + (bh * T + t0 + row) * 64 + qd * 16;
+        ((uint4*)dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        ((uint4*)dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        bf16_t* tdst = which == 0 ? qt : which == 1 ? kt : vt;
+        if (tdst) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(uint32_t*)&tile[row][qd * 16 + 2 * i] = w[i];
+            __syncthreads();
+            // thread -> feature d = row, tokens qd*16 .. +15
+            uint32_t o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (uint32_t)tile[qd * 16 + 2 * i][row] | ((uint32_t)tile[qd * 16 + 2 * i + 1][row] << 16);
+            bf16_t* td = tdst + (bh * 64 + row) * T + t0 + qd * 16;
+            ((uint4*)td)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            ((uint4*)td)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
+// Backward: dqn,dkn,dv [BH][T][64] + saved qkv -> dqkv [M,3D].  dq = s*(dq^ - q (dq^.q)/(n (n+eps))), s = 8/(n+eps).
+__global__ __launch_bounds__(256) void qkv_merge_bwd_kernel(const bf16_t* __restrict__ qkv, int T, int H,
+                                                          const bf16_t* __restrict__ dqn, const bf16_t* __restrict__ dkn,
+                                                          const bf16_t* __restrict__ dv, bf16_t* __restrict__ dqkv) {
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+    const size_t bh = (size_t)b * H + h;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const size_t moff = ((size_t)b * T + t0 + row) * (3 * D) + which * D + h * 64 + qd * 16;
+        const bf16_t* gsrc = (which == 0 ? dqn : which == 1 ? dkn : dv) + (bh * T + t0 + row) * 64 + qd * 16;
+        uint4 g0 = ((const uint4*)gsrc)[0], g1 = ((const uint4*)gsrc)[1];
+        uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        if (which < 2) {
+            uint4 u0 = ((const uint4*)(qkv + moff))[0], u1 = ((const uint4*)(qkv + moff))[1];
+            uint32_t w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            float f[16], gf[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+                gf[2 * i] = __uint_as_float(gw[i] << 16); gf[2 * i + 1] = __uint_as_float(gw[i] & 0xffff0000u);
+            }
+            float ss = 0.f, dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ss += f[i] * f[i]; dot += f[i] * gf[i]; }
+            ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+            const float n = sqrtf(ss), s = 8.f / (n + NORM_EPS);
+            const float c = dot / (fmaxf(n, 1e-30f) * (n + NORM_EPS));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gf[i] = s * (gf[i] - f[i] * c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gw[i] = pack2bf(gf[2 * i], gf[2 * i + 1]);
+        }
+        ((uint4*)(dqkv + moff))[0] = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+        ((uint4*)(dqkv + moff))[1] = make_uint4(gw[4], gw[5], gw[6], gw[7]);
+    }
+}
+
+// dO prep for attention backward: do [M, D] (merged heads) -> doT [BH][64][T] and delta[BH][T] = sum_d do*o.
+__global__ __launch_bounds__(256) void do_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, int T,
+                                                    int H, bf16_t* __restrict__ doT, float* __restrict__ delta) {
+    __shared__ bf16_t tile[64][72];
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
+    const size_t bh = (size_t)b * H + h;
+    const size_t moff = ((size_t)b * T + t0 + row) * D + h * 64 + qd * 16;
+    uint4 g0 = ((const uint4*)(dO + moff))[0], g1 = ((const uint4*)(dO + moff))[1];
+    uint4 o0 = ((const uint4*)(O + moff))[0], o1 = ((const uint4*)(O + moff))[1];
+    uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        dot += __uint_as_float(gw[i] << 16) * __uint_as_float(ow[i] << 16);
+        dot += __uint_as_float(gw[i] & 0xffff0000u) * __uint_as_float(ow[i] & 0xffff0000u);
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    if (qd == 0) delta[bh * T + t0 + row] = dot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(uint32_t*)&tile[row][qd * 16 + 2 * i] = gw[i];
+    __syncthreads();
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (uint32_t)tile[qd * 16 + 2 * i][row] | ((uint32_t)tile[qd * 16 + 2 * i + 1][row] << 16);
+    bf16_t* td = doT + (bh * 64 + row) * T + t0 + qd * 16;
+    ((uint4*)td)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    ((uint4*)td)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// mp_silu on a small fp32 matrix -> bf16 GEMM operand (conditioning path: MPSiLU(c), dit_block.py:24-25).
+__global__ void mpsilu_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(silu_f(x[i]) * (1.f / MP_SILU_DIV));
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n, float alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(alpha * x[i]);
+}
+
+}  // namespace
+
+extern "C" int mapdit_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
+                                   uint16_t* out, int n_samples, int T, int D, void* stream) {
+    MD_CHECK(x && shift && scale && gain && out, "modulate_fwd: null argument");
+    MD_CHECK(D % 8 == 0 && ldmod % 4 == 0, "modulate_fwd: D=%d must be a multiple of 8, ldmod=%d of 4", D, ldmod);
+    const long total8 = (long)n_samples * T * (D / 8);
+    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(modulate_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, shift, scale, ldmod, gain,
+                       out, total8, D, T);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* stream) {
+    MD_CHECK(a, "resid_mod_bwd: null argument");
+    MD_CHECK(a->D % 128 == 0, "resid_mod_bwd: D=%d must be a multiple of 128", a->D);
+    MD_CHECK(a->dxo || a->dxm, "resid_mod_bwd: need dxo and/or dxm");
+    MD_CHECK(!a->dxm || (a->x && a->shift && a->scale && a->gain && a->dshift && a->dscale && a->dgain_part),
+             "resid_mod_bwd: modulate backward needs x, shift, scale, gain, dshift, dscale, dgain_part");
+    MD_CHECK(!a->y_up || (a->g_up && a->dy_up && a->dg_up), "resid_mod_bwd: residual backward needs g_up, dy_up, dg_up");
+    RmbP p;
+    p.dxo = a->dxo; p.dxm = a->dxm; p.x = a->x; p.shift = a->shift; p.scale = a->scale; p.gain = a->gain;
+    p.y_up = a->y_up; p.g_up = a->g_up; p.dx = a->dx; p.dx_bf = a->dx_bf; p.dshift = a->dshift; p.dscale = a->dscale;
+    p.dgain_part = a->dgain_part; p.dy_up = a->dy_up; p.dg_up = a->dg_up;
+    p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
+    hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128), dim3(256), 0, (hipStream_t)stream, p);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream) {
+    MD_CHECK(part && out && count > 0, "reduce_partials: null/empty argument");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, count, out, accumulate);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
+                                uint16_t* v, uint16_t* qt, uint16_t* kt, uint16_t* vt, void* stream) {
+    MD_CHECK(qkv && qn && kn && v, "qkv_split: null argument");
+    MD_CHECK(head_dim == 64, "qkv_split: head_dim=%d unsupported (64 only: DiT-XS/S/B/L)", head_dim);
+    MD_CHECK(T % 64 == 0, "qkv_split: T=%d must be a multiple of 64", T);
+    hipLaunchKernelGGL(qkv_split_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, qn, kn, v, qt, kt, vt);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+                                    const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream) {
+    MD_CHECK(qkv && dqn && dkn && dv && dqkv, "qkv_merge_bwd: null argument");
+    MD_CHECK(head_dim == 64 && T % 64 == 0, "qkv_merge_bwd: head_dim=%d T=%d unsupported", head_dim, T);
+    hipLaunchKernelGGL(qkv_merge_bwd_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, dqn, dkn, dv, dqkv);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_attn_do_prep(const uint16_t* dO, const uint16_t* O, int B, int T, int H, int head_dim,
+                                   uint16_t* doT, float* delta, void* stream) {
+    MD_CHECK(dO && O && doT && delta, "attn_do_prep: null argument");
+    MD_CHECK(head_dim == 64 && T % 64 == 0, "attn_do_prep: head_dim=%d T=%d unsupported", head_dim, T);
+    hipLaunchKernelGGL(do_prep_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, dO, O, T, H, doT, delta);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream) {
+    MD_CHECK(x && out && n > 0, "mpsilu_to_bf16: null/empty argument");
+    hipLaunchKernelGGL(mpsilu_f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void* stream) {
+    MD_CHECK(x && out && n > 0, "f32_to_bf16: null/empty argument");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n, alpha);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}

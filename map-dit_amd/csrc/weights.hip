@@ -1,0 +1,159 @@
+// Weight-side kernels: weight normalisation forward/backward and the fused Adam + EMA update.
+// All are HBM-bound streams over the parameters; one wave per weight row,
+// 16-byte accesses, fp32 arithmetic.
+#include "common.h"
+
+namespace {
+
+// One wave per row.  Pass 1: sum of squares.  Pass 2 (row is L1/L2-hot): rewrite the master weight
+// (forced weight norm, reference mp_linear.py:38-40 / mp_embedding.py:17-19) and emit the effective
+// weight  w = out_scale * Wn / (|Wn| + eps)  (mp_linear.py:44: normalize(W)/sqrt(in) == W/(|W|+eps)).
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__ W, int rows, int cols, int forced,
+                                                           float out_scale, bf16_t* __restrict__ wb,
+                                                           float* __restrict__ wf, float* __restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* w = W + (size_t)row * cols;
+    float ss = 0.f;
+    const bool vec = (cols & 3) == 0;
+    if (vec) {
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 v = *(const float4*)(w + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) ss += w[c] * w[c];
+    }
+    ss = wave_sum(ss);
+    float n = sqrtf(ss);
+    float f = 1.f;                       // factor applied to the stored master weight
+    if (forced) {
+        f = sqrtf((float)cols) / (n + NORM_EPS);
+        n = n * f;                       // norm of the rewritten row
+    }
+    const float s = 1.f / (n + NORM_EPS);
+    const float e = f * s * out_scale;   // w_eff = W_old * f * s * out_scale
+    if (inv && lane == 0) inv[row] = s;
+    if (vec) {
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 v = *(const float4*)(w + c);
+            if (forced) *(float4*)(w + c) = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+            float4 o = make_float4(v.x * e, v.y * e, v.z * e, v.w * e);
+            if (wf) *(float4*)(wf + (size_t)row * cols + c) = o;
+            if (wb) {
+                uint2 u;
+                u.x = pack2bf(o.x, o.y);
+                u.y = pack2bf(o.z, o.w);
+                *(uint2*)(wb + (size_t)row * cols + c) = u;
+            }
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) {
+            const float v = w[c];
+            if (forced) w[c] = v * f;
+            if (wf) wf[(size_t)row * cols + c] = v * e;
+            if (wb) wb[(size_t)row * cols + c] = f2bf(v * e);
+        }
+    }
+}
+
+// Backward of w = out_scale * W / (n + eps), n = |W|:  dW = out_scale * (G/(n+eps) - W (G.W) / (n (n+eps)^2)).
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, const float* __restrict__ G, int ldg,
+                                                           float* __restrict__ dW, int rows, int cols,
+                                                           float out_scale, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* w = W + (size_t)row * cols;
+    const float* g = G + (size_t)row * ldg;
+    float* d = dW + (size_t)row * cols;
+    float ss = 0.f, gw = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float a = w[c], b = g[c];
+        ss += a * a;
+        gw += a * b;
+    }
+    ss = wave_sum(ss);
+    gw = wave_sum(gw);
+    const float n = sqrtf(ss);
+    const float a1 = out_scale / (n + NORM_EPS);
+    const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
+    for (int c = lane; c < cols; c += 64) {
+        float r = a1 * g[c] - a2 * w[c];
+        if (accumulate) r += d[c];
+        d[c] = r;
+    }
+}
+
+// torch.optim.Adam (train.py:57: lr, betas (0.9, 0.99), eps 1e-8, no weight decay) fused with the two
+// power-function EMA copies (src/ema.py:135-140: ema.lerp_(param, beta)).  Step-dependent scalars are read
+// from a small device array so the launch is graph-replayable:
+//   hp[0] = lr / (1 - b1^t)   hp[1] = 1 / sqrt(1 - b2^t)   hp[2] = ema beta (std 0.05)   hp[3] = ema beta (std 0.1)
+//   hp[4] = grad scale (1 / world size for the DP mean)
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v,
+                                                     float* __restrict__ e1, float* __restrict__ e2, long n,
+                                                     const float* __restrict__ hp, float b1, float b2, float eps) {
+    const float step_size = hp[0], inv_sqrt_bc2 = hp[1], eb1 = hp[2], eb2 = hp[3], gs = hp[4];
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w},
+              vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gs;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+        }
+        *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (e1) {
+            float4 E = *(float4*)(e1 + i);
+            E.x += eb1 * (pp[0] - E.x); E.y += eb1 * (pp[1] - E.y); E.z += eb1 * (pp[2] - E.z); E.w += eb1 * (pp[3] - E.w);
+            *(float4*)(e1 + i) = E;
+        }
+        if (e2) {
+            float4 E = *(float4*)(e2 + i);
+            E.x += eb2 * (pp[0] - E.x); E.y += eb2 * (pp[1] - E.y); E.z += eb2 * (pp[2] - E.z); E.w += eb2 * (pp[3] - E.w);
+            *(float4*)(e2 + i) = E;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16,
+                                     float* w_f32, float* inv, void* stream) {
+    MD_CHECK(W && rows > 0 && cols > 0, "weightnorm_fwd: null/empty argument");
+    MD_CHECK((cols & 3) != 0 || (((uintptr_t)W | (uintptr_t)w_f32) & 15) == 0, "weightnorm_fwd: unaligned pointer");
+    hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, rows, cols,
+                       forced, out_scale, w_bf16, w_f32, inv);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, float* dW, int rows, int cols,
+                                     float out_scale, int accumulate, void* stream) {
+    MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols, "weightnorm_bwd: null/empty argument");
+    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg, dW,
+                       rows, cols, out_scale, accumulate);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
+                                    float* ema_b, long n, const float* hyper, float beta1, float beta2, float eps,
+                                    void* stream) {
+    MD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && n > 0, "adam_ema_step: null/empty argument");
+    MD_CHECK(n % 4 == 0, "adam_ema_step: n=%ld must be a multiple of 4 (pad the flat buffer)", n);
+    const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, ema_a, ema_b, n, hyper, beta1, beta2, eps);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}

@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/mapdit.h declares (no compute calls here: there is no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mapdit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mapdit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    import mapdit_amd
+    L = mapdit_amd._lib
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    cdll = ctypes.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(cdll, s), f"{s} declared in mapdit.h but not exported by libmapdit_hip.so"
+    assert sorted(L.EXPORTS) == syms, set(L.EXPORTS) ^ set(syms)
+    assert cdll.mapdit_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import mapdit_amd
+    L = mapdit_amd._lib
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(L, "_handle", None)
+    with pytest.raises(L.MapditError):
+        L.lib()
+
+
+def test_workspace_query_and_config_errors():
+    import mapdit_amd
+    L = mapdit_amd._lib
+    lib = L.lib()
+    cfg = L.Config(depth=12, hidden=768, patch=2, input_size=32, in_channels=4, num_heads=12, mlp_hidden=3072,
+                   table_rows=1001, max_batch=32)
+    train = lib.engine_workspace_bytes(ctypes.byref(cfg), 1)
+    infer = lib.engine_workspace_bytes(ctypes.byref(cfg), 0)
+    assert train > infer > 0
+    assert train < 16 << 30
+    bad = L.Config(depth=28, hidden=1152, patch=2, input_size=32, in_channels=4, num_heads=16, mlp_hidden=4608,
+                   table_rows=1001, max_batch=2)
+    assert lib.engine_workspace_bytes(ctypes.byref(bad), 0) == 0           # head_dim 72: refused, not mis-computed
+    assert b"head_dim" in lib.last_error()

@@ -1,0 +1,494 @@
+"""Per-kernel parity tests on the MI355X, called through the C ABI (ctypes).
+
+Checker: the CPU oracle (oracle/) and plain fp32/fp64 torch restatements of single ops.
+Where a kernel takes bf16 operands the inputs are generated bf16-exact, so the only
+differences left are fp32 accumulation order and the final bf16 rounding of outputs;
+tolerances are stated per test.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    import mapdit_amd
+    return mapdit_amd._lib
+
+
+def bf16_exact(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
+
+
+def to_bf(x):
+    return x.to(DEV).bfloat16().contiguous()
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------
+def run_gemm(L, layout, a, b, kind, M, N, K, **kw):
+    ep = L.Epilogue()
+    ep.kind = kind
+    for k, v in kw.items():
+        setattr(ep, k, v)
+    lda = a.shape[1]
+    ldb = b.shape[1]
+    L.lib().gemm_bf16(layout, M, N, K, p(a), lda, p(b), ldb, C.byref(ep), st())
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 128), (200, 136, 192), (1024, 768, 768), (77, 32, 64),
+                                   (64, 24, 256), (8, 128, 32), (130, 128, 8)])
+def test_gemm_layouts(L, layout, shape):
+    """C = A B^T in the three storage layouts, incl. ragged M/N and the non-MFMA fallback (K % 64 != 0)."""
+    M, N, K = shape
+    if layout == 2 and M % 8:
+        pytest.skip("TN needs M % 8 == 0 (rows of the K-major operand are 16-byte chunks)")
+    A = bf16_exact(M, K, seed=1)
+    B = bf16_exact(N, K, seed=2)          # asymmetric, random: catches transposed C
+    ref = A.double() @ B.double().t()
+    a = to_bf(A if layout != 2 else A.t())
+    b = to_bf(B if layout == 0 else B.t())
+    out = torch.full((M, N), float("nan"), device=DEV)
+    run_gemm(L, layout, a, b, L.EPI_STORE_F32, M, N, K, out=p(out), ldo=N, alpha=1.0)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-3
+
+
+def test_gemm_identity_asymmetric(L):
+    """A = I with an asymmetric B: output must be B^T exactly (guide: catches row/col swaps)."""
+    N, K = 128, 128
+    A = torch.eye(128)
+    B = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251
+    out = torch.zeros(128, N, device=DEV)
+    run_gemm(L, 0, to_bf(A), to_bf(B), L.EPI_STORE_F32, 128, N, K, out=p(out), ldo=N, alpha=1.0)
+    assert torch.equal(out.cpu(), B.t().contiguous())
+
+
+def test_gemm_epilogues(L):
+    M, N, K, T = 256, 256, 128, 64
+    A, B = bf16_exact(M, K, seed=3), bf16_exact(N, K, seed=4, scale=0.2)
+    acc = (A.double() @ B.double().t()).float()
+    a, b = to_bf(A), to_bf(B)
+    # bf16 store with alpha
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    run_gemm(L, 0, a, b, L.EPI_STORE_BF16, M, N, K, out=p(out), ldo=N, alpha=0.5)
+    assert rel_err(out.float().cpu().numpy(), (0.5 * acc).numpy()) < 3e-3
+    # accumulate fp32
+    base = torch.randn(M, N)
+    o2 = base.to(DEV).clone()
+    run_gemm(L, 0, a, b, L.EPI_STORE_F32, M, N, K, out=p(o2), ldo=N, alpha=2.0, accumulate=1)
+    assert rel_err(o2.cpu().numpy(), (base + 2 * acc).numpy()) < 2e-6
+    # silu2
+    pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    act = torch.zeros_like(pre)
+    run_gemm(L, 0, a, b, L.EPI_SILU2, M, N, K, out=p(pre), out2=p(act), ldo=N)
+    assert rel_err(pre.float().cpu().numpy(), acc.numpy()) < 3e-3
+    assert rel_err(act.float().cpu().numpy(), (torch.nn.functional.silu(acc) / 0.596).numpy()) < 3e-3
+    # residual: xout = ca*x + cb*gate[m/T]*acc
+    x = torch.randn(M, N)
+    gate = torch.randn(M // T, 3 * N)
+    xo = torch.zeros(M, N, device=DEV)
+    y = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    xd, gd = x.to(DEV), gate.to(DEV)
+    run_gemm(L, 0, a, b, L.EPI_RESID, M, N, K, out=p(y), out2=p(xo), aux=p(xd), gate=gd.data_ptr() + 4 * N, ldg=3 * N,
+             rows_per_sample=T, ldo=N, alpha=0.7, beta=0.3)
+    ref = 0.7 * x + 0.3 * gate[:, N:2 * N].repeat_interleave(T, 0) * acc
+    assert rel_err(xo.cpu().numpy(), ref.numpy()) < 2e-6
+    assert rel_err(y.float().cpu().numpy(), acc.numpy()) < 3e-3
+    # dsilu
+    h = bf16_exact(M, N, seed=9)
+    o3 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    hd = to_bf(h)
+    run_gemm(L, 0, a, b, L.EPI_DSILU, M, N, K, out=p(o3), aux=p(hd), ldo=N)
+    hh = h.clone().requires_grad_(True)
+    (torch.nn.functional.silu(hh) / 0.596).backward(acc)
+    assert rel_err(o3.float().cpu().numpy(), hh.grad.numpy()) < 3e-3
+
+
+def test_gemm_rejects_bad_args(L):
+    a = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    ep = L.Epilogue()
+    ep.kind = L.EPI_STORE_F32
+    ep.out = None
+    with pytest.raises(L.MapditError):
+        L.lib().gemm_bf16(0, 64, 64, 64, p(a), 64, p(a), 64, C.byref(ep), st())
+    ep.out = p(a)
+    ep.ldo = 64
+    with pytest.raises(L.MapditError):
+        L.lib().gemm_bf16(0, 64, 60, 64, p(a), 64, p(a), 64, C.byref(ep), st())   # N % 8
+
+
+# ---------------------------------------------------------------------------------------------------
+# weight norm / optimiser
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(384, 128), (16, 17), (11, 128), (768, 3072)])
+@pytest.mark.parametrize("forced", [0, 1])
+def test_weightnorm(L, rows, cols, forced):
+    from oracle.dit_oracle import normalize
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(rows, cols, generator=g) * 1.7
+    Wd = W.to(DEV).clone()
+    wb = torch.zeros(rows, cols, device=DEV, dtype=torch.bfloat16)
+    wf = torch.zeros(rows, cols, device=DEV)
+    inv = torch.zeros(rows, device=DEV)
+    L.lib().weightnorm_fwd(p(Wd), rows, cols, forced, 1.0, p(wb), p(wf), p(inv), st())
+    torch.cuda.synchronize()
+    Wn = normalize(W) if forced else W
+    w_eff = normalize(Wn) / math.sqrt(cols)
+    assert rel_err(Wd.cpu().numpy(), Wn.numpy()) < 1e-6
+    assert rel_err(wf.cpu().numpy(), w_eff.numpy()) < 1e-6
+    assert rel_err(wb.float().cpu().numpy(), w_eff.numpy()) < 3e-3
+    # backward
+    G = torch.randn(rows, cols + 3, generator=g)
+    Wr = Wn.clone().requires_grad_(True)
+    (normalize(Wr) / math.sqrt(cols)).backward(G[:, :cols])
+    dW = torch.zeros(rows, cols, device=DEV)
+    Gd = G.to(DEV).contiguous()
+    Wnd = Wn.to(DEV)
+    L.lib().weightnorm_bwd(p(Wnd), p(Gd), cols + 3, p(dW), rows, cols, 1.0, 0, st())
+    torch.cuda.synchronize()
+    assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
+
+
+def test_adam_ema(L):
+    from oracle.dit_oracle import adam_step, ema_beta
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(6)
+    P, Gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    m, v = torch.zeros(n), torch.zeros(n)
+    e1, e2 = P.clone(), P.clone()
+    d = [t.to(DEV).clone() for t in (P, Gr, m, v, e1, e2)]
+    for step in (1, 2, 3):
+        b1, b2 = 0.9, 0.99
+        hp = torch.tensor([1e-2 / (1 - b1 ** step), 1 / math.sqrt(1 - b2 ** step), ema_beta(0.05, step), ema_beta(0.1, step), 1.0],
+                          device=DEV)
+        L.lib().adam_ema_step(p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), n, p(hp), b1, b2, 1e-8, st())
+        adam_step(P, Gr, m, v, step, lr=1e-2)
+        e1.lerp_(P, ema_beta(0.05, step))
+        e2.lerp_(P, ema_beta(0.1, step))
+    torch.cuda.synchronize()
+    assert rel_err(d[0].cpu().numpy(), P.numpy()) < 1e-6
+    assert rel_err(d[4].cpu().numpy(), e1.numpy()) < 1e-6
+    assert rel_err(d[5].cpu().numpy(), e2.numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# token-stream kernels
+# ---------------------------------------------------------------------------------------------------
+def test_modulate_and_fused_backward(L):
+    from oracle.dit_oracle import modulate, mp_sum
+    N, T, D = 3, 64, 256
+    g = torch.Generator().manual_seed(7)
+    x_up = torch.randn(N, T, D, generator=g)
+    y_up = bf16_exact(N, T, D, seed=8)
+    mod_up = torch.randn(N, 6 * D, generator=g)
+    mod = torch.randn(N, 6 * D, generator=g)
+    gain = torch.tensor(0.37)
+    dxm = bf16_exact(N, T, D, seed=9)
+    dxo = torch.randn(N, T, D, generator=g)
+    # reference chain: x' = mp_sum(x_up, g_up*y_up, .3); u = modulate(x', shift, scale, gain); loss = <u, dxm> + <x', dxo'>
+    ca, cb = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58)
+    leaves = [t.clone().requires_grad_(True) for t in (x_up, y_up, mod_up, mod, gain)]
+    xu, yu, mu, mm, gg = leaves
+    xp = mp_sum(xu, mu[:, 5 * D:].unsqueeze(1) * yu, 0.3)
+    u = modulate(xp, mm[:, 3 * D:4 * D], mm[:, 4 * D:5 * D], gg)
+    # downstream residual contributes ca*dxo to d x'
+    ((u * dxm).sum() + (xp * (ca * dxo)).sum()).backward()
+    # forward kernel
+    xpd = xp.detach().to(DEV).contiguous()
+    modd = mod.to(DEV)
+    gd = gain.to(DEV)
+    out = torch.zeros(N * T, D, device=DEV, dtype=torch.bfloat16)
+    L.lib().modulate_fwd(p(xpd), modd.data_ptr() + 4 * 3 * D, modd.data_ptr() + 4 * 4 * D, 6 * D, p(gd), p(out), N, T, D, st())
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu().numpy().reshape(N, T, D), u.detach().numpy()) < 3e-3
+    # fused backward kernel
+    a = L.ResidModBwd()
+    dxod, dxmd, yud, mud = dxo.to(DEV).contiguous(), to_bf(dxm), to_bf(y_up), mod_up.to(DEV)
+    dx = torch.zeros(N, T, D, device=DEV)
+    dxbf = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    dmod = torch.zeros(N, 6 * D, device=DEV)
+    dmod_up = torch.zeros(N, 6 * D, device=DEV)
+    part = torch.zeros(N * (D // 128), device=DEV)
+    dy = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    a.dxo, a.dxm, a.x = p(dxod), p(dxmd), p(xpd)
+    a.shift, a.scale, a.gain, a.ldmod = modd.data_ptr() + 4 * 3 * D, modd.data_ptr() + 4 * 4 * D, p(gd), 6 * D
+    a.y_up, a.g_up, a.ldg_up = p(yud), mud.data_ptr() + 4 * 5 * D, 6 * D
+    a.dx, a.dx_bf = p(dx), p(dxbf)
+    a.dshift, a.dscale, a.ldd = dmod.data_ptr() + 4 * 3 * D, dmod.data_ptr() + 4 * 4 * D, 6 * D
+    a.dgain_part, a.dy_up, a.dg_up, a.ldd_up = p(part), p(dy), dmod_up.data_ptr() + 4 * 5 * D, 6 * D
+    a.n_samples, a.T, a.D, a.ca, a.cb = N, T, D, ca, cb
+    L.lib().resid_mod_bwd(C.byref(a), st())
+    dgain = torch.zeros((), device=DEV)
+    L.lib().reduce_partials(p(part), N * (D // 128), p(dgain), 0, st())
+    torch.cuda.synchronize()
+    # d x' = ca*dxo + k*scale*dxm ; autograd: xu.grad = ca * d x'
+    assert rel_err((dx.cpu() * ca).numpy(), xu.grad.numpy()) < 1e-5
+    assert rel_err(dxbf.float().cpu().numpy(), dx.cpu().numpy()) < 3e-3
+    assert rel_err(dy.float().cpu().numpy(), yu.grad.numpy()) < 3e-3
+    assert rel_err(dmod.cpu().numpy(), mm.grad.numpy()) < 1e-5
+    assert rel_err(dmod_up.cpu().numpy(), mu.grad.numpy()) < 1e-5
+    assert abs(dgain.item() - gg.grad.item()) < 1e-4 * abs(gg.grad.item()) + 1e-5
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (1, 256, 3), (3, 128, 1)])
+def test_attention_fwd_bwd(L, B, T, H):
+    """qkv split + cosine normalise + attention forward and the whole backward chain vs autograd of the oracle ops."""
+    from oracle.dit_oracle import normalize
+    D = H * 64
+    qkv = bf16_exact(B * T, 3 * D, seed=10)
+    dO = bf16_exact(B * T, D, seed=11)
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, 64).transpose(1, 2)
+    qn, kn = normalize(sp(q)), normalize(sp(k))
+    att = torch.softmax(qn @ kn.transpose(-1, -2) / 8.0, dim=-1) @ sp(v)
+    o_ref = att.transpose(1, 2).reshape(B * T, D)
+    o_ref.backward(dO)
+
+    qkvd = to_bf(qkv)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    qn_d, kn_d, v_d = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
+    qt_d, kt_d, vt_d = mk(B * H, 64, T), mk(B * H, 64, T), mk(B * H, 64, T)
+    lib = L.lib()
+    lib.qkv_split(p(qkvd), B, T, H, 64, p(qn_d), p(kn_d), p(v_d), p(qt_d), p(kt_d), p(vt_d), st())
+    o_d = mk(B * T, D)
+    lse = torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd(p(qn_d), p(kn_d), p(vt_d), p(o_d), p(lse), B, T, H, 64, st())
+    torch.cuda.synchronize()
+    assert rel_err(qn_d.float().cpu().numpy(), qn.detach().reshape(B * H, T, 64).numpy()) < 3e-3
+    assert torch.equal(qt_d.cpu(), qn_d.cpu().transpose(1, 2))
+    assert torch.equal(vt_d.cpu(), v_d.cpu().transpose(1, 2))
+    # forward: bf16 q^,k^ and bf16 P in the PV product -> ~1e-2 relative
+    assert rel_err(o_d.float().cpu().numpy(), o_ref.detach().numpy()) < 1e-2
+    dOd = to_bf(dO)
+    doT = mk(B * H, 64, T)
+    delta = torch.zeros(B * H, T, device=DEV)
+    lib.attn_do_prep(p(dOd), p(o_d), B, T, H, 64, p(doT), p(delta), st())
+    dqn, dkn, dv = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
+    lib.attn_cos_bwd(p(qn_d), p(kn_d), p(v_d), p(qt_d), p(kt_d), p(dOd), p(doT), p(lse), p(delta), p(dqn), p(dkn), p(dv),
+                     B, T, H, 64, st())
+    dqkv = mk(B * T, 3 * D)
+    lib.qkv_merge_bwd(p(qkvd), B, T, H, 64, p(dqn), p(dkn), p(dv), p(dqkv), st())
+    torch.cuda.synchronize()
+    got = dqkv.float().cpu().view(B * T, 3, D)
+    ref = leaf.grad.view(B * T, 3, D)
+    assert rel_err(got[:, 2].numpy(), ref[:, 2].numpy()) < 1.5e-2     # dV
+    assert rel_err(got[:, 0].numpy(), ref[:, 0].numpy()) < 3e-2       # dQ (through the cosine-norm Jacobian)
+    assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
+
+
+def test_attention_exact_small_integers(L):
+    """Uniform attention (all logits equal) with integer V: O must be the exact key-mean of V."""
+    B, T, H = 1, 64, 1
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    qn = mk(1, T, 64)          # zero queries -> all logits 0 -> uniform softmax
+    kn = to_bf(bf16_exact(1, T, 64, seed=12))
+    V = (torch.arange(T * 64).reshape(1, T, 64) % 7).float()
+    vt = to_bf(V.transpose(1, 2))
+    o = mk(T, 64)
+    lse = torch.zeros(1, T, device=DEV)
+    L.lib().attn_cos_fwd(p(qn), p(kn), p(vt), p(o), p(lse), B, T, H, 64, st())
+    torch.cuda.synchronize()
+    ref = V.mean(1).expand(T, 64)
+    assert rel_err(o.float().cpu().numpy(), ref.numpy()) < 4e-3
+    assert np.allclose(lse.cpu().numpy(), math.log(T), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# embedding / output side
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p_,S", [(2, 16), (4, 32)])
+def test_patch_embed(L, p_, S):
+    from oracle.dit_oracle import patchify, mp_sum
+    N, C_, D = 3, 4, 128
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, C_, S, S, generator=g)
+    P = p_ * p_ * C_
+    w = torch.randn(D, P + 1, generator=g)
+    T = (S // p_) ** 2
+    pos = torch.randn(T, D, generator=g)
+    h = patchify(x, p_)
+    h = torch.cat([h, torch.ones_like(h[:, :, :1])], -1)
+    ref = mp_sum(h @ w.t(), pos.unsqueeze(0), 0.5)
+    ldp = (P + 1 + 7) // 8 * 8
+    out = torch.zeros(N * T, D, device=DEV)
+    patches = torch.full((N * T, ldp), 7.0, device=DEV, dtype=torch.bfloat16)
+    xd, wd, pd = x.to(DEV), w.to(DEV), pos.to(DEV)
+    L.lib().patch_embed_fwd(p(xd), p(wd), p(pd), p(out), p(patches), ldp, N, C_, S, p_, D, st())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy().reshape(N, T, D), ref.numpy()) < 1e-6
+    assert rel_err(patches[:, :P + 1].float().cpu().numpy().reshape(N, T, P + 1), h.numpy()) < 3e-3
+    assert float(patches[:, P + 1:].float().abs().max()) == 0.0
+
+
+def test_conditioning_kernels(L):
+    N, D = 5, 128
+    g = torch.Generator().manual_seed(14)
+    t = torch.randint(0, 1000, (N,), generator=g)
+    scale, shift = 2 * math.pi * torch.randn(256, generator=g), 2 * math.pi * torch.rand(256, generator=g)
+    ref = math.sqrt(2) * torch.cos(torch.outer(t.float(), scale) + shift)
+    four = torch.zeros(N, 256, device=DEV, dtype=torch.bfloat16)
+    td, sd, hd = t.to(DEV), scale.to(DEV), shift.to(DEV)
+    L.lib().fourier_fwd(p(td), p(sd), p(hd), p(four), N, 256, st())
+    torch.cuda.synchronize()
+    # fp32 cos of arguments up to ~2e4 rad: device vs host libm differ by ~1e-3 abs on a few entries
+    assert float((four.float().cpu() - ref).abs().max()) < 2e-2
+    assert rel_err(four.float().cpu().numpy(), ref.numpy()) < 4e-3
+    temb, table = torch.randn(N, D, generator=g), torch.randn(11, D, generator=g)
+    y = torch.randint(0, 11, (N,), generator=g)
+    cref = (temb + table[y]) * 0.5 / math.sqrt(0.5)
+    c = torch.zeros(N, D, device=DEV)
+    cs = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
+    cb = torch.zeros_like(cs)
+    tb, tab, yd = temb.to(DEV), table.to(DEV), y.to(DEV)
+    L.lib().cond_combine_fwd(p(tb), p(tab), p(yd), p(c), p(cs), p(cb), N, D, st())
+    torch.cuda.synchronize()
+    assert rel_err(c.cpu().numpy(), cref.numpy()) < 1e-6
+    assert rel_err(cs.float().cpu().numpy(), (torch.nn.functional.silu(cref) / 0.596).numpy()) < 3e-3
+    # backward
+    dcs, dcd = torch.randn(N, D, generator=g), torch.randn(N, D, generator=g)
+    leaf_t, leaf_tab = temb.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    cc = (leaf_t + leaf_tab[y]) * 0.5 / math.sqrt(0.5)
+    ((torch.nn.functional.silu(cc) / 0.596 * dcs).sum() + (cc * dcd).sum()).backward()
+    dtemb = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
+    dtable = torch.zeros(11, D, device=DEV)
+    a, b = dcs.to(DEV), dcd.to(DEV)
+    L.lib().cond_combine_bwd(p(c), p(a), p(b), p(yd), p(dtemb), p(dtable), N, D, st())
+    torch.cuda.synchronize()
+    assert rel_err(dtemb.float().cpu().numpy(), leaf_t.grad.numpy()) < 3e-3
+    assert rel_err(dtable.cpu().numpy(), leaf_tab.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("p_,S", [(2, 16), (4, 32)])
+def test_final_out(L, p_, S):
+    from oracle.dit_oracle import unpatchify
+    N, C_ = 3, 4
+    P = p_ * p_ * C_
+    T = (S // p_) ** 2
+    g = torch.Generator().manual_seed(15)
+    lin = torch.randn(N * T, 2 * P, generator=g)
+    am, asg = torch.randn(N, 8, generator=g), torch.randn(N, 8, generator=g)
+    rm, rs = torch.randn(8, generator=g), torch.randn(8, generator=g)
+    leaves = [z.clone().requires_grad_(True) for z in (lin, am, asg, rm, rs)]
+    l_, a1, a2, r1, r2 = leaves
+    mean, sigma = l_.view(N, T, 2 * P).chunk(2, -1)
+    gm = torch.sigmoid(a1 @ r1 / math.sqrt(8)).view(-1, 1, 1)
+    gs = torch.sigmoid(a2 @ r2 / math.sqrt(8)).view(-1, 1, 1)
+    ref = torch.cat([unpatchify(mean * gm, S, p_), unpatchify(sigma * gs, S, p_)], 1)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    d = [z.to(DEV).contiguous() for z in (lin, am, asg, rm, rs)]
+    out = torch.zeros(N, 2 * C_, S, S, device=DEV)
+    L.lib().final_out_fwd(p(d[0]), 2 * P, p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(out), N, C_, S, p_, st())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref.detach().numpy()) < 1e-6
+    ldd = 2 * P if 2 * P > 64 else 64
+    dlin = torch.zeros(N * T, ldd, device=DEV, dtype=torch.bfloat16)
+    da = torch.zeros(2, N, 8, device=DEV, dtype=torch.bfloat16)
+    drm, drs = torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
+    dd = dout.to(DEV).contiguous()
+    L.lib().final_out_bwd(p(dd), p(d[0]), 2 * P, p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(dlin), ldd, p(da), p(drm), p(drs),
+                          N, C_, S, p_, st())
+    torch.cuda.synchronize()
+    assert rel_err(dlin[:, :2 * P].float().cpu().numpy(), l_.grad.numpy()) < 3e-3
+    assert rel_err(da[0].float().cpu().numpy(), a1.grad.numpy()) < 4e-3
+    assert rel_err(da[1].float().cpu().numpy(), a2.grad.numpy()) < 4e-3
+    assert rel_err(drm.cpu().numpy(), r1.grad.numpy()) < 1e-5
+    assert rel_err(drs.cpu().numpy(), r2.grad.numpy()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# diffusion math
+# ---------------------------------------------------------------------------------------------------
+def _tables(d):
+    import numpy as np
+    rows = [d.sqrt_alphas_cumprod, d.sqrt_one_minus_alphas_cumprod, d.sqrt_recip_alphas_cumprod, d.sqrt_recipm1_alphas_cumprod,
+            d.posterior_log_variance_clipped, d.log_betas, d.posterior_mean_coef1, d.posterior_mean_coef2]
+    return torch.from_numpy(np.stack(rows)).float().to(DEV).contiguous()
+
+
+def test_loss_and_sampling_math(L):
+    from oracle.diffusion_oracle import DiffusionOracle
+    d = DiffusionOracle("")
+    tab = _tables(d)
+    N, C_, S = 6, 4, 16
+    per = C_ * S * S
+    g = torch.Generator().manual_seed(16)
+    x0 = torch.randn(N, C_, S, S, generator=g)
+    x0[0, 0, 0, :4] = torch.tensor([-1.5, 1.5, 0.9995, -0.9995])
+    noise = torch.randn(N, C_, S, S, generator=g)
+    t = torch.tensor([0, 5, 999, 400, 0, 37])
+    mo = torch.randn(N, 2 * C_, S, S, generator=g) * 0.7
+    # q_sample
+    xt_ref = d.q_sample(x0, t, noise)
+    xt = torch.zeros(N, C_, S, S, device=DEV)
+    d_ = [z.to(DEV).contiguous() for z in (x0, noise, t, mo)]
+    L.lib().q_sample(p(d_[0]), p(d_[1]), p(d_[2]), p(tab), 1000, p(xt), N, per, st())
+    torch.cuda.synchronize()
+    assert rel_err(xt.cpu().numpy(), xt_ref.numpy()) < 1e-6
+    # loss forward + gradient
+    leaf = mo.clone().requires_grad_(True)
+    ref = d.training_losses(lambda xx, tt, **kw: leaf, x0, t, noise=noise)
+    wl, wm, wv = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(N, generator=g)
+    ((ref["loss"] * wl).sum() + (ref["mse"] * wm).sum() + (ref["vb"] * wv).sum()).backward()
+    mse, vb, loss = (torch.zeros(N, device=DEV) for _ in range(3))
+    G = torch.zeros(N, 2 * C_, S, S, device=DEV)
+    xtd = xt_ref.to(DEV).contiguous()
+    L.lib().loss_fwd(p(d_[3]), p(d_[0]), p(xtd), p(d_[1]), p(d_[2]), p(tab), 1000, p(mse), p(vb), p(loss), p(G), N, per, st())
+    dout = torch.zeros_like(G)
+    w = [z.to(DEV) for z in (wl, wm, wv)]
+    L.lib().loss_bwd(p(G), p(w[0]), p(w[1]), p(w[2]), p(dout), N, per, st())
+    torch.cuda.synchronize()
+    assert rel_err(mse.cpu().numpy(), ref["mse"].detach().numpy()) < 1e-5
+    assert rel_err(vb.cpu().numpy(), ref["vb"].detach().numpy()) < 2e-5
+    assert rel_err(loss.cpu().numpy(), ref["loss"].detach().numpy()) < 1e-5
+    assert rel_err(dout.cpu().numpy(), leaf.grad.numpy()) < 1e-4
+    # p_sample at t > 0 and t == 0
+    d250 = DiffusionOracle("250")
+    tab250 = _tables(d250)
+    for tv in (137, 0):
+        ts = torch.full((N,), tv)
+        r = d250.p_sample(lambda xx, tt, **kw: mo, x0, ts, noise, clip_denoised=bool(tv == 0))
+        smp, xs = torch.zeros(N, C_, S, S, device=DEV), torch.zeros(N, C_, S, S, device=DEV)
+        tsd = ts.to(DEV)
+        L.lib().psample_step(p(d_[3]), p(d_[0]), p(d_[1]), p(tsd), p(tab250), 250, int(tv == 0), p(smp), p(xs), N, per, st())
+        torch.cuda.synchronize()
+        assert rel_err(smp.cpu().numpy(), r["sample"].numpy()) < 1e-5
+        assert rel_err(xs.cpu().numpy(), r["pred_xstart"].numpy()) < 1e-5
+
+
+def test_cfg_combine(L):
+    n, C_, HW = 6, 4, 64
+    g = torch.Generator().manual_seed(17)
+    mo = torch.randn(n, 2 * C_, 8, 8, generator=g)
+    eps, rest = mo[:, :C_], mo[:, C_:]
+    cond, unc = eps[:3], eps[3:]
+    half = unc + 1.5 * (cond - unc)
+    ref = torch.cat([torch.cat([half, half], 0), rest], 1)
+    out = torch.zeros(n, 2 * C_, 8, 8, device=DEV)
+    md = mo.to(DEV).contiguous()
+    L.lib().cfg_combine(p(md), p(out), n, C_, HW, 1.5, st())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-6
