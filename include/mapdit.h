@@ -42,7 +42,8 @@ enum {
     MAPDIT_EPI_SILU2 = 2,      /* out = bf16(acc) [optional]; out2 = bf16(silu(acc)/0.596)   (mlp.py:18-20, mp_silu.py:7) */
     MAPDIT_EPI_RESID = 3,      /* out = bf16(acc) [optional]; out2[m,n] = alpha*aux[m,n] + beta*gate[m/rows,n]*acc
                                   = mp_sum(x, gate*y, 0.3) of dit_block.py:35-36; aux/out2: fp32 residual stream       */
-    MAPDIT_EPI_DSILU = 4       /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
+    MAPDIT_EPI_DSILU = 4,      /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
+    MAPDIT_EPI_SILU2_COND = 5  /* SILU2 under its own kernel symbol (timestep MLP, timestep_embedder.py:43)           */
 };
 
 typedef struct {
@@ -204,6 +205,12 @@ int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const int64_t* t, 
                           float* out, void* stream);
 /* Backward of the last saved forward: writes d loss / d parameter into every bound grad pointer (overwrite). */
 int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* stream);
+
+/* Measurement hook: bracket every launch of one kernel family with HIP events on the launch stream.
+ * MAPDIT_PROF_FC1_FWD = the block-MLP fc1 GEMM (gemm NT + SILU2 epilogue, [N*T, 4D] = [N*T, D] x [4D, D]^T). */
+enum { MAPDIT_PROF_FC1_FWD = 0 };
+int mapdit_engine_profile_begin(mapdit_engine_t* e, int which, int max_events);
+int mapdit_engine_profile_end(mapdit_engine_t* e, int* count, double* total_ms); /* synchronises on the events */
 
 #ifdef __cplusplus
 }

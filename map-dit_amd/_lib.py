@@ -39,7 +39,8 @@ class Config(C.Structure):
 
 
 NT, NN, TN = 0, 1, 2
-EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU = range(5)
+EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND = range(6)
+PROF_FC1_FWD = 0
 
 # parameter-table indices (mapdit.h)
 (P_X_EMB, P_T0, P_T2, P_Y_EMB, P_F_LIN, P_F_MOD, P_MS_LIN, P_MS_REF, P_SS_LIN, P_SS_REF, P_F_GAIN, P_FOURIER_SCALE,
@@ -78,6 +79,8 @@ _SIGS = {
     "mapdit_engine_prepare_weights": [vp, ci, vp],
     "mapdit_engine_forward": [vp, vp, vp, vp, ci, ci, vp, vp],
     "mapdit_engine_backward": [vp, vp, vp],
+    "mapdit_engine_profile_begin": [vp, ci, ci],
+    "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
 }
 # entry points that do not return a status
 _OTHER = {

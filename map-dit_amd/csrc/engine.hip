@@ -46,7 +46,7 @@ struct WeightImg {
 struct mapdit_engine {
     mapdit_config_t cfg;
     int train;
-    int T, P, P1, ldp, D, Hm, heads, M_max;
+    int T, P, P1, ldp, ldl, D, Hm, heads, M_max;
     int last_N = 0;
     bool have_saved = false;
     std::vector<float*> params, grads;
@@ -71,6 +71,10 @@ struct mapdit_engine {
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
     bf16_t *dy, *dh, *dxm, *dO, *doT, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
+    // optional HIP-event timing of one kernel family (bench.py roofline)
+    int prof_which = -1;
+    size_t prof_used = 0;
+    std::vector<hipEvent_t> prof_start, prof_stop;
 };
 
 namespace {
@@ -92,7 +96,7 @@ size_t carve(mapdit_engine* e, void* base) {
     };
     img(MAPDIT_P_T0, D, FOURIER, D);
     img(MAPDIT_P_T2, D, D, D);
-    img(MAPDIT_P_F_LIN, 2 * e->P, D, 64 > 2 * e->P ? 64 : 2 * e->P);
+    img(MAPDIT_P_F_LIN, 2 * e->P, D, e->ldl);
     img(MAPDIT_P_F_MOD, 2 * D, D, 2 * D);
     img(MAPDIT_P_MS_LIN, NSCALE, D, NSCALE);
     img(MAPDIT_P_SS_LIN, NSCALE, D, NSCALE);
@@ -167,8 +171,8 @@ size_t carve(mapdit_engine* e, void* base) {
         e->dkn = cv.take<bf16_t>(M * D);
         e->dv = cv.take<bf16_t>(M * D);
         e->dqkv = cv.take<bf16_t>(M * 3 * D);
-        e->dlin = cv.take<bf16_t>(M * 64);
-        e->zero_bytes_dlin = M * 64 * sizeof(bf16_t);
+        e->dlin = cv.take<bf16_t>(M * e->ldl);
+        e->zero_bytes_dlin = M * e->ldl * sizeof(bf16_t);
         e->da_bf = cv.take<bf16_t>((size_t)2 * N * NSCALE);
         e->dmod_bf = cv.take<bf16_t>((size_t)N * 6 * D);
         e->dx0_bf = cv.take<bf16_t>(M * D);
@@ -188,7 +192,7 @@ int check_cfg(const mapdit_config_t* c) {
     const int g = c->input_size / c->patch, T = g * g;
     MD_CHECK(T == 64 || T == 128 || T == 256, "engine: %d tokens per sample unsupported (64, 128, 256)", T);
     MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
-    MD_CHECK(2 * c->patch * c->patch * c->in_channels <= 64 && (c->patch * c->patch * c->in_channels) % 4 == 0,
+    MD_CHECK(c->patch * c->patch * c->in_channels <= 256 && (c->patch * c->patch * c->in_channels) % 4 == 0,
              "engine: patch dim %d unsupported", c->patch * c->patch * c->in_channels);
     return MAPDIT_OK;
 }
@@ -200,6 +204,7 @@ void init_dims(mapdit_engine* e) {
     e->P = c.patch * c.patch * c.in_channels;
     e->P1 = e->P + 1;
     e->ldp = (e->P1 + 7) & ~7;
+    e->ldl = (2 * e->P + 63) & ~63;      // K of the final-linear dX GEMM, zero padded to the MFMA K-tile
     e->D = c.hidden;
     e->Hm = c.mlp_hidden;
     e->heads = c.num_heads;
@@ -277,7 +282,7 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     e->grads.assign(np, nullptr);
     // Padding rows of the final-linear image and padding columns of dlin must be (and stay) zero.
     const WeightImg& fl = e->wimg[MAPDIT_P_F_LIN];
-    hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)(64 > fl.rows ? 64 : fl.rows) * fl.cols * sizeof(bf16_t), (hipStream_t)stream);
+    hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t), (hipStream_t)stream);
     if (he == hipSuccess && train) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
     if (he != hipSuccess) {
         delete e;
@@ -288,7 +293,51 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     return MAPDIT_OK;
 }
 
-extern "C" void mapdit_engine_destroy(mapdit_engine_t* e) { delete e; }
+static void prof_release(mapdit_engine* e) {
+    for (hipEvent_t ev : e->prof_start) hipEventDestroy(ev);
+    for (hipEvent_t ev : e->prof_stop) hipEventDestroy(ev);
+    e->prof_start.clear();
+    e->prof_stop.clear();
+    e->prof_used = 0;
+    e->prof_which = -1;
+}
+
+extern "C" void mapdit_engine_destroy(mapdit_engine_t* e) {
+    if (!e) return;
+    prof_release(e);
+    delete e;
+}
+
+extern "C" int mapdit_engine_profile_begin(mapdit_engine_t* e, int which, int max_events) {
+    MD_CHECK(e && which == MAPDIT_PROF_FC1_FWD && max_events > 0, "engine_profile_begin: bad argument");
+    prof_release(e);
+    e->prof_start.resize(max_events);
+    e->prof_stop.resize(max_events);
+    for (int i = 0; i < max_events; ++i) {
+        if (hipEventCreate(&e->prof_start[i]) != hipSuccess || hipEventCreate(&e->prof_stop[i]) != hipSuccess) {
+            mapdit_set_error("engine_profile_begin: hipEventCreate failed");
+            return MAPDIT_ERR_HIP;
+        }
+    }
+    e->prof_which = which;
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_engine_profile_end(mapdit_engine_t* e, int* count, double* total_ms) {
+    MD_CHECK(e && count && total_ms, "engine_profile_end: null argument");
+    double tot = 0.0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        float ms = 0.f;
+        hipError_t he = hipEventSynchronize(e->prof_stop[i]);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e->prof_start[i], e->prof_stop[i]);
+        MD_CHECK(he == hipSuccess, "engine_profile_end: %s", hipGetErrorString(he));
+        tot += ms;
+    }
+    *count = (int)e->prof_used;
+    *total_ms = tot;
+    prof_release(e);
+    return MAPDIT_OK;
+}
 
 extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host, float* const* grads_host) {
     MD_CHECK(e && params_host, "engine_bind: null argument");
@@ -327,7 +376,11 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
 
     // conditioning: c = mp_sum(t_embedder(t), y_embedder(y), 0.5)        (dit.py:86-88)
     TRY(mapdit_fourier_fwd(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], e->four, N, FOURIER, st));
-    TRY(gemm(MAPDIT_NT, N, D, FOURIER, e->four, FOURIER, W(MAPDIT_P_T0), FOURIER, epi_silu2(e->h1_pre, e->h1_act, D), st));
+    {
+        mapdit_epilogue_t ep = epi_silu2(e->h1_pre, e->h1_act, D);
+        ep.kind = MAPDIT_EPI_SILU2_COND;
+        TRY(gemm(MAPDIT_NT, N, D, FOURIER, e->four, FOURIER, W(MAPDIT_P_T0), FOURIER, ep, st));
+    }
     TRY(gemm(MAPDIT_NT, N, D, D, e->h1_act, D, W(MAPDIT_P_T2), D, epi_f32(e->temb, D), st));
     TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));
     if (save) {
@@ -355,7 +408,10 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
                  epi_resid(save ? b.y : nullptr, xin, xmid, b.mod + 2 * D, 6 * D, T, D), st));
         // MLP branch                                                    (dit_block.py:36)
         TRY(mapdit_modulate_fwd(xmid, b.mod + 3 * D, b.mod + 4 * D, 6 * D, gmlp, b.xm2, N, T, D, st));
+        const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
+        if (timed) hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2(save ? b.hpre : nullptr, b.hact, Hm), st));
+        if (timed) hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
                  epi_resid(save ? b.y2 : nullptr, xmid, xout, b.mod + 5 * D, 6 * D, T, D), st));
     }
@@ -394,15 +450,15 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
 
     // ---- final layer ---------------------------------------------------------------------------------------
     TRY(mapdit_final_out_bwd(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], e->dlin,
-                             64, e->da_bf, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size, c.patch, st));
+                             e->ldl, e->da_bf, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size, c.patch, st));
     for (int w = 0; w < 2; ++w) {
         const int pi = w == 0 ? MAPDIT_P_MS_LIN : MAPDIT_P_SS_LIN;
         const bf16_t* da = e->da_bf + (size_t)w * N * NSCALE;
         TRY(gemm(MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
         TRY(linear_dw(e, pi, da, NSCALE, e->c_bf, D, N, 1.f, st));
     }
-    TRY(gemm(MAPDIT_NN, M, D, 64, e->dlin, 64, W(MAPDIT_P_F_LIN), D, epi_bf16(e->dxm, D), st));
-    TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, 64, e->xmodf, D, M, 1.f, st));
+    TRY(gemm(MAPDIT_NN, M, D, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), D, epi_bf16(e->dxm, D), st));
+    TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, e->ldl, e->xmodf, D, M, 1.f, st));
     {
         const BlockBufs& bl = e->blk[L - 1];
         mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));

@@ -128,7 +128,9 @@ struct EpiStoreF32 {
         p[0] = a; p[1] = b;
     }
 };
-struct EpiSilu2 {
+// TAG only separates the kernel symbols of the block MLP (0) and the tiny conditioning MLP (1) so that per-kernel
+// profiles of the dominant fc1 GEMM are not diluted by the [batch x D] launch.
+template <int TAG> struct EpiSilu2 {
     bf16_t* pre; bf16_t* act; int ldo;
     __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
         float a[8];
@@ -297,7 +299,8 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {
     MD_CHECK(layout >= MAPDIT_NT && layout <= MAPDIT_TN, "gemm: bad layout %d", layout);
     MD_CHECK(M > 0 && N > 0 && K > 0 && A && B && e, "gemm: null/empty argument (M=%d N=%d K=%d)", M, N, K);
-    MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_RESID, "gemm: null output");
+    MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_SILU2_COND || e->kind == MAPDIT_EPI_RESID,
+             "gemm: null output");
     MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
     MD_CHECK(e->ldo % 8 == 0, "gemm: ldo=%d must be a multiple of 8", e->ldo);
     hipStream_t st = (hipStream_t)stream;
@@ -308,7 +311,10 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
             return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreF32{(float*)e->out, e->ldo, e->alpha, e->accumulate}, st);
         case MAPDIT_EPI_SILU2:
             MD_CHECK(e->out2, "gemm: SILU2 needs out2");
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2<0>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+        case MAPDIT_EPI_SILU2_COND:
+            MD_CHECK(e->out2, "gemm: SILU2 needs out2");
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2<1>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
         case MAPDIT_EPI_RESID:
             MD_CHECK(e->out2 && e->aux && e->gate && e->rows_per_sample > 0, "gemm: RESID needs out2, aux, gate, rows_per_sample");
             MD_CHECK(e->ldg % 4 == 0, "gemm: ldg=%d must be a multiple of 4", e->ldg);

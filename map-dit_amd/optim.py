@@ -1,0 +1,102 @@
+"""Optimiser step of the reference training loop as one fused HIP pass over flat buffers:
+``torch.optim.Adam(lr, betas=(0.9, 0.99))`` (reference train.py:57), the LambdaLR schedule (train.py:179-197) and
+the two power-function EMA copies (reference src/ema.py:10-40, 117-140; std 0.05 and 0.1).
+
+With data parallelism the mean over ranks is folded in as the gradient scale (``1 / world_size``) after the
+sum-all-reduce of the flat gradient buffer (see parallel.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def create_lr_lambda(num_lin_warmup: int, start_decay: int):
+    """reference train.py:179-197."""
+
+    def lr_lambda(step):
+        if step + 1 < num_lin_warmup:
+            return (step + 1) / num_lin_warmup
+        if step >= start_decay:
+            return 1.0 / math.sqrt(max(step / start_decay, 1))
+        return 1.0
+
+    return lr_lambda
+
+
+def std_to_gamma(std: float) -> float:
+    """reference src/ema.py:10-20."""
+    t = float(std) ** -2
+    return float(np.roots([1, 7, 16 - t, 12 - t]).real.max())
+
+
+def calc_beta(std: float, t: int) -> float:
+    """reference src/ema.py:33-40."""
+    return (1 - 1 / t) ** (std_to_gamma(std) + 1)
+
+
+class FusedAdamEMA:
+    """Adam + LR schedule + two EMA copies over the model's flat parameter / gradient buffers (one kernel launch)."""
+
+    def __init__(self, model, lr: float = 1e-2, betas=(0.9, 0.99), eps: float = 1e-8, ema_stds=(0.05, 0.1),
+                 lr_lambda=None, grad_scale: float = 1.0):
+        assert len(ema_stds) in (0, 2), "the fused kernel carries exactly two EMA copies (or none)"
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.ema_stds = tuple(ema_stds)
+        self.lr_lambda = lr_lambda or (lambda step: 1.0)
+        self.grad_scale = grad_scale
+        self.step_count = 0
+        flat = model._pflat
+        assert flat is not None and flat.is_cuda and flat.dtype == torch.float32
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.ema = [flat.clone() for _ in self.ema_stds]
+        self._gammas = [std_to_gamma(s) for s in self.ema_stds]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model.parameters():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def current_lr(self) -> float:
+        return self.lr * self.lr_lambda(self.step_count)
+
+    def step(self):
+        m = self.model
+        assert m._gflat is not None, "no gradients: call backward() first"
+        assert m._pflat.numel() == self.exp_avg.numel(), "the model was re-flattened after the optimiser was built"
+        lr = self.current_lr()                       # LambdaLR: lr for optimiser step k uses lambda(k), k from 0
+        self.step_count += 1
+        t = self.step_count
+        b1, b2 = self.betas
+        betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
+        hyper = torch.tensor([lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale],
+                             dtype=torch.float32, device=m._pflat.device)
+        with torch.cuda.device(m._pflat.device):
+            L.lib().adam_ema_step(m._pflat.data_ptr(), m._gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                  L.ptr(self.ema[0]) if self.ema else None, L.ptr(self.ema[1]) if self.ema else None,
+                                  m._pflat.numel(), hyper.data_ptr(), b1, b2, self.eps, L.cur_stream())
+        m.mark_weights_changed()
+
+    def ema_state_dict(self, std: float):
+        """EMA weights as a state_dict with the reference's keys (what src/ema.py:143-155 snapshots), fp32."""
+        i = self.ema_stds.index(std)
+        flat = self.ema[i]
+        sd = {}
+        params = dict(self.model.named_parameters())
+        offs = dict(zip((id(p) for p in self.model.parameters()), self.model._poffs))
+        for k, v in self.model.state_dict().items():
+            if k in params:
+                p = params[k]
+                o = offs[id(p)]
+                sd[k] = flat[o:o + p.numel()].view(p.shape).clone()
+            else:
+                sd[k] = v.clone()
+        return sd

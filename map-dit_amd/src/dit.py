@@ -1,0 +1,447 @@
+"""``DiT`` — the reference's nn.Module surface (src/dit.py:12-118) on top of the HIP engine.
+
+Same constructor arguments, same ``state_dict`` keys, same ``forward(x, t, y)`` /
+``forward_with_cfg(x, t, y, cfg_scale)``, train/eval semantics (training-mode forward rewrites the
+weights in place = forced weight normalisation, mp_linear.py:38-40), autograd through
+``loss.backward()``.  The sub-modules exist to carry the parameters under the reference's names;
+the arithmetic of the whole network runs in ``libmapdit_hip.so`` (``mapdit_engine_*``), there is no
+PyTorch fallback.
+
+Snapshot semantics: every magnitude-preserving feature is on, conditioning is the
+MP-AdaLN shift/scale/gate form — exactly what the reference snapshot implements.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+FOURIER_DIM = 256
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter containers named like the reference's modules
+# ----------------------------------------------------------------------------------------------------
+class _Fused(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter container: its arithmetic runs inside the fused "
+                           "MaP-DiT engine (call the DiT module)")
+
+
+class MPLinear(_Fused):
+    """reference src/basic/mp_linear.py:9-46 (gain is the constant 1)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
+        nn.init.normal_(self.weight)
+
+
+class MPLinearChunk(_Fused):
+    """reference src/basic/mp_linear.py:48-75."""
+
+    def __init__(self, in_dim, out_dim, n_chunks):
+        super().__init__()
+        self.in_dim, self.n_chunks = in_dim, n_chunks
+        self.weight = nn.Parameter(torch.empty(n_chunks * out_dim, in_dim))
+        nn.init.normal_(self.weight)
+
+
+class MPEmbedding(_Fused):
+    """reference src/basic/mp_embedding.py:8-24."""
+
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)
+
+
+class MPSiLU(_Fused):
+    """reference src/basic/mp_silu.py:5-7 (no parameters)."""
+
+
+class Attention(_Fused):
+    """reference src/layers/attention.py:9-27."""
+
+    def __init__(self, in_dim, num_heads):
+        super().__init__()
+        assert in_dim % num_heads == 0
+        self.num_heads, self.head_dim = num_heads, in_dim // num_heads
+        self.qkv_proj = MPLinearChunk(in_dim, in_dim, 3)
+        self.out_proj = MPLinear(in_dim, in_dim)
+        self.scale = 1.0 / math.sqrt(self.head_dim)
+
+
+class MLP(_Fused):
+    """reference src/layers/mlp.py:7-22."""
+
+    def __init__(self, in_dim, out_dim, mlp_ratio=4.0, hidden_dim=None):
+        super().__init__()
+        self.hidden_dim = int(in_dim * mlp_ratio) if hidden_dim is None else hidden_dim
+        self.net = nn.Sequential(MPLinear(in_dim, self.hidden_dim), MPSiLU(), MPLinear(self.hidden_dim, out_dim))
+
+
+class DiTBlock(_Fused):
+    """reference src/blocks/dit_block.py:10-29."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0):
+        super().__init__()
+        self.attn = Attention(hidden_size, num_heads)
+        self.mlp = MLP(hidden_size, hidden_size, mlp_ratio=mlp_ratio)
+        self.modulation = nn.Sequential(MPSiLU(), MPLinearChunk(hidden_size, hidden_size, 6))
+        self.gain_msa = nn.Parameter(torch.tensor(0.0))
+        self.gain_mlp = nn.Parameter(torch.tensor(0.0))
+
+
+class MPScale(_Fused):
+    """reference src/blocks/final_layer.py:12-18."""
+
+    def __init__(self, in_dim, angle_dim=8, zero_init=True):
+        super().__init__()
+        self.angle_dim = angle_dim
+        self.linear = MPLinear(in_dim, angle_dim)
+        self.reference = nn.Parameter(torch.zeros(angle_dim) if zero_init else torch.ones(angle_dim))
+
+
+class FinalLayer(_Fused):
+    """reference src/blocks/final_layer.py:24-51."""
+
+    def __init__(self, hidden_size, patch_size, out_channels, learn_sigma=True):
+        super().__init__()
+        self.learn_sigma = learn_sigma
+        self.linear = MPLinearChunk(hidden_size, patch_size * patch_size * out_channels, 2 if learn_sigma else 1)
+        self.modulation = nn.Sequential(MPSiLU(), MPLinearChunk(hidden_size, hidden_size, 2))
+        self.gain_mod = nn.Parameter(torch.tensor(0.0))
+        self.mean_scale = MPScale(hidden_size, zero_init=False)
+        if learn_sigma:
+            self.sigma_scale = MPScale(hidden_size, zero_init=True)
+
+
+class MPFourier(_Fused):
+    """reference src/blocks/timestep_embedder.py:8-16."""
+
+    def __init__(self, num_channels):
+        super().__init__()
+        self.register_buffer("scale", (2 * torch.pi * torch.randn(num_channels)).to(torch.float32))
+        self.register_buffer("shift", (2 * torch.pi * torch.rand(num_channels)).to(torch.float32))
+
+
+class TimestepEmbedder(_Fused):
+    """reference src/blocks/timestep_embedder.py:24-40."""
+
+    def __init__(self, hidden_size, frequency_embedding_size=FOURIER_DIM):
+        super().__init__()
+        self.mlp = MLP(frequency_embedding_size, hidden_size, hidden_dim=hidden_size)
+        self.embedding = MPFourier(frequency_embedding_size)
+
+
+class LabelEmbedder(_Fused):
+    """reference src/blocks/label_embedder.py:6-34 (token_drop is real: it is the path's only RNG consumer)."""
+
+    def __init__(self, num_classes, hidden_size, dropout_prob):
+        super().__init__()
+        use_cfg_embedding = dropout_prob > 0
+        self.embedding = MPEmbedding(num_classes + use_cfg_embedding, hidden_size)
+        self.num_classes, self.dropout_prob = num_classes, dropout_prob
+
+    def token_drop(self, labels, force_drop_ids=None):
+        if force_drop_ids is None:
+            drop_ids = torch.rand(labels.shape[0], device=labels.device) < self.dropout_prob
+        else:
+            drop_ids = force_drop_ids == 1
+        return torch.where(drop_ids, self.num_classes, labels)
+
+
+def get_2d_sincos_pos_embed(embed_dim: int, grid_size: int) -> np.ndarray:
+    """MAE sin-cos table as the reference builds it (src/pos_embed.py:4-60): first half encodes the w index."""
+    gw, gh = np.meshgrid(np.arange(grid_size, dtype=np.float32), np.arange(grid_size, dtype=np.float32))
+
+    def one_d(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    return np.concatenate([one_d(embed_dim // 2, gw), one_d(embed_dim // 2, gh)], axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# engine runtime (one per (module, mode))
+# ----------------------------------------------------------------------------------------------------
+class _Runtime:
+    """Owns a mapdit engine handle and its workspace tensor."""
+
+    def __init__(self, model: "DiT", max_batch: int, train: bool):
+        lib = L.lib()
+        self.lib, self.train, self.max_batch = lib, train, max_batch
+        self.device = model.pos_embed.device
+        rows = model.y_embedder.embedding.weight.shape[0]
+        self.cfg = L.Config(depth=len(model.blocks), hidden=model.hidden_size, patch=model.patch_size,
+                            input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
+                            mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch)
+        need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
+        if need == 0:
+            raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            lib.engine_create(C.byref(self.cfg), int(train), self.workspace.data_ptr(), need, L.cur_stream(), C.byref(h))
+        self.handle = h
+        self.bound_key = None
+        self.weights_key = None
+
+    def bind(self, model: "DiT"):
+        params = model._param_table()
+        grads = model._grad_table() if self.train else None
+        key = tuple(t.data_ptr() for t in params) + (tuple(g.data_ptr() for g in grads) if grads else ())
+        if key == self.bound_key:
+            return
+        n = len(params)
+        pa = (C.c_void_p * n)(*[t.data_ptr() for t in params])
+        ga = (C.c_void_p * n)(*[g.data_ptr() for g in grads]) if grads else None
+        self.lib.engine_bind(self.handle, pa, ga)
+        self.bound_key = key
+        self.weights_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _DiTFunction(torch.autograd.Function):
+    """Autograd node for the whole network.  Parameter gradients are written by the engine straight into the
+    module's flat gradient buffer (``p.grad`` are views of it), so they are not returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, model, rt, x, t, y_eff, anchor):
+        out = torch.empty(x.shape[0], 2 * model.in_channels, model.input_size, model.input_size, device=x.device)
+        rt.lib.engine_forward(rt.handle, x.data_ptr(), t.data_ptr(), y_eff.data_ptr(), x.shape[0], 1, out.data_ptr(),
+                              L.cur_stream())
+        ctx.model, ctx.rt = model, rt
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, rt = ctx.model, ctx.rt
+        dout = dout.contiguous().float()
+        accumulate = model._attach_grads()
+        keep = model._gflat.clone() if accumulate else None
+        rt.bind(model)
+        rt.lib.engine_backward(rt.handle, dout.data_ptr(), L.cur_stream())
+        if keep is not None:
+            model._gflat.add_(keep)
+        return None, None, None, None, None, None
+
+
+class DiT(nn.Module):
+    """Diffusion model with a Transformer backbone (reference src/dit.py:12-62)."""
+
+    def __init__(self, depth: int, hidden_size: int, patch_size: int, input_size: int = 32, in_channels: int = 3,
+                 num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
+                 learn_sigma: bool = True):
+        super().__init__()
+        if not learn_sigma:
+            raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
+        self.learn_sigma = learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels
+        self.input_size = input_size
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.hidden_size = hidden_size
+        self.depth = depth
+        self.mlp_ratio = mlp_ratio
+        self.class_dropout_prob = class_dropout_prob
+        self.num_classes = num_classes
+
+        self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.y_embedder = LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
+        pe = torch.from_numpy(get_2d_sincos_pos_embed(hidden_size, input_size // patch_size)).float().unsqueeze(0)
+        pe = pe * math.sqrt(pe.shape[-1]) / (torch.linalg.vector_norm(pe, dim=-1, keepdim=True) + 1e-4)   # dit.py:46-48
+        self.register_buffer("pos_embed", pe)
+        self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
+
+        self._rt = {}                 # {train: _Runtime}
+        self._pflat = None            # flat fp32 storage behind every parameter (views)
+        self._gflat = None            # flat gradient buffer, p.grad are views of it
+        self._gviews = None
+        self._w_epoch = 0             # bumped by anything that rewrites parameters through raw pointers
+        self._flatten_parameters()
+
+    # ---- flat parameter / gradient storage ----------------------------------------------------------------
+    def _flatten_parameters(self):
+        """Re-home every parameter as a view of one flat buffer (128-byte aligned slots): lets the optimiser, EMA
+        and the data-parallel gradient reduction work on single contiguous buffers."""
+        params = list(self.parameters())
+        if not params:
+            return
+        dev, dt = params[0].device, params[0].dtype
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 31) // 32 * 32
+        flat = torch.zeros(total, device=dev, dtype=dt)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].view(p.shape).copy_(p.data)
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._pflat, self._poffs = flat, offs
+        self._gflat, self._gviews = None, None
+        self._rt = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten_parameters()
+        return out
+
+    def _attach_grads(self) -> bool:
+        """Make every p.grad a view of the flat gradient buffer.  Returns True when gradients that are already
+        there must be accumulated into (p.grad was not reset to None since the previous backward)."""
+        self._attach_grads_storage()
+        fresh, accumulate = [], False
+        for p, g in zip(self.parameters(), self._gviews):
+            if p.grad is None:
+                p.grad = g
+                fresh.append(g)
+            elif p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+                p.grad = g
+                accumulate = True
+            else:
+                accumulate = True
+        if accumulate:
+            for g in fresh:
+                g.zero_()
+        return accumulate
+
+    def _param_table(self):
+        """Tensors in the order of the engine's parameter table (include/mapdit.h: MAPDIT_P_*, MAPDIT_B_*)."""
+        f = self.final_layer
+        tab = [self.x_embedder.weight, self.t_embedder.mlp.net[0].weight, self.t_embedder.mlp.net[2].weight,
+               self.y_embedder.embedding.weight, f.linear.weight, f.modulation[1].weight, f.mean_scale.linear.weight,
+               f.mean_scale.reference, f.sigma_scale.linear.weight, f.sigma_scale.reference, f.gain_mod,
+               self.t_embedder.embedding.scale, self.t_embedder.embedding.shift, self.pos_embed]
+        for b in self.blocks:
+            tab += [b.attn.qkv_proj.weight, b.attn.out_proj.weight, b.mlp.net[0].weight, b.mlp.net[2].weight,
+                    b.modulation[1].weight, b.gain_msa, b.gain_mlp]
+        return tab
+
+    def _grad_table(self):
+        self._attach_grads_storage()
+        by_id = {id(p): g for p, g in zip(self.parameters(), self._gviews)}
+        scratch = self._buffer_grad_scratch
+        return [by_id.get(id(t), scratch) for t in self._param_table()]
+
+    def _attach_grads_storage(self):
+        if self._gflat is None or self._gflat.device != self._pflat.device:
+            params = list(self.parameters())
+            self._gflat = torch.zeros_like(self._pflat, dtype=torch.float32)
+            self._gviews = [self._gflat[o:o + p.numel()].view(p.shape) for p, o in zip(params, self._poffs)]
+        if getattr(self, "_buffer_grad_scratch", None) is None or self._buffer_grad_scratch.device != self._pflat.device:
+            self._buffer_grad_scratch = torch.zeros(8, device=self._pflat.device)   # buffers have no gradient
+
+    # ---- runtime ----------------------------------------------------------------------------------------------
+    def _runtime(self, batch: int, train: bool) -> _Runtime:
+        if self._pflat is None or not self._pflat.is_cuda:
+            raise L.MapditError("MaP-DiT runs on the MI355X only: move the module to a cuda device (there is no CPU path)")
+        if self._pflat.dtype != torch.float32:
+            raise L.MapditError("master parameters must be fp32 (bf16 is the engine's internal GEMM operand type)")
+        rt = self._rt.get(train)
+        if rt is None or rt.max_batch < batch or rt.device != self._pflat.device:
+            if rt is not None:
+                del self._rt[train]
+            rt = _Runtime(self, max(batch, 1), train)
+            self._rt[train] = rt
+        rt.bind(self)
+        return rt
+
+    def _weights_key(self):
+        return (self._w_epoch, sum(p._version for p in self.parameters()))
+
+    def mark_weights_changed(self):
+        """Call after rewriting parameters through raw pointers (the fused optimiser does)."""
+        self._w_epoch += 1
+
+    def _check_inputs(self, x, t, y):
+        assert x.dim() == 4 and x.shape[1] == self.in_channels and x.shape[2] == x.shape[3] == self.input_size, \
+            f"x must be [N,{self.in_channels},{self.input_size},{self.input_size}], got {tuple(x.shape)}"
+        assert t.shape == (x.shape[0],) and y.shape == (x.shape[0],)
+        x = x.contiguous().float()
+        t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        y = y.to(device=x.device, dtype=torch.int64).contiguous()
+        return x, t, y
+
+    # ---- reference API ----------------------------------------------------------------------------------------------
+    def forward(self, x, t, y):
+        """x [N,C,H,W], t [N], y [N] -> [N,2C,H,W]   (reference src/dit.py:70-105)."""
+        x, t, y = self._check_inputs(x, t, y)
+        if self.training and self.class_dropout_prob > 0:
+            y = self.y_embedder.token_drop(y)                                   # label_embedder.py:19-34
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        rt = self._runtime(x.shape[0], train=need_grad)
+        with torch.cuda.device(x.device):
+            if self.training:
+                rt.lib.engine_prepare_weights(rt.handle, 1, L.cur_stream())    # forced weight norm: rewrites weights
+                rt.weights_key = None
+                for other in self._rt.values():
+                    other.weights_key = None
+            else:
+                key = self._weights_key()
+                if rt.weights_key != key:
+                    rt.lib.engine_prepare_weights(rt.handle, 0, L.cur_stream())
+                    rt.weights_key = key
+            if need_grad:
+                return _DiTFunction.apply(self, rt, x, t, y, self._anchor())
+            out = torch.empty(x.shape[0], 2 * self.in_channels, self.input_size, self.input_size, device=x.device)
+            rt.lib.engine_forward(rt.handle, x.data_ptr(), t.data_ptr(), y.data_ptr(), x.shape[0], 0, out.data_ptr(),
+                                  L.cur_stream())
+            return out
+
+    def _anchor(self):
+        a = getattr(self, "_anchor_t", None)
+        if a is None or a.device != self._pflat.device:
+            a = torch.zeros(1, device=self._pflat.device, requires_grad=True)
+            self._anchor_t = a
+        return a
+
+    def forward_with_cfg(self, x, t, y, cfg_scale):
+        """Classifier-free guidance batch (reference src/dit.py:107-118)."""
+        half = x[: len(x) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = self.forward(combined, t, y)
+        out = torch.empty_like(model_out)
+        hw = self.input_size * self.input_size
+        with torch.cuda.device(model_out.device):
+            L.lib().cfg_combine(model_out.data_ptr(), out.data_ptr(), model_out.shape[0], self.in_channels, hw,
+                                float(cfg_scale), L.cur_stream())
+        return out
+
+    # ---- copying (EMA does copy.deepcopy(model), reference src/ema.py:121) ---------------------------------------------
+    def __deepcopy__(self, memo):
+        new = DiT(depth=self.depth, hidden_size=self.hidden_size, patch_size=self.patch_size, input_size=self.input_size,
+                  in_channels=self.in_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
+                  class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma)
+        new.to(device=self._pflat.device, dtype=self._pflat.dtype)
+        new.load_state_dict(copy.deepcopy(self.state_dict()))
+        for p_new, p_old in zip(new.parameters(), self.parameters()):
+            p_new.requires_grad_(p_old.requires_grad)
+        new.train(self.training)
+        return new
+
+    def __getstate__(self):
+        st = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        st = dict(st)
+        for k in ("_rt", "_gflat", "_gviews", "_anchor_t", "_buffer_grad_scratch"):
+            st[k] = {} if k == "_rt" else None
+        return st

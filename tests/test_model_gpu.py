@@ -1,0 +1,206 @@
+"""End-to-end parity of the HIP engine behind the reference API (DIT_MODELS / create_diffusion) against
+the golden vectors captured from the reference (tests/golden/*.npz) and against the CPU oracle.
+
+Tolerances.  The reference computes in fp32; the engine's GEMM / attention operands are bf16 (fp32 accumulate,
+fp32 residual stream), so the comparison with the fp32 goldens carries bf16 operand rounding (2^-9 per element,
+accumulating over depth): logits are checked norm-wise at 2e-2, losses at 2e-2, gradients at 6e-2 (small /
+cancellation-heavy tensors looser).  Integer/bit-exact items (label drop, timestep maps) are checked exactly,
+and forced-weight-norm rewritten weights (fp32 path) at 2e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, golden_state_dict, load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+LOGIT_TOL = 2e-2
+LOSS_TOL = 2e-2
+GRAD_TOL = 6e-2
+
+
+def build(g, train=False):
+    from mapdit_amd.src.dit import DiT
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    m = DiT(**cfg.to_dict())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    m.train(train)
+    return m, cfg, sd
+
+
+def dev(g, *names):
+    return [torch.from_numpy(g[n]).to(DEV) for n in names]
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
+def test_eval_forward_matches_reference(name):
+    g = load_golden(name)
+    m, cfg, _ = build(g)
+    x, t, y = dev(g, "x", "t", "y")
+    with torch.no_grad():
+        out = m(x, t, y)
+    e = rel_err(out.cpu().numpy(), g["eval_out"])
+    print(f"{name}: eval logits rel err {e:.3e}")
+    assert e < LOGIT_TOL
+    # calling again must give the same bits (cached weight images, no hidden state)
+    with torch.no_grad():
+        out2 = m(x, t, y)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
+def test_training_losses_and_gradients(name):
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden(name)
+    m, cfg, _ = build(g, train=True)
+    x, t, y_eff, noise = dev(g, "x", "t", "y_eff", "noise")
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels      # golden labels already carry the drop
+    diff = create_diffusion(timestep_respacing="")
+    assert diff.num_timesteps == 1000
+    losses = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)
+    losses["loss"].mean().backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "mse", "vb"):
+        e = rel_err(losses[k].detach().cpu().numpy(), g["train_" + k])
+        print(f"{name}: {k} rel err {e:.3e}")
+        assert e < LOSS_TOL, k
+    worst, worst_k = 0.0, ""
+    # the scalar gain gradients are sums of ~1e5 signed terms (heavy cancellation): judge them on the scale of the
+    # largest gain gradient of the model, not on their own (possibly tiny) magnitude
+    gain_scale = max(float(np.abs(g["grad/" + k]).max()) for k, p in m.named_parameters() if p.dim() == 0)
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        gref = g["grad/" + k]
+        if p.dim() == 0:
+            assert abs(float(p.grad) - float(gref)) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            continue
+        e = rel_err(sub(p.grad), gref)
+        if e > worst:
+            worst, worst_k = e, k
+        tol = GRAD_TOL if gref.size >= 64 else 0.15
+        assert e < tol or np.linalg.norm(gref) < 1e-7, (k, e)
+        # forced weight normalisation rewrote the weights in place, on the fp32 path
+        if "postw/" + k in g:
+            assert rel_err(sub(p.detach()), g["postw/" + k]) < 2e-6, k
+    print(f"{name}: worst gradient rel err {worst:.3e} ({worst_k})")
+
+
+def test_gradient_accumulation_and_zero_grad():
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden("tiny_c")
+    m, cfg, _ = build(g, train=False)            # eval mode: weights are not rewritten, so two backward passes are identical
+    x, t, y, noise = dev(g, "x", "t", "y", "noise")
+    diff = create_diffusion("")
+    diff.training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean().backward()
+    g1 = m.blocks[0].attn.qkv_proj.weight.grad.clone()
+    diff.training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean().backward()
+    g2 = m.blocks[0].attn.qkv_proj.weight.grad.clone()
+    assert rel_err(g2.cpu().numpy(), (2 * g1).cpu().numpy()) < 1e-6
+    for p in m.parameters():
+        p.grad = None
+    diff.training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean().backward()
+    assert rel_err(m.blocks[0].attn.qkv_proj.weight.grad.cpu().numpy(), g1.cpu().numpy()) < 1e-6
+
+
+def test_sampler_matches_reference():
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden("tiny_b")
+    m, cfg, _ = build(g)
+    d = create_diffusion("250")
+    assert list(d.timestep_map) == g["timestep_map_250"].tolist()
+    assert list(create_diffusion("5").timestep_map) == g["timestep_map_5"].tolist()
+    z, yy, ts, nz = dev(g, "ps_z", "ps_y", "ps_t", "ps_noise")
+    kw = dict(y=yy, cfg_scale=1.5)
+    with torch.no_grad():
+        mo = d._wrap_model(m.forward_with_cfg)(z, ts, **kw)
+        sample, xstart = d._step_math(mo, z, ts, nz, False)
+    e1, e2 = rel_err(sample.cpu().numpy(), g["ps_sample"]), rel_err(xstart.cpu().numpy(), g["ps_xstart"])
+    print(f"p_sample rel err {e1:.3e}, pred_xstart {e2:.3e}")
+    assert e1 < LOGIT_TOL and e2 < 2 * LOGIT_TOL
+    # loop prefix with injected per-step noise
+    img = z
+    noises = torch.from_numpy(g["loop_noise"]).to(DEV)
+    with torch.no_grad():
+        for k, i in enumerate(list(range(d.num_timesteps))[::-1][:3]):
+            tt = torch.full((z.shape[0],), i, device=DEV, dtype=torch.int64)
+            mo = d._wrap_model(m.forward_with_cfg)(img, tt, **kw)
+            img, _ = d._step_math(mo, img, tt, noises[k], False)
+            e = rel_err(img.cpu().numpy(), g["loop_traj"][k])
+            print(f"loop step {k}: rel err {e:.3e}")
+            assert e < 3 * LOGIT_TOL
+    # public p_sample_loop API runs end to end (own RNG): shape / finiteness on a 2-step schedule
+    d2 = create_diffusion("2")
+    out = d2.p_sample_loop(m.forward_with_cfg, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=DEV)
+    assert out.shape == z.shape and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("name", ["s4_n8", "s2_n2", "b2_n2"])
+def test_named_models_match_reference(name):
+    """DiT-S/4 (BASELINE configs[0]), DiT-S/2 (configs[1]) and DiT-B/2 (the metric's model) against reference outputs."""
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.models import DIT_MODELS
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    fam = {384: "S", 768: "B"}[cfg.hidden_size]
+    m = DIT_MODELS[f"DiT-{fam}/{cfg.patch_size}"](in_channels=4, input_size=32, num_classes=1000)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x, t, y, y_eff, noise = dev(g, "x", "t", "y", "y_eff", "noise")
+    with torch.no_grad():
+        out = m(x, t, y)
+    e = rel_err(out.cpu().numpy(), g["eval_out"])
+    print(f"{name}: eval logits rel err {e:.3e}")
+    assert e < 3e-2
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    losses = create_diffusion("").training_losses(m, x, t, dict(y=y_eff), noise=noise)
+    losses["loss"].mean().backward()
+    e = rel_err(losses["loss"].detach().cpu().numpy(), g["train_loss"])
+    print(f"{name}: loss rel err {e:.3e}")
+    assert e < 3e-2
+    worst = 0.0
+    gain_scale = max(float(g["gradnorm/" + k]) for k, p in m.named_parameters() if p.dim() == 0)
+    for k, p in m.named_parameters():
+        gn = float(g["gradnorm/" + k])
+        if p.dim() == 0:     # cancellation-heavy scalar sums: see test_training_losses_and_gradients
+            assert abs(float(p.grad) - float(g["grad/" + k])) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(g["grad/" + k]))
+            continue
+        if gn < 1e-7:
+            continue
+        got = float(p.grad.double().norm())
+        worst = max(worst, abs(got / gn - 1))
+        assert abs(got / gn - 1) < 0.1, (k, got, gn)
+        e = rel_err(sub(p.grad, stride=4099), g["grad/" + k])
+        assert e < 0.12 or p.numel() < 64, (k, e)
+    print(f"{name}: worst gradient-norm deviation {worst:.3e}")
+
+
+def test_deepcopy_and_state_dict_roundtrip():
+    import copy
+    g = load_golden("tiny_a")
+    m, cfg, sd = build(g)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    e = copy.deepcopy(m).eval().requires_grad_(False)            # what src/ema.py:121 does
+    x, t, y = dev(g, "x", "t", "y")
+    with torch.no_grad():
+        a, b = m(x, t, y), e(x, t, y)
+    assert torch.equal(a, b)
+    half = copy.deepcopy(e).cpu().half().state_dict()            # src/ema.py:153
+    assert half["x_embedder.weight"].dtype == torch.float16
+    with torch.no_grad():
+        for p_e, p_m in zip(e.parameters(), m.parameters()):
+            p_e.lerp_(p_m, 0.5)
+
+
+def test_rejects_unsupported():
+    from mapdit_amd import _lib as L
+    from mapdit_amd.src.dit import DiT
+    xl = DiT(depth=1, hidden_size=144, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10).to(DEV)
+    with pytest.raises(L.MapditError):
+        xl(torch.zeros(2, 4, 16, 16, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV),
+           torch.zeros(2, dtype=torch.long, device=DEV))
