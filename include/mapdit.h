@@ -57,6 +57,8 @@ typedef struct {
     int rows_per_sample;
     float alpha, beta;
     int accumulate;
+    int split_k;       /* STORE_F32 only: K is cut into split_k ranges, partial sum z is stored at out + z*slab_stride */
+    long slab_stride;  /* elements between slabs (the consumer adds the slabs: mapdit_weightnorm_bwd) */
 } mapdit_epilogue_t;
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
@@ -71,9 +73,10 @@ int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda
  * ------------------------------------------------------------------------------------------------------------ */
 int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16, float* w_f32,
                           float* inv, void* stream);
-/* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)), G rows have stride ldg. */
-int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, float* dW, int rows, int cols, float out_scale,
-                          int accumulate, void* stream);
+/* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)).  G rows have stride ldg; G may be
+ * given as nslabs partial sums slab_stride elements apart (split-K GEMM output), added here in a fixed order. */
+int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
+                          int cols, float out_scale, int accumulate, void* stream);
 
 /* torch.optim.Adam (train.py:57) fused with the two power-function EMA copies (src/ema.py:135-140) over flat
  * fp32 buffers.  hyper (device, 5 floats): lr/(1-b1^t), 1/sqrt(1-b2^t), ema beta a, ema beta b, grad scale. */

@@ -23,7 +23,7 @@ class MapditError(RuntimeError):
 
 class Epilogue(C.Structure):
     _fields_ = [("kind", ci), ("out", vp), ("ldo", ci), ("out2", vp), ("aux", vp), ("gate", vp), ("ldg", ci),
-                ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci)]
+                ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci), ("split_k", ci), ("slab_stride", cl)]
 
 
 class ResidModBwd(C.Structure):
@@ -51,7 +51,7 @@ PROF_FC1_FWD = 0
 _SIGS = {
     "mapdit_gemm_bf16": [ci, ci, ci, ci, vp, ci, vp, ci, C.POINTER(Epilogue), vp],
     "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
-    "mapdit_weightnorm_bwd": [vp, vp, ci, vp, ci, ci, cf, ci, vp],
+    "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],

@@ -71,6 +71,7 @@ struct mapdit_engine {
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
     bf16_t *dy, *dh, *dxm, *dO, *doT, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
+    long G_cap = 0;                       // floats available in G (split-K slabs)
     // optional HIP-event timing of one kernel family (bench.py roofline)
     int prof_which = -1;
     size_t prof_used = 0;
@@ -152,7 +153,9 @@ size_t carve(mapdit_engine* e, void* base) {
         if ((size_t)Hm * D > gmax) gmax = (size_t)Hm * D;
         if ((size_t)D * FOURIER > gmax) gmax = (size_t)D * FOURIER;
         if ((size_t)D * e->ldp > gmax) gmax = (size_t)D * e->ldp;
+        if (gmax < (size_t)1152 * 128 * 128) gmax = (size_t)1152 * 128 * 128;   // room for ~1024 split-K tile slabs
         e->G = cv.take<float>(gmax);
+        e->G_cap = (long)gmax;
         e->DXa = cv.take<float>(M * D);
         e->DXb = cv.take<float>(M * D);
         e->dmod = cv.take<float>((size_t)L * N * 6 * D);
@@ -243,11 +246,33 @@ mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const floa
     e.ldo = ldo; e.alpha = CA; e.beta = CB; return e;
 }
 
+// Largest divisor s of K/64 with tiles*s <= ~1024 blocks (4 per CU) and s <= max_slabs.
+int pick_split_k(int rows, int cols, int K, long max_slabs) {
+    if (K % 64 != 0 || rows % 8 != 0 || cols % 8 != 0) return 1;       // not on the MFMA path
+    const int tiles = cdiv(rows, 128) * cdiv(cols, 128);
+    const int units = K / 64;
+    long want = 1024 / tiles;
+    if (want > max_slabs) want = max_slabs;
+    if (want > units / 4) want = units / 4;                             // keep >= 4 K-tiles per block
+    int best = 1;
+    for (int s = 1; s <= want; ++s)
+        if (units % s == 0) best = s;
+    return best;
+}
+
 // dW for one linear: G = dy^T x (TN GEMM into scratch), then the weight-norm Jacobian into the bound grad.
 int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf16_t* x, int ld_x, int K, float alpha, void* st) {
     const WeightImg& w = e->wimg[pidx];
-    TRY(gemm(MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, epi_f32(e->G, w.cols, alpha), st));
-    if (e->grads[pidx]) TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
+    // Few output tiles, very long K (= tokens): cut K into slabs so the launch fills the chip; the slabs are summed,
+    // in a fixed order, by the weight-norm backward that consumes G anyway.
+    const long slab = (long)w.rows * w.cols;
+    const int split = pick_split_k(w.rows, w.cols, K, e->G_cap / slab);
+    mapdit_epilogue_t ep = epi_f32(e->G, w.cols, alpha);
+    ep.split_k = split;
+    ep.slab_stride = slab;
+    TRY(gemm(MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
+    if (e->grads[pidx])
+        TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
     return MAPDIT_OK;
 }
 
@@ -527,12 +552,16 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
     // ---- patch embedding: x0 = (x_embedder(patches) + pos) * C5 -----------------------------------------------------
     {
         const float c5 = 0.70710678118654752f;
-        TRY(gemm(MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, epi_f32(e->G, e->ldp, c5), st));
-        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
+        const long slab = (long)D * e->ldp;
+        mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5);
+        ep.split_k = pick_split_k(D, e->ldp, M, e->G_cap / slab);
+        ep.slab_stride = slab;
+        TRY(gemm(MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, ep, st));
+        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
     }
     // ---- conditioning path ------------------------------------------------------------------------------------------
     TRY(mapdit_cond_combine_bwd(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, st));
-    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
+    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
     TRY(gemm(MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
     TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));
     TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));

@@ -38,6 +38,8 @@ struct GemmP {
     int lda, ldb;
     int M, N, K;
     int tiles_n;
+    int tiles;      // output tiles (grid = tiles * split_k)
+    int split_k;    // K is cut into split_k equal ranges; slab z of the output holds the partial sum of range z
 };
 
 // ---- staging: HBM -> LDS by LDS-DMA --------------------------------------------------------------
@@ -107,7 +109,7 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {
 
 struct EpiStoreBf16 {
     bf16_t* out; int ldo; float alpha;
-    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = alpha * v[i];
@@ -115,9 +117,9 @@ struct EpiStoreBf16 {
     }
 };
 struct EpiStoreF32 {
-    float* out; int ldo; float alpha; int accumulate;
-    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
-        float4* p = (float4*)(out + (size_t)m * ldo + n);
+    float* out; int ldo; float alpha; int accumulate; long slab_stride;
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int z = 0) const {
+        float4* p = (float4*)(out + (size_t)z * slab_stride + (size_t)m * ldo + n);
         float4 a = make_float4(alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]);
         float4 b = make_float4(alpha * v[4], alpha * v[5], alpha * v[6], alpha * v[7]);
         if (accumulate) {
@@ -132,7 +134,7 @@ struct EpiStoreF32 {
 // profiles of the dominant fc1 GEMM are not diluted by the [batch x D] launch.
 template <int TAG> struct EpiSilu2 {
     bf16_t* pre; bf16_t* act; int ldo;
-    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float a[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = silu_f(v[i]) * (1.f / MP_SILU_DIV);
@@ -142,7 +144,7 @@ template <int TAG> struct EpiSilu2 {
 };
 struct EpiResid {
     bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
-    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         const float4* g = (const float4*)(gate + (size_t)(m / rows) * ldg + n);
         const float4* xi = (const float4*)(xin + (size_t)m * ldo + n);
         float4 g0 = g[0], g1 = g[1], x0 = xi[0], x1 = xi[1];
@@ -158,7 +160,7 @@ struct EpiResid {
 };
 struct EpiDSilu {
     bf16_t* out; const bf16_t* pre; int ldo;
-    __device__ __forceinline__ void operator()(int m, int n, const float* v) const {
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float h[8], w[8];
         load8_bf16(pre + (size_t)m * ldo + n, h);
 #pragma unroll
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (wg / p.tiles_n) * BM, n0 = (wg % p.tiles_n) * BN;
+    const int z = wg / p.tiles, tile = wg - z * p.tiles;      // z-major: neighbouring blocks share operand panels
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int kbeg = z * (p.K / p.split_k);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -187,16 +191,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BKT;
-    stage_tile<AK>(p.A, p.lda, m0, p.M, 0, smem, wave, lane);
-    stage_tile<BK>(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    const int nk = p.K / p.split_k / BKT;
+    stage_tile<AK>(p.A, p.lda, m0, p.M, kbeg, smem, wave, lane);
+    stage_tile<BK>(p.B, p.ldb, n0, p.N, kbeg, smem + TILE_BYTES, wave, lane);
     for (int t = 0; t < nk; ++t) {
         __syncthreads();   // tile t has landed (vmcnt(0) + barrier); everyone is done with the other buffer
         char* cur = smem + (t & 1) * BUF_BYTES;
         if (t + 1 < nk) {
             char* nxt = smem + ((t + 1) & 1) * BUF_BYTES;
-            stage_tile<AK>(p.A, p.lda, m0, p.M, (t + 1) * BKT, nxt, wave, lane);
-            stage_tile<BK>(p.B, p.ldb, n0, p.N, (t + 1) * BKT, nxt + TILE_BYTES, wave, lane);
+            stage_tile<AK>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BKT, nxt, wave, lane);
+            stage_tile<BK>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BKT, nxt + TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
             float v[8];
             *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS_LD + col);
             *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS_LD + col + 4);
-            epi(gm, gn, v);
+            epi(gm, gn, v, z);
         }
     }
 }
@@ -258,7 +262,7 @@ __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long 
 
 template <class Epi>
 int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, Epi epi,
-           hipStream_t st) {
+           hipStream_t st, int split_k = 1) {
     const bool a_kmaj = layout == MAPDIT_TN, b_kmaj = layout != MAPDIT_NT;
     bool mfma = (K % BKT == 0) && (N % 8 == 0) && K > 0;
     if (a_kmaj && (M % 8 != 0 || lda % 8 != 0)) mfma = false;
@@ -266,9 +270,14 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (!a_kmaj && lda % 8 != 0) mfma = false;
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
+    if (split_k > 1 && (!mfma || K % (split_k * BKT) != 0)) {
+        mapdit_set_error("gemm: split_k=%d needs the MFMA path and K %% (split_k*64) == 0 (K=%d)", split_k, K);
+        return MAPDIT_ERR_ARG;
+    }
     if (mfma) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN)};
-        const int grid = cdiv(M, BM) * p.tiles_n;
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k};
+        p.tiles = cdiv(M, BM) * p.tiles_n;
+        const int grid = p.tiles * split_k;
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
@@ -304,11 +313,15 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
     MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
     MD_CHECK(e->ldo % 8 == 0, "gemm: ldo=%d must be a multiple of 8", e->ldo);
     hipStream_t st = (hipStream_t)stream;
+    MD_CHECK(e->split_k <= 1 || e->kind == MAPDIT_EPI_STORE_F32, "gemm: split_k is only available with EPI_STORE_F32");
     switch (e->kind) {
         case MAPDIT_EPI_STORE_BF16:
             return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreBf16{(bf16_t*)e->out, e->ldo, e->alpha}, st);
         case MAPDIT_EPI_STORE_F32:
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreF32{(float*)e->out, e->ldo, e->alpha, e->accumulate}, st);
+            MD_CHECK(e->split_k <= 1 || !e->accumulate, "gemm: split_k with accumulate is not supported");
+            return launch(layout, M, N, K, A, lda, B, ldb,
+                          EpiStoreF32{(float*)e->out, e->ldo, e->alpha, e->accumulate, e->slab_stride}, st,
+                          e->split_k > 1 ? e->split_k : 1);
         case MAPDIT_EPI_SILU2:
             MD_CHECK(e->out2, "gemm: SILU2 needs out2");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2<0>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);

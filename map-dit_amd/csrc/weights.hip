@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__
 
 // Backward of w = out_scale * W / (n + eps), n = |W|:  dW = out_scale * (G/(n+eps) - W (G.W) / (n (n+eps)^2)).
 __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, const float* __restrict__ G, int ldg,
-                                                           float* __restrict__ dW, int rows, int cols,
-                                                           float out_scale, int accumulate) {
+                                                           int nslabs, long slab_stride, float* __restrict__ dW, int rows,
+                                                           int cols, float out_scale, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     float* d = dW + (size_t)row * cols;
     float ss = 0.f, gw = 0.f;
     for (int c = lane; c < cols; c += 64) {
-        const float a = w[c], b = g[c];
+        float b = g[c];
+        for (int s = 1; s < nslabs; ++s) b += g[(size_t)s * slab_stride + c];
+        const float a = w[c];
         ss += a * a;
         gw += a * b;
     }
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     const float a1 = out_scale / (n + NORM_EPS);
     const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
     for (int c = lane; c < cols; c += 64) {
-        float r = a1 * g[c] - a2 * w[c];
+        float b = g[c];
+        for (int s = 1; s < nslabs; ++s) b += g[(size_t)s * slab_stride + c];
+        float r = a1 * b - a2 * w[c];
         if (accumulate) r += d[c];
         d[c] = r;
     }
@@ -137,11 +141,11 @@ extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, f
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, float* dW, int rows, int cols,
-                                     float out_scale, int accumulate, void* stream) {
-    MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols, "weightnorm_bwd: null/empty argument");
-    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg, dW,
-                       rows, cols, out_scale, accumulate);
+extern "C" int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, int nslabs, long slab_stride, float* dW,
+                                     int rows, int cols, float out_scale, int accumulate, void* stream) {
+    MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols && nslabs >= 1, "weightnorm_bwd: null/empty argument");
+    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg, nslabs,
+                       slab_stride, dW, rows, cols, out_scale, accumulate);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

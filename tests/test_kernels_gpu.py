@@ -75,6 +75,30 @@ def test_gemm_layouts(L, layout, shape):
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3
 
 
+def test_gemm_split_k_slabs_feed_weightnorm_bwd(L):
+    """dW = dy^T x with K cut into slabs; mapdit_weightnorm_bwd adds the slabs in order (deterministic split-K)."""
+    from oracle.dit_oracle import normalize
+    rows, cols, K, S = 256, 128, 1024, 8
+    dy, x = bf16_exact(K, rows, seed=21), bf16_exact(K, cols, seed=22)
+    G_ref = (dy.double().t() @ x.double()).float()
+    slabs = torch.full((S, rows, cols), float("nan"), device=DEV)
+    run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=S,
+             slab_stride=rows * cols)
+    assert rel_err(slabs.sum(0).cpu().numpy(), G_ref.numpy()) < 2e-6
+    assert float((slabs[0].cpu() - (dy[:K // S].double().t() @ x[:K // S].double()).float()).abs().max()) < 1e-3
+    W = torch.randn(rows, cols, generator=torch.Generator().manual_seed(23))
+    Wr = W.clone().requires_grad_(True)
+    (normalize(Wr) / math.sqrt(cols)).backward(G_ref)
+    dW = torch.zeros(rows, cols, device=DEV)
+    Wd = W.to(DEV)
+    L.lib().weightnorm_bwd(p(Wd), p(slabs), cols, S, rows * cols, p(dW), rows, cols, 1.0, 0, st())
+    torch.cuda.synchronize()
+    assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
+    with pytest.raises(L.MapditError):                      # K not divisible into 64-wide slabs
+        run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=3,
+                 slab_stride=rows * cols)
+
+
 def test_gemm_identity_asymmetric(L):
     """A = I with an asymmetric B: output must be B^T exactly (guide: catches row/col swaps)."""
     N, K = 128, 128
@@ -166,7 +190,7 @@ def test_weightnorm(L, rows, cols, forced):
     dW = torch.zeros(rows, cols, device=DEV)
     Gd = G.to(DEV).contiguous()
     Wnd = Wn.to(DEV)
-    L.lib().weightnorm_bwd(p(Wnd), p(Gd), cols + 3, p(dW), rows, cols, 1.0, 0, st())
+    L.lib().weightnorm_bwd(p(Wnd), p(Gd), cols + 3, 1, 0, p(dW), rows, cols, 1.0, 0, st())
     torch.cuda.synchronize()
     assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
 
