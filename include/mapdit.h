@@ -63,6 +63,8 @@ typedef struct {
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
                      const mapdit_epilogue_t* epi, void* stream);
+/* Edge (128 or 256) of the output tile the dispatcher picks for an [M, N] result (to size split_k). */
+int mapdit_gemm_tile_size(int M, int N);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight normalisation of MPLinear / MPLinearChunk / MPEmbedding (src/utils.py:19-34, mp_linear.py:38-44,66-74,
@@ -74,8 +76,9 @@ int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda
 int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16, float* w_f32,
                           float* inv, void* stream);
 /* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)).  G rows have stride ldg; G may be
- * given as nslabs partial sums slab_stride elements apart (split-K GEMM output), added here in a fixed order. */
-int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
+ * given as nslabs partial sums slab_stride elements apart (split-K GEMM output), added here in a fixed order.
+ * G is scratch: with nslabs > 1 its slab 0 is overwritten with the sum. */
+int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
                           int cols, float out_scale, int accumulate, void* stream);
 
 /* torch.optim.Adam (train.py:57) fused with the two power-function EMA copies (src/ema.py:135-140) over flat

@@ -86,6 +86,7 @@ _SIGS = {
 _OTHER = {
     "mapdit_last_error": (C.c_char_p, []),
     "mapdit_abi_version": (ci, []),
+    "mapdit_gemm_tile_size": (ci, [ci, ci]),
     "mapdit_engine_workspace_bytes": (C.c_size_t, [C.POINTER(Config), ci]),
     "mapdit_engine_destroy": (None, [vp]),
 }

@@ -249,9 +249,10 @@ mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const floa
 // Largest divisor s of K/64 with tiles*s <= ~1024 blocks (4 per CU) and s <= max_slabs.
 int pick_split_k(int rows, int cols, int K, long max_slabs) {
     if (K % 64 != 0 || rows % 8 != 0 || cols % 8 != 0) return 1;       // not on the MFMA path
-    const int tiles = cdiv(rows, 128) * cdiv(cols, 128);
+    const int edge = mapdit_gemm_tile_size(rows, cols);
+    const int tiles = cdiv(rows, edge) * cdiv(cols, edge);
     const int units = K / 64;
-    long want = 1024 / tiles;
+    long want = (edge == 256 ? 512 : 1024) / tiles;      // ~2 (256^2, 1 per CU) or ~4 (128^2, 2 per CU) rounds of the chip
     if (want > max_slabs) want = max_slabs;
     if (want > units / 4) want = units / 4;                             // keep >= 4 K-tiles per block
     int best = 1;

@@ -12,7 +12,7 @@
 // under the current tile's MFMAs.  The LDS image is lane-linear (a DMA constraint), so the bank-conflict
 // swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the fragment read:
 //   row-major operand  : [128 rows][128 B]  chunk16 ^= row & 7            read with ds_read_b128
-//   K-major operand    : [64 k][256 B]      chunk16 ^= (k & 7) << 1       read with ds_read_b64_tr_b16
+//   K-major operand    : [64 k][256 B]      chunk16 ^= kswz(k) << 1       read with ds_read_b64_tr_b16
 // The accumulators are produced transposed (MFMA "A" = the N-side operand) so that each lane owns four
 // consecutive columns of one output row; the tile is then bounced through LDS (aliasing the staging
 // buffers) so the epilogue runs on whole 8-column row chunks with fully coalesced 16/32-byte accesses.
@@ -42,6 +42,11 @@ struct GemmP {
     int split_k;    // K is cut into split_k equal ranges; slab z of the output holds the partial sum of range z
 };
 
+// Swizzle key of K-major row k.  One ds_read_b64_tr_b16 half-wave touches rows {8g+q, q = 0..3, g = 0..1} (then the
+// same +4), each row a 32-byte run: the 8 rows must land on 8 different 32-byte bank groups of the 256-byte bank
+// row, so rows k and k+8 need different keys ((k & 7) alone made them collide: 2-way conflict on every read).
+__device__ __forceinline__ int kswz(int k) { return (k & 3) | ((k >> 1) & 4); }
+
 // ---- staging: HBM -> LDS by LDS-DMA --------------------------------------------------------------
 template <int KIND>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0,
@@ -58,7 +63,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
             src = G + (size_t)grow * ld + k0 + c * 8;
         } else {
             const int krow = seg * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ ((krow & 7) << 1);
+            const int c = (lane & 15) ^ (kswz(krow) << 1);
             int col = idx0 + c * 8;
             col = col < idx_max ? col : 0;
             src = G + (size_t)(k0 + krow) * ld + col;
@@ -80,8 +85,8 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, 
         const int k_a = 32 * ks + 8 * g + q, k_b = k_a + 4;
         const int c = (i0 >> 3) + (pp >> 1);
         const int sub = (pp & 1) << 3;
-        const int off_a = k_a * 256 + ((c ^ ((k_a & 7) << 1)) << 4) + sub;
-        const int off_b = k_b * 256 + ((c ^ ((k_b & 7) << 1)) << 4) + sub;
+        const int off_a = k_a * 256 + ((c ^ (kswz(k_a) << 1)) << 4) + sub;
+        const int off_b = k_b * 256 + ((c ^ (kswz(k_b) << 1)) << 4) + sub;
         typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
         bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_a));
         bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_b));
@@ -242,6 +247,202 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     }
 }
 
+// ---- the large-tile kernel: 256x256x64, 8 waves (2 M x 4 N, 128x64 per wave), one workgroup per CU ---------------
+// Staggered 8-phase schedule (guide §5 "The 256^2 8-phase template"), written against explicit hazard rules:
+//
+//  * LDS = 2 K-tile buffers x 4 half-tile slots {A0, A1, B0, B1} of 16 KiB (128 idx x 64 k, the same swizzled images
+//    as the 128^2 kernel).  Half h of the M side holds, for both wave rows, the wave's rows [64h, 64h+64); half h of
+//    the N side holds, for all four wave columns, the wave's columns [32h, 32h+32).  A K-tile is consumed in four
+//    phases, one 64x32 quadrant of the wave's output each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); every phase reads only
+//    the operand half that changed (8 or 4 ds_read_b128) and issues 16 MFMAs.
+//  * Each phase is a LOAD interval {ds_read fragments; issue ONE half-tile of LDS-DMA; counted waits; barrier} and an
+//    MFMA interval {16 MFMAs; barrier}.  Waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave's
+//    MFMA interval overlaps its partner's LOAD interval.
+//  * DMA order per wave: ... B0[t+1] (phase 1 of tile t), A0[t+2] (2), B1[t+2] (3), A1[t+2] (4), B0[t+2] (phase 1 of
+//    t+1) ...: always into the slot whose last ds_read was the phase before.  The only DMA wait is in phase 4:
+//    vmcnt(6) leaves the three youngest half-tiles in flight and retires all of tile t+1, which is read from the next
+//    phase on.  RAW: a wait in LOAD(j) + that interval's barrier, in both wave groups, precedes any read in LOAD(j+1).
+//    WAR: a slot's ds_reads are drained by lgkmcnt(0) inside LOAD(k) before its barrier; the slot is re-staged in
+//    LOAD(k+1) at the earliest.  Both hold for either wave group because the groups are exactly one barrier apart.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int SLOT_BYTES = 16384, KBUF_BYTES = 4 * SLOT_BYTES;
+constexpr int OFF_A0 = 0, OFF_A1 = SLOT_BYTES, OFF_B0 = 2 * SLOT_BYTES, OFF_B1 = 3 * SLOT_BYTES;
+constexpr int CS2_LD = 260;                               // fp32 row stride of the epilogue image (1040 B)
+constexpr int SMEM2_BYTES = 128 * CS2_LD * 4;             // 133,120 B >= 2 x 64 KiB staging
+
+template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
+    return SIDE == 0 ? ((i >> 6) * 128 + h * 64 + (i & 63)) : ((i >> 5) * 64 + h * 32 + (i & 31));
+}
+
+template <int KIND, int SIDE>
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, int h,
+                                           char* slot, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int seg = wave * 2 + j;
+        const bf16_t* src;
+        if (KIND == OP_ROW) {
+            const int row = seg * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            int g = idx0 + half_map<SIDE>(row, h);
+            g = g < idx_max ? g : idx_max - 1;
+            src = G + (size_t)g * ld + k0 + c * 8;
+        } else {
+            const int krow = seg * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (kswz(krow) << 1);
+            int col = idx0 + half_map<SIDE>(c * 8, h);
+            col = col < idx_max ? col : 0;
+            src = G + (size_t)(k0 + krow) * ld + col;
+        }
+        __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(slot + seg * 1024), 16, 0, 0);
+    }
+}
+
+#define G256_END_LOAD()                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+#define G256_END_MFMA()                                   \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <int AK, int BK, class Epi>
+__global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;               // wm doubles as the stagger group (waves 4-7 run behind)
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int z = wg / p.tiles, tile = wg - z * p.tiles;
+    const int m0 = (tile / p.tiles_n) * BM2, n0 = (tile % p.tiles_n) * BN2;
+    const int kbeg = z * (p.K / p.split_k);
+    const int nk = p.K / p.split_k / BKT;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[4][2], fb[2][2];
+
+    auto load_a = [&](const char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK>(slot, wm * 64 + i * 16, ks, lane);
+    };
+    auto load_b = [&](const char* slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = read_frag<BK>(slot, wn * 32 + j * 16, ks, lane);
+    };
+#define G256_MFMA(MQ, NQ)                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+        acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0)
+
+    // prologue: all of tile 0, and tile 1's A0, B1, A1 (its B0 is phase 1's DMA)
+    stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg, 0, smem + OFF_A0, wave, lane);
+    stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 0, smem + OFF_B0, wave, lane);
+    stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 1, smem + OFF_B1, wave, lane);
+    stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg, 1, smem + OFF_A1, wave, lane);
+    if (nk > 1) {
+        char* b1 = smem + KBUF_BYTES;
+        stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 0, b1 + OFF_A0, wave, lane);
+        stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 1, b1 + OFF_B1, wave, lane);
+        stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 1, b1 + OFF_A1, wave, lane);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) {                                         // stagger: the second wave group runs one interval behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int t = 0; t < nk; ++t) {
+        char* cur = smem + (t & 1) * KBUF_BYTES;
+        char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
+        const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+        // phase 1: quadrant (0,0); DMA B0 of tile t+1
+        load_a(cur + OFF_A0);
+        load_b(cur + OFF_B0);
+        if (has1) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k1, 0, nxt + OFF_B0, wave, lane);
+        G256_END_LOAD();
+        G256_MFMA(0, 0);
+        G256_END_MFMA();
+        // phase 2: quadrant (0,1); DMA A0 of tile t+2 into the slot phase 1 just finished with
+        load_b(cur + OFF_B1);
+        if (has2) stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 0, cur + OFF_A0, wave, lane);
+        G256_END_LOAD();
+        G256_MFMA(0, 1);
+        G256_END_MFMA();
+        // phase 3: quadrant (1,1); DMA B1 of tile t+2
+        load_a(cur + OFF_A1);
+        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+        G256_END_LOAD();
+        G256_MFMA(1, 1);
+        G256_END_MFMA();
+        // phase 4: quadrant (1,0); DMA A1 of tile t+2; retire tile t+1 (three half-tiles stay in flight)
+        load_b(cur + OFF_B0);
+        if (has2) {
+            stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 1, cur + OFF_A1, wave, lane);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G256_END_LOAD();
+        G256_MFMA(1, 0);
+        G256_END_MFMA();
+    }
+    if (wm == 0) {                                         // rebalance the barrier count of the two groups
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+
+    // epilogue: two passes of 128 rows through LDS, then whole 8-column row chunks per thread
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + i * 16 + (lane & 15);
+                const int col = wn * 64 + j * 16 + 4 * (lane >> 4);
+                *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (tid >> 5) + 16 * it, col = (tid & 31) * 8;
+            const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63), gn = n0 + col;
+            if (gm < p.M && gn < p.N) {
+                float v[8];
+                *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + col);
+                *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + col + 4);
+                epi(gm, gn, v, z);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 64 != 0: tiny conditioning GEMMs) --------
 // One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
 template <class Epi>
@@ -260,6 +461,19 @@ __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long 
     epi(m, n, v);
 }
 
+}  // namespace
+
+// Output tile edge the dispatcher uses for an [M, N] result: 256 (8-wave staggered kernel, one workgroup per CU) for
+// token-sized problems, 128 for small ones (conditioning path, final linear).  Exposed so callers can size split-K.
+extern "C" int mapdit_gemm_tile_size(int M, int N) {
+    const char* env = getenv("MAPDIT_GEMM_TILE");         // A/B switch for benchmarking (read per call, cheap)
+    const int force = env ? atoi(env) : 0;
+    if (force == 128 || force == 256) return force;
+    return (M >= 512 && N >= 256) ? 256 : 128;
+}
+
+namespace {
+
 template <class Epi>
 int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, Epi epi,
            hipStream_t st, int split_k = 1) {
@@ -274,7 +488,14 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         mapdit_set_error("gemm: split_k=%d needs the MFMA path and K %% (split_k*64) == 0 (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
-    if (mfma) {
+    if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k};
+        p.tiles = cdiv(M, BM2) * p.tiles_n;
+        const int grid = p.tiles * split_k;
+        if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
+        else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
+        else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
+    } else if (mfma) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;

@@ -59,34 +59,62 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__
 }
 
 // Backward of w = out_scale * W / (n + eps), n = |W|:  dW = out_scale * (G/(n+eps) - W (G.W) / (n (n+eps)^2)).
-__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, const float* __restrict__ G, int ldg,
+// G may arrive as `nslabs` split-K partial sums: pass 1 adds them in slab order (deterministic) and, when there is
+// more than one, parks the sum in slab 0 so that pass 2 re-reads one L2-hot row instead of all slabs again.
+template <bool VEC>
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, float* __restrict__ G, int ldg,
                                                            int nslabs, long slab_stride, float* __restrict__ dW, int rows,
                                                            int cols, float out_scale, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* w = W + (size_t)row * cols;
-    const float* g = G + (size_t)row * ldg;
+    float* g = G + (size_t)row * ldg;
     float* d = dW + (size_t)row * cols;
     float ss = 0.f, gw = 0.f;
-    for (int c = lane; c < cols; c += 64) {
-        float b = g[c];
-        for (int s = 1; s < nslabs; ++s) b += g[(size_t)s * slab_stride + c];
-        const float a = w[c];
-        ss += a * a;
-        gw += a * b;
+    if (VEC) {
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 b = *(const float4*)(g + c);
+            for (int s = 1; s < nslabs; ++s) {
+                const float4 t = *(const float4*)(g + (size_t)s * slab_stride + c);
+                b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
+            }
+            if (nslabs > 1) *(float4*)(g + c) = b;
+            const float4 a = *(const float4*)(w + c);
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            gw += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) {
+            float b = g[c];
+            for (int s = 1; s < nslabs; ++s) b += g[(size_t)s * slab_stride + c];
+            if (nslabs > 1) g[c] = b;
+            const float a = w[c];
+            ss += a * a;
+            gw += a * b;
+        }
     }
     ss = wave_sum(ss);
     gw = wave_sum(gw);
     const float n = sqrtf(ss);
     const float a1 = out_scale / (n + NORM_EPS);
     const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
-    for (int c = lane; c < cols; c += 64) {
-        float b = g[c];
-        for (int s = 1; s < nslabs; ++s) b += g[(size_t)s * slab_stride + c];
-        float r = a1 * b - a2 * w[c];
-        if (accumulate) r += d[c];
-        d[c] = r;
+    if (VEC) {
+        for (int c = lane * 4; c < cols; c += 256) {      // each lane re-reads exactly the columns it wrote above
+            const float4 b = *(const float4*)(g + c), a = *(const float4*)(w + c);
+            float4 r = make_float4(a1 * b.x - a2 * a.x, a1 * b.y - a2 * a.y, a1 * b.z - a2 * a.z, a1 * b.w - a2 * a.w);
+            if (accumulate) {
+                const float4 o = *(const float4*)(d + c);
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            *(float4*)(d + c) = r;
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) {
+            float r = a1 * g[c] - a2 * w[c];
+            if (accumulate) r += d[c];
+            d[c] = r;
+        }
     }
 }
 
@@ -141,11 +169,17 @@ extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, f
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_weightnorm_bwd(const float* W, const float* G, int ldg, int nslabs, long slab_stride, float* dW,
+extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW,
                                      int rows, int cols, float out_scale, int accumulate, void* stream) {
     MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols && nslabs >= 1, "weightnorm_bwd: null/empty argument");
-    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg, nslabs,
-                       slab_stride, dW, rows, cols, out_scale, accumulate);
+    const bool vec = (cols % 4 == 0) && (ldg % 4 == 0) && (slab_stride % 4 == 0) &&
+                     ((((uintptr_t)W | (uintptr_t)G | (uintptr_t)dW) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(weightnorm_bwd_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg,
+                           nslabs, slab_stride, dW, rows, cols, out_scale, accumulate);
+    else
+        hipLaunchKernelGGL(weightnorm_bwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg,
+                           nslabs, slab_stride, dW, rows, cols, out_scale, accumulate);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -58,7 +58,9 @@ def run_gemm(L, layout, a, b, kind, M, N, K, **kw):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 128), (200, 136, 192), (1024, 768, 768), (77, 32, 64),
-                                   (64, 24, 256), (8, 128, 32), (130, 128, 8)])
+                                   (64, 24, 256), (8, 128, 32), (130, 128, 8),
+                                   # 256x256 staggered kernel (M >= 512, N >= 256): 1..7 K-tiles, ragged edges
+                                   (512, 256, 64), (512, 256, 128), (768, 512, 192), (600, 264, 448), (2048, 3072, 768)])
 def test_gemm_layouts(L, layout, shape):
     """C = A B^T in the three storage layouts, incl. ragged M/N and the non-MFMA fallback (K % 64 != 0)."""
     M, N, K = shape
@@ -78,7 +80,13 @@ def test_gemm_layouts(L, layout, shape):
 def test_gemm_split_k_slabs_feed_weightnorm_bwd(L):
     """dW = dy^T x with K cut into slabs; mapdit_weightnorm_bwd adds the slabs in order (deterministic split-K)."""
     from oracle.dit_oracle import normalize
-    rows, cols, K, S = 256, 128, 1024, 8
+    _split_k_case(L, 256, 128, 1024, 8)       # 128^2 kernel
+    _split_k_case(L, 768, 256, 2048, 4)       # 256^2 staggered kernel
+    _split_k_case(L, 512, 512, 1344, 7)       # 3 K-tiles per slab (odd tile count)
+
+
+def _split_k_case(L, rows, cols, K, S):
+    from oracle.dit_oracle import normalize
     dy, x = bf16_exact(K, rows, seed=21), bf16_exact(K, cols, seed=22)
     G_ref = (dy.double().t() @ x.double()).float()
     slabs = torch.full((S, rows, cols), float("nan"), device=DEV)
@@ -95,7 +103,7 @@ def test_gemm_split_k_slabs_feed_weightnorm_bwd(L):
     torch.cuda.synchronize()
     assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
     with pytest.raises(L.MapditError):                      # K not divisible into 64-wide slabs
-        run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=3,
+        run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=5,
                  slab_stride=rows * cols)
 
 
