@@ -252,13 +252,12 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
     const int edge = mapdit_gemm_tile_size(rows, cols);
     const int tiles = cdiv(rows, edge) * cdiv(cols, edge);
     const int units = K / 64;
-    long want = (edge == 256 ? 512 : 1024) / tiles;      // ~2 (256^2, 1 per CU) or ~4 (128^2, 2 per CU) rounds of the chip
+    // One full round of the chip (256 CUs x 1 workgroup of the 256^2 kernel, x 2 of the 128^2 kernel): every block
+    // gets the longest possible K loop and there is no partially filled tail round.  Slab ranges may be uneven.
+    long want = (edge == 256 ? 256 : 512) / tiles;
     if (want > max_slabs) want = max_slabs;
     if (want > units / 4) want = units / 4;                             // keep >= 4 K-tiles per block
-    int best = 1;
-    for (int s = 1; s <= want; ++s)
-        if (units % s == 0) best = s;
-    return best;
+    return want < 1 ? 1 : (int)want;
 }
 
 // dW for one linear: G = dy^T x (TN GEMM into scratch), then the weight-norm Jacobian into the bound grad.

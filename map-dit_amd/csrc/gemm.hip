@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int z = wg / p.tiles, tile = wg - z * p.tiles;      // z-major: neighbouring blocks share operand panels
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-    const int kbeg = z * (p.K / p.split_k);
+    // slab z owns K-tiles [z*base + min(z, rem), +base (+1 if z < rem)): any split_k <= K/64 works
+    const int nkt = p.K / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / p.split_k / BKT;
+    const int nk = kbase + (z < krem ? 1 : 0);
     stage_tile<AK>(p.A, p.lda, m0, p.M, kbeg, smem, wave, lane);
     stage_tile<BK>(p.B, p.ldb, n0, p.N, kbeg, smem + TILE_BYTES, wave, lane);
     for (int t = 0; t < nk; ++t) {
@@ -258,10 +260,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
 //  * Each phase is a LOAD interval {ds_read fragments; issue ONE half-tile of LDS-DMA; counted waits; barrier} and an
 //    MFMA interval {16 MFMAs; barrier}.  Waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave's
 //    MFMA interval overlaps its partner's LOAD interval.
-//  * DMA order per wave: ... B0[t+1] (phase 1 of tile t), A0[t+2] (2), B1[t+2] (3), A1[t+2] (4), B0[t+2] (phase 1 of
-//    t+1) ...: always into the slot whose last ds_read was the phase before.  The only DMA wait is in phase 4:
-//    vmcnt(6) leaves the three youngest half-tiles in flight and retires all of tile t+1, which is read from the next
-//    phase on.  RAW: a wait in LOAD(j) + that interval's barrier, in both wave groups, precedes any read in LOAD(j+1).
+//  * The B0 fragments stay in registers from phase 1 to phase 4, so slot B0 is free after phase 1 and every slot can
+//    be re-staged one phase after its last read.  DMA order per wave: ... A1[t+1] (phase 1 of tile t), A0[t+2] (2),
+//    B0[t+2] (3), B1[t+2] (4), A1[t+2] (phase 1 of t+1) ...  Waits sit in phases 1, 2 and 4 and are all vmcnt(10):
+//    the five youngest half-tiles (80 KiB per workgroup) stay in flight, what the next phase reads is retired.
+//    RAW: a wait in LOAD(j) + that interval's barrier, in both wave groups, precedes any read in LOAD(j+1).
 //    WAR: a slot's ds_reads are drained by lgkmcnt(0) inside LOAD(k) before its barrier; the slot is re-staged in
 //    LOAD(k+1) at the earliest.  Both hold for either wave group because the groups are exactly one barrier apart.
 constexpr int BM2 = 256, BN2 = 256;
@@ -320,15 +323,16 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int z = wg / p.tiles, tile = wg - z * p.tiles;
     const int m0 = (tile / p.tiles_n) * BM2, n0 = (tile % p.tiles_n) * BN2;
-    const int kbeg = z * (p.K / p.split_k);
-    const int nk = p.K / p.split_k / BKT;
+    const int nkt = p.K / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
+    const int nk = kbase + (z < krem ? 1 : 0);
 
     f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[4][2], fb[2][2];
+    bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];               // B half 0 stays in registers for phases 1 and 4
 
     auto load_a = [&](const char* slot) {
 #pragma unroll
@@ -336,22 +340,22 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK>(slot, wm * 64 + i * 16, ks, lane);
     };
-    auto load_b = [&](const char* slot) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = read_frag<BK>(slot, wn * 32 + j * 16, ks, lane);
-    };
-#define G256_MFMA(MQ, NQ)                                                                                      \
+#define G256_LOAD_B(FB, SLOT)                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) FB[j][ks] = read_frag<BK>(SLOT, wn * 32 + j * 16, ks, lane)
+#define G256_MFMA(MQ, NQ, FB)                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
         acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][ks], fa[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0)
+#define G256_WAIT_DMA(has2)                                                  \
+    if (has2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-    // prologue: all of tile 0, and tile 1's A0, B1, A1 (its B0 is phase 1's DMA)
+    // prologue, in steady-state issue order: A0 B0 B1 A1 of tile 0, then A0 B0 B1 of tile 1 (its A1 is phase 1's DMA)
     stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg, 0, smem + OFF_A0, wave, lane);
     stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 0, smem + OFF_B0, wave, lane);
     stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 1, smem + OFF_B1, wave, lane);
@@ -359,9 +363,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     if (nk > 1) {
         char* b1 = smem + KBUF_BYTES;
         stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 0, b1 + OFF_A0, wave, lane);
+        stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 0, b1 + OFF_B0, wave, lane);
         stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 1, b1 + OFF_B1, wave, lane);
-        stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 1, b1 + OFF_A1, wave, lane);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0, B0 of tile 0 have landed; five half-tiles in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -373,40 +377,40 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // DMA issue order per wave: ... A1[t+1] (phase 1 of tile t), A0[t+2] (2), B0[t+2] (3), B1[t+2] (4), A1[t+2] ...
+    // Every wait leaves the five youngest half-tiles in flight (vmcnt(10)) and retires what the NEXT phase reads:
+    //   phase 1 -> B1[t] (read in 2)   phase 2 -> A1[t] (read in 3)   phase 4 -> A0[t+1], B0[t+1] (read in 1 of t+1)
     for (int t = 0; t < nk; ++t) {
         char* cur = smem + (t & 1) * KBUF_BYTES;
         char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
         const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
         const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-        // phase 1: quadrant (0,0); DMA B0 of tile t+1
+        // phase 1: quadrant (0,0); slot A1 of the other buffer was last read in phase 3 of tile t-1
         load_a(cur + OFF_A0);
-        load_b(cur + OFF_B0);
-        if (has1) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k1, 0, nxt + OFF_B0, wave, lane);
+        G256_LOAD_B(fb0, cur + OFF_B0);
+        if (has1) stage_half<AK, 0>(p.A, p.lda, m0, p.M, k1, 1, nxt + OFF_A1, wave, lane);
+        G256_WAIT_DMA(has2);
         G256_END_LOAD();
-        G256_MFMA(0, 0);
+        G256_MFMA(0, 0, fb0);
         G256_END_MFMA();
-        // phase 2: quadrant (0,1); DMA A0 of tile t+2 into the slot phase 1 just finished with
-        load_b(cur + OFF_B1);
+        // phase 2: quadrant (0,1); slot A0 was last read in phase 1
+        G256_LOAD_B(fb1, cur + OFF_B1);
         if (has2) stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 0, cur + OFF_A0, wave, lane);
+        G256_WAIT_DMA(has2);
         G256_END_LOAD();
-        G256_MFMA(0, 1);
+        G256_MFMA(0, 1, fb1);
         G256_END_MFMA();
-        // phase 3: quadrant (1,1); DMA B1 of tile t+2
+        // phase 3: quadrant (1,1); slot B0 was last read in phase 1 (its fragments live on in fb0)
         load_a(cur + OFF_A1);
-        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 0, cur + OFF_B0, wave, lane);
         G256_END_LOAD();
-        G256_MFMA(1, 1);
+        G256_MFMA(1, 1, fb1);
         G256_END_MFMA();
-        // phase 4: quadrant (1,0); DMA A1 of tile t+2; retire tile t+1 (three half-tiles stay in flight)
-        load_b(cur + OFF_B0);
-        if (has2) {
-            stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 1, cur + OFF_A1, wave, lane);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // phase 4: quadrant (1,0) from registers only; slot B1 was last read in phase 2
+        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+        G256_WAIT_DMA(has2);
         G256_END_LOAD();
-        G256_MFMA(1, 0);
+        G256_MFMA(1, 0, fb0);
         G256_END_MFMA();
     }
     if (wm == 0) {                                         // rebalance the barrier count of the two groups
@@ -484,8 +488,8 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (!a_kmaj && lda % 8 != 0) mfma = false;
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
-    if (split_k > 1 && (!mfma || K % (split_k * BKT) != 0)) {
-        mapdit_set_error("gemm: split_k=%d needs the MFMA path and K %% (split_k*64) == 0 (K=%d)", split_k, K);
+    if (split_k > 1 && (!mfma || split_k > K / BKT)) {
+        mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= K/64 (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
     if (mfma && mapdit_gemm_tile_size(M, N) == 256) {

@@ -83,6 +83,7 @@ def test_gemm_split_k_slabs_feed_weightnorm_bwd(L):
     _split_k_case(L, 256, 128, 1024, 8)       # 128^2 kernel
     _split_k_case(L, 768, 256, 2048, 4)       # 256^2 staggered kernel
     _split_k_case(L, 512, 512, 1344, 7)       # 3 K-tiles per slab (odd tile count)
+    _split_k_case(L, 512, 256, 1216, 5)       # 19 K-tiles over 5 slabs: uneven ranges 4,4,4,4,3
 
 
 def _split_k_case(L, rows, cols, K, S):
@@ -93,7 +94,8 @@ def _split_k_case(L, rows, cols, K, S):
     run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=S,
              slab_stride=rows * cols)
     assert rel_err(slabs.sum(0).cpu().numpy(), G_ref.numpy()) < 2e-6
-    assert float((slabs[0].cpu() - (dy[:K // S].double().t() @ x[:K // S].double()).float()).abs().max()) < 1e-3
+    k0 = 64 * ((K // 64) // S + (1 if (K // 64) % S else 0))          # slab 0 owns the first ceil(tiles/S) K-tiles
+    assert float((slabs[0].cpu() - (dy[:k0].double().t() @ x[:k0].double()).float()).abs().max()) < 1e-3
     W = torch.randn(rows, cols, generator=torch.Generator().manual_seed(23))
     Wr = W.clone().requires_grad_(True)
     (normalize(Wr) / math.sqrt(cols)).backward(G_ref)
@@ -102,9 +104,9 @@ def _split_k_case(L, rows, cols, K, S):
     L.lib().weightnorm_bwd(p(Wd), p(slabs), cols, S, rows * cols, p(dW), rows, cols, 1.0, 0, st())
     torch.cuda.synchronize()
     assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
-    with pytest.raises(L.MapditError):                      # K not divisible into 64-wide slabs
-        run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0, split_k=5,
-                 slab_stride=rows * cols)
+    with pytest.raises(L.MapditError):                      # more slabs than 64-wide K-tiles
+        run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0,
+                 split_k=K // 64 + 1, slab_stride=rows * cols)
 
 
 def test_gemm_identity_asymmetric(L):
