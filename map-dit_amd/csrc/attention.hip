@@ -67,7 +67,10 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int d0, int kbase,
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 template <int T> struct Geo {
-    static constexpr int NW = T >= 128 ? 4 : T / 32;   // waves per workgroup, 32 owner rows each
+    // One workgroup per head: T/32 waves (8 at T = 256), 32 owner rows each, all sharing one LDS copy of the head's
+    // operands.  The backward images fill most of the LDS (one workgroup per CU), so the wave count per workgroup IS
+    // the occupancy: 8 waves = 2 per SIMD.
+    static constexpr int NW = T / 32;
     static constexpr int NTH = NW * 64;
     static constexpr int NT = T / 32;
     static constexpr int VLD = 2 * T + 8;
