@@ -204,7 +204,7 @@ def optimizer_fixture():
     """Three Adam + EMA steps of the reference harness pieces (train.py:57,94-105; src/ema.py)
     on a tiny model; pins SURVEY §8(f) N1."""
     import copy
-    cfg = O.DiTConfig(depth=1, hidden_size=128, patch_size=4, input_size=16, in_channels=4, num_heads=2, num_classes=10)
+    cfg = O.DiTConfig(depth=1, hidden_size=128, patch_size=4, input_size=32, in_channels=4, num_heads=2, num_classes=10)
     sd = O.init_state_dict(cfg, seed=5, gains=0.2, perturb_reference=0.3)
     ref = build_ref(cfg, sd).train()
     diff = ref_create("")
@@ -240,6 +240,9 @@ def optimizer_fixture():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "optim3":
+        optimizer_fixture()
+        sys.exit(0)
     tiny = dict(in_channels=4, num_heads=2, num_classes=10)
     fixture("tiny_a", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=16, **tiny), n=4, wseed=1, dseed=2)
     fixture("tiny_b", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=16, **tiny), n=4, wseed=3, dseed=4,

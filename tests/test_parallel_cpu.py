@@ -1,0 +1,95 @@
+"""Data-parallel plumbing on CPU (gloo, world_size 2): the flat-gradient reducer, the bucket slicing, the batch
+sharding, and the invariant the multi-GPU path relies on — mean-of-rank-gradients == gradient of the global batch
+(SURVEY.md §8e), checked with the CPU oracle as the per-rank compute."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import mapdit_amd  # noqa: F401
+    from mapdit_amd.parallel import GradReducer, init_from_env, shard_batch
+    from oracle import dit_oracle as O
+    from oracle.diffusion_oracle import DiffusionOracle
+    r, w, _ = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # 1. reducer on a flat buffer, several buckets, ragged tail
+    flat = torch.arange(10_007, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(n_buckets=3)
+    red.reduce(flat)
+    assert torch.equal(flat, torch.arange(10_007, dtype=torch.float32) * 3)
+    assert red.grad_scale == 0.5
+    # 2. DP invariant with the oracle as the model: each rank differentiates the mean loss of ITS half of the batch
+    cfg = O.DiTConfig(depth=1, hidden_size=64, patch_size=4, input_size=16, in_channels=4, num_heads=1, num_classes=10)
+    sd = O.init_state_dict(cfg, seed=3, gains=0.2, perturb_reference=0.2)
+    g = torch.Generator().manual_seed(4)
+    n = 4
+    x, y = torch.randn(n, 4, 16, 16, generator=g), torch.randint(0, 10, (n,), generator=g)
+    t, noise = torch.randint(0, 1000, (n,), generator=g), torch.randn(n, 4, 16, 16, generator=g)
+    drop = torch.tensor([False, True, False, False])
+    d = DiffusionOracle("")
+
+    def grads(lo, hi):
+        leaf = {k: v.clone().requires_grad_(k not in O.BUFFER_KEYS) for k, v in sd.items()}
+        loss = d.training_losses(lambda xx, tt, **kw: O.dit_forward(leaf, cfg, xx, tt, kw["y"], train=True, drop=drop[lo:hi]),
+                                 x[lo:hi], t[lo:hi], dict(y=y[lo:hi]), noise=noise[lo:hi])["loss"].mean()
+        loss.backward()
+        return torch.cat([leaf[k].grad.reshape(-1) for k in leaf if k not in O.BUFFER_KEYS])
+
+    lo, hi = shard_batch(n, rank, world)
+    local = grads(lo, hi)
+    red.reduce(local)
+    local *= red.grad_scale
+    if rank == 0:
+        full = grads(0, n)
+        ret["dp_err"] = float((local - full).norm() / full.norm())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_reducer_and_dp_invariant():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["dp_err"] < 1e-5
+
+
+def test_bucket_slices_and_shards():
+    import mapdit_amd  # noqa: F401
+    from mapdit_amd.parallel import bucket_slices, shard_batch
+    for numel, nb in ((10, 3), (1 << 20, 4), (130_190_000, 8), (5, 1)):
+        sl = bucket_slices(numel, nb)
+        assert sl[0][0] == 0 and sl[-1][1] == numel
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        assert all(lo % 1024 == 0 for lo, _ in sl)
+    assert shard_batch(256, 3, 8) == (96, 128)
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)
+
+
+def test_lr_schedule_and_ema_betas_match_reference_fixtures():
+    import numpy as np
+    import mapdit_amd  # noqa: F401
+    from conftest import load_golden
+    from mapdit_amd.optim import calc_beta, create_lr_lambda, std_to_gamma
+    g = load_golden("tables")
+    np.testing.assert_allclose([std_to_gamma(0.05), std_to_gamma(0.1)], g["ema_gamma"], rtol=1e-12)
+    np.testing.assert_allclose([calc_beta(0.05, 100), calc_beta(0.1, 100)], g["ema_beta_t100"], rtol=1e-12)
+    lam = create_lr_lambda(400_000 // 150, 400_000 // 10)          # train.py:60-66 defaults
+    assert lam(0) == 1 / 2666 and lam(2664) == 2665 / 2666 and lam(2665) == 1.0 and lam(39_999) == 1.0
+    assert abs(lam(160_000) - 0.5) < 1e-12
