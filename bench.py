@@ -80,7 +80,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="DiT-B/2")
     ap.add_argument("--batch-per-gpu", type=int, default=256)
-    ap.add_argument("--buckets", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -91,7 +90,7 @@ def main():
     from mapdit_amd import _lib as L
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.optim import FusedAdamEMA, create_lr_lambda
-    from mapdit_amd.parallel import GradReducer, init_from_env
+    from mapdit_amd.parallel import OverlappedGradReducer, init_from_env
     from mapdit_amd.src.models import DIT_MODELS
 
     rank, world, local = init_from_env()
@@ -104,7 +103,7 @@ def main():
     model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000).to(dev).train()
     diffusion = create_diffusion(timestep_respacing="")
     num_steps = 400_000                                    # train.py defaults -> warm-up / decay points
-    reducer = GradReducer(n_buckets=args.buckets)
+    reducer = OverlappedGradReducer(model)                 # all-reduce of block i overlaps backward of blocks i-1..0
     opt = FusedAdamEMA(model, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
                        lr_lambda=create_lr_lambda(num_steps // 150, num_steps // 10), grad_scale=reducer.grad_scale)
     B = args.batch_per_gpu
@@ -117,7 +116,7 @@ def main():
         loss = diffusion.training_losses(model, x, t, dict(y=y))["loss"].mean()
         opt.zero_grad()
         loss.backward()
-        reducer.reduce(model._gflat)
+        reducer.finish()
         opt.step()
         return loss
 

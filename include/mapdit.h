@@ -211,6 +211,10 @@ int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const int64_t* t, 
                           float* out, void* stream);
 /* Backward of the last saved forward: writes d loss / d parameter into every bound grad pointer (overwrite). */
 int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* stream);
+/* The same in pieces, for overlapping the data-parallel gradient reduction with backward: stage 0 = final layer,
+ * stage k in 1..depth = block depth-k, stage depth+1 = patch embedding + conditioning path.  Stages must be run in
+ * order; when a call returns, the gradients owned by its stages are final (enqueued on `stream`). */
+int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* dout, int stage_from, int stage_to, void* stream);
 
 /* Measurement hook: bracket every launch of one kernel family with HIP events on the launch stream.
  * MAPDIT_PROF_FC1_FWD = the block-MLP fc1 GEMM (gemm NT + SILU2 epilogue, [N*T, 4D] = [N*T, D] x [4D, D]^T). */

@@ -79,6 +79,7 @@ _SIGS = {
     "mapdit_engine_prepare_weights": [vp, ci, vp],
     "mapdit_engine_forward": [vp, vp, vp, vp, ci, ci, vp, vp],
     "mapdit_engine_backward": [vp, vp, vp],
+    "mapdit_engine_backward_stages": [vp, vp, ci, ci, vp],
     "mapdit_engine_profile_begin": [vp, ci, ci],
     "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
 }

@@ -48,6 +48,7 @@ struct mapdit_engine {
     int train;
     int T, P, P1, ldp, ldl, D, Hm, heads, M_max;
     int last_N = 0;
+    int next_stage = 0;                   // backward stage expected next (stages run in order)
     bool have_saved = false;
     std::vector<float*> params, grads;
     // weight images
@@ -450,13 +451,24 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     TRY(mapdit_final_out_fwd(e->lin, 2 * e->P, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], out, N,
                              c.in_channels, c.input_size, c.patch, st));
     e->last_N = N;
+    e->next_stage = 0;
     e->have_saved = save != 0;
     return MAPDIT_OK;
 }
 
 extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* st) {
+    MD_CHECK(e, "engine_backward: null argument");
+    return mapdit_engine_backward_stages(e, dout, 0, e->cfg.depth + 1, st);
+}
+
+// Stage 0 = final layer, stage k (1..L) = block L-k, stage L+1 = patch embedding + conditioning path.  After stage
+// k returns, the gradients of the parameters that stage owns are final (enqueued) — the data-parallel reducer hooks in.
+extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* dout, int stage_from, int stage_to, void* st) {
     MD_CHECK(e && dout, "engine_backward: null argument");
     MD_CHECK(e->train && e->have_saved, "engine_backward: no saved forward");
+    MD_CHECK(stage_from >= 0 && stage_to <= e->cfg.depth + 1 && stage_from <= stage_to, "engine_backward: bad stage range %d..%d",
+             stage_from, stage_to);
+    MD_CHECK(stage_from == e->next_stage, "engine_backward: stages must run in order (expected %d, got %d)", e->next_stage, stage_from);
     const mapdit_config_t& c = e->cfg;
     const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, N = e->last_N;
     const int M = N * T, P2 = 2 * e->P;
@@ -465,6 +477,7 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
     auto G = [&](int idx) { return e->grads[idx]; };
     const int npart = N * (D / 128);
 
+    if (stage_from == 0) {
     hipError_t he = hipMemsetAsync(e->dcs, 0, (size_t)N * D * 4, hs);
     if (he == hipSuccess) he = hipMemsetAsync(e->dcd, 0, (size_t)N * D * 4, hs);
     if (he == hipSuccess) he = hipMemsetAsync(e->dtable, 0, (size_t)c.table_rows * D * 4, hs);
@@ -498,9 +511,12 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
     TRY(mapdit_f32_to_bf16(e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
     TRY(gemm(MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
     TRY(linear_dw(e, MAPDIT_P_F_MOD, e->dmod_bf, 2 * D, e->c_silu, D, N, 1.f, st));
+    }   // stage 0
 
     // ---- blocks, last to first.  Invariant: DXa = d/d X[2i+2]; dy = grad of the MLP branch output y2_i. -----------
     for (int i = L - 1; i >= 0; --i) {
+        const int stage = L - i;
+        if (stage < stage_from || stage > stage_to) continue;
         const BlockBufs& b = e->blk[i];
         float* dmod = e->dmod + (size_t)i * N * 6 * D;
         // MLP branch
@@ -549,6 +565,8 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf, 6 * D, e->c_silu, D, N, 1.f, st));
     }
 
+    e->next_stage = stage_to + 1;
+    if (stage_to < L + 1) return MAPDIT_OK;
     // ---- patch embedding: x0 = (x_embedder(patches) + pos) * C5 -----------------------------------------------------
     {
         const float c5 = 0.70710678118654752f;
@@ -566,5 +584,6 @@ extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, voi
     TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));
     TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));
     e->have_saved = false;
+    e->next_stage = 0;
     return MAPDIT_OK;
 }

@@ -4,12 +4,16 @@ The reference is single-process; its semantics under DP are those of
 the mean over the global batch (train.py:91), so parameter gradients are averaged over ranks.  Samples are
 independent through forward/backward — the only exchange is the gradient sum.  Parameters, Adam state and EMA
 copies are replicated; forced weight normalisation is a deterministic function of the weights, so replicas stay
-bit-identical as long as every rank applies the same reduced gradient (RCCL all-reduce returns identical bits
-on every rank).
+bit-identical as long as every rank applies the same reduced gradient (an all-reduce returns identical bits on
+every rank).
 
-Gradients live in ONE flat fp32 buffer (``model._gflat``), so the reduction is a handful of large collectives
-instead of one per tensor.  The buffer is reduced in ``n_buckets`` contiguous slices launched back to back on a
-side stream so the tail of one bucket's ring overlaps the head of the next; the optimiser waits on the stream.
+Gradients live in ONE flat fp32 buffer (``model._gflat``), laid out in module registration order, so each DiT
+block owns one contiguous slice.  ``OverlappedGradReducer`` hooks the engine's staged backward
+(``mapdit_engine_backward_stages``): as soon as a stage's kernels are enqueued, the slice it finalised is handed to an
+asynchronous all-reduce (RCCL runs it on its own stream behind the compute already queued), so the reduction of block
+i overlaps the backward of blocks i-1 ... 0 — the usual DDP bucketing, with the engine's stages as buckets.
+``GradReducer`` is the plain variant (reduce everything after backward).  The mean is applied by the optimiser's
+gradient scale 1/world.
 """
 from __future__ import annotations
 
@@ -48,15 +52,18 @@ def bucket_slices(numel: int, n_buckets: int, align: int = 1024):
     return out
 
 
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
 class GradReducer:
-    """Sum-all-reduce of a flat gradient buffer across the data-parallel group (mean is applied by the optimiser's
-    gradient scale = 1/world).  Works with any torch.distributed backend: RCCL on GPUs, gloo on CPU for tests."""
+    """Sum-all-reduce of a flat gradient buffer after backward, in a few large buckets.  Works with any
+    torch.distributed backend: RCCL on GPUs, gloo on CPU for tests."""
 
     def __init__(self, group=None, n_buckets: int = 4):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = _world(group)
         self.n_buckets = n_buckets
-        self._stream = None
 
     @property
     def grad_scale(self) -> float:
@@ -65,17 +72,65 @@ class GradReducer:
     def reduce(self, flat: torch.Tensor):
         if self.world == 1:
             return
-        if flat.is_cuda:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self._stream):
-                for lo, hi in bucket_slices(flat.numel(), self.n_buckets):
-                    dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for lo, hi in bucket_slices(flat.numel(), self.n_buckets)]
+        for w in works:
+            w.wait()
+
+
+def stage_slices(model):
+    """[lo, hi) of the flat parameter/gradient buffer owned by each backward stage of the engine:
+    stage 0 = final_layer, stage k = blocks[depth-k], stage depth+1 = the embedders (x, t, y)."""
+    L = model.depth
+    ranges = {}
+    params = list(model.named_parameters())
+    for (name, p), off in zip(params, model._poffs):
+        if name.startswith("final_layer."):
+            st = 0
+        elif name.startswith("blocks."):
+            st = L - int(name.split(".")[1])
         else:
-            for lo, hi in bucket_slices(flat.numel(), self.n_buckets):
-                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            st = L + 1
+        size = (p.numel() + 31) // 32 * 32
+        lo, hi = ranges.get(st, (off, off))
+        assert off == hi or st not in ranges, f"parameters of stage {st} are not contiguous in the flat buffer"
+        ranges[st] = (min(lo, off), off + size)
+    total = model._pflat.numel()
+    out = [ranges[s] for s in range(L + 2)]
+    assert sorted(out)[0][0] == 0 and sorted(out)[-1][1] == total
+    assert sum(hi - lo for lo, hi in out) == total
+    return out
+
+
+class OverlappedGradReducer:
+    """All-reduce each backward stage's gradient slice as soon as that stage is enqueued (see module docstring).
+    Usage: r = OverlappedGradReducer(model); ...; loss.backward(); r.finish(); opt.step()."""
+
+    def __init__(self, model, group=None):
+        self.model, self.group = model, group
+        self.world = _world(group)
+        self.slices = stage_slices(model)
+        self.works = []
+        model._stage_hook = self._on_stage if self.world > 1 or os.environ.get("MAPDIT_FORCE_STAGED_BACKWARD") else None
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def _on_stage(self, stage: int):
+        if self.world == 1:
+            return
+        lo, hi = self.slices[stage]
+        self.works.append(dist.all_reduce(self.model._gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Make the current stream wait for every outstanding reduction (call before the optimiser step)."""
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+
+    def reduce(self, flat=None):          # same call site as GradReducer
+        self.finish()
 
 
 def shard_batch(global_batch: int, rank: int, world: int):

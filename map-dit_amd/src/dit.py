@@ -237,7 +237,15 @@ class _DiTFunction(torch.autograd.Function):
         accumulate = model._attach_grads()
         keep = model._gflat.clone() if accumulate else None
         rt.bind(model)
-        rt.lib.engine_backward(rt.handle, dout.data_ptr(), L.cur_stream())
+        hook = getattr(model, "_stage_hook", None)
+        if hook is None:
+            rt.lib.engine_backward(rt.handle, dout.data_ptr(), L.cur_stream())
+        else:
+            # staged backward: after each stage the data-parallel reducer all-reduces the slice that stage finalised
+            assert keep is None, "gradient accumulation is not supported together with the overlapped DP reducer"
+            for stage in range(model.depth + 2):
+                rt.lib.engine_backward_stages(rt.handle, dout.data_ptr(), stage, stage, L.cur_stream())
+                hook(stage)
         if keep is not None:
             model._gflat.add_(keep)
         return None, None, None, None, None, None

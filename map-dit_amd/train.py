@@ -139,7 +139,7 @@ def main(argv=None):
         args.num_lin_warmup = args.num_steps // 150
     if args.start_decay is None:
         args.start_decay = args.num_steps // 10
-    reducer = parallel.GradReducer()
+    reducer = parallel.OverlappedGradReducer(model)
     opt = FusedAdamEMA(model, lr=args.lr, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
                        lr_lambda=create_lr_lambda(args.num_lin_warmup, args.start_decay), grad_scale=reducer.grad_scale)
 
@@ -164,7 +164,7 @@ def main(argv=None):
         loss = diffusion.training_losses(model, x, t, dict(y=y))["loss"].mean()
         opt.zero_grad()
         loss.backward()
-        reducer.reduce(model._gflat)
+        reducer.finish()
         opt.step()
         running += loss.detach()
         log_steps += 1
