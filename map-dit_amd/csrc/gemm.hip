@@ -40,6 +40,7 @@ struct GemmP {
     int tiles_n;
     int tiles;      // output tiles (grid = tiles * split_k)
     int split_k;    // K is cut into split_k equal ranges; slab z of the output holds the partial sum of range z
+    int band;       // 256^2 kernel: column tiles per band of the band-major tile order (L2 residency of the B panel)
 };
 
 // Swizzle key of K-major row k.  One ds_read_b64_tr_b16 half-wave touches rows {8g+q, q = 0..3, g = 0..1} (then the
@@ -322,7 +323,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int z = wg / p.tiles, tile = wg - z * p.tiles;
-    const int m0 = (tile / p.tiles_n) * BM2, n0 = (tile % p.tiles_n) * BN2;
+    // Band-major tile order: all row tiles of the first `band` column tiles, then the next band, ...  Consecutive
+    // workgroups (= one XCD, one private 4 MiB L2) then share a B (weight) sub-panel small enough to stay L2-resident
+    // while the A panels stream through; a full-width order re-streams the whole weight matrix from the Infinity
+    // Cache for every round of workgroups once it exceeds the L2 (measured: 30 % L2 read misses on fc1).
+    const int tiles_m = p.tiles / p.tiles_n;
+    const int bsz = tiles_m * p.band;
+    const int bidx = tile / bsz, rem = tile - bidx * bsz;
+    const int bw = (bidx + 1) * p.band <= p.tiles_n ? p.band : p.tiles_n - bidx * p.band;   // last band may be narrower
+    const int m0 = (rem / bw) * BM2, n0 = (bidx * p.band + rem % bw) * BN2;
     const int nkt = p.K / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
     const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
     const int nk = kbase + (z < krem ? 1 : 0);
@@ -493,14 +502,19 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         return MAPDIT_ERR_ARG;
     }
     if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
+        // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
+        const char* be = getenv("MAPDIT_GEMM_BAND");
+        long band = be ? atol(be) : (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);
+        if (band < 1 || band > p.tiles_n) band = p.tiles_n;
+        p.band = (int)band;
         const int grid = p.tiles * split_k;
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
     } else if (mfma) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
