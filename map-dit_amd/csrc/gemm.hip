@@ -507,6 +507,9 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
         const char* be = getenv("MAPDIT_GEMM_BAND");
         long band = be ? atol(be) : (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);
+        // every band re-reads the A panels once more, so banding only pays with wide bands: fewer than 4 column tiles
+        // per band (large K) -> one full-width band (measured: band = 1 at K = 3072 costs 25 %)
+        if (!be && band < 4) band = p.tiles_n;
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
         const int grid = p.tiles * split_k;
