@@ -140,6 +140,19 @@ int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* 
                         const float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                         int head_dim, void* stream);
 
+/* Generic-shape variants (any head_dim <= 96, any T <= 256; fp32 VALU): DiT-XL (head_dim 72), patch-8 models (T = 16).
+ * Head-major buffers are [B*H][T][head_dim] without padding; no transposed images are needed. */
+int mapdit_qkv_split_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
+                             void* stream);
+int mapdit_qkv_merge_bwd_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+                                 const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
+int mapdit_attn_generic_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T,
+                            int H, int head_dim, void* stream);
+/* also writes delta [B*H][T] = rowsum(dO*O) */
+int mapdit_attn_generic_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                            const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+                            int head_dim, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Embedding / conditioning / output side (src/dit.py:81-101, timestep_embedder.py, label_embedder.py, final_layer.py).
  * ------------------------------------------------------------------------------------------------------------ */

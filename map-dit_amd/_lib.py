@@ -63,6 +63,10 @@ _SIGS = {
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_do_prep": [vp, vp, ci, ci, ci, ci, vp, vp, vp],
     "mapdit_attn_cos_bwd": [vp] * 12 + [ci, ci, ci, ci, vp],
+    "mapdit_qkv_split_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
+    "mapdit_qkv_merge_bwd_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
+    "mapdit_attn_generic_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_attn_generic_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
     "mapdit_patch_embed_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "mapdit_fourier_fwd": [vp, vp, vp, vp, ci, ci, vp],
     "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],

@@ -9,18 +9,19 @@ namespace {
 // ---- patchify + ones column + x_embedder + mp_sum with pos_embed (reference src/dit.py:81-84) --------------------
 // x [N,C,S,S] fp32, w [D][P+1] fp32 effective weight, pos [T][D]; out x0 [M,D] fp32; patches [M][ldp] bf16
 // (zero padded to ldp, ones column at index P) kept for the dW GEMM.  Block = 64 tokens x 128 features.
+template <int DT>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ pos, float* __restrict__ out,
                                                             bf16_t* __restrict__ patches, int ldp, int C, int S, int p,
                                                             int D, long M) {
     extern __shared__ float sm[];
     const int P = p * p * C, P1 = P + 1, grid = S / p, T = grid * grid;
-    float* ws = sm;                    // [P1][128]
-    float* ps = sm + P1 * 128;         // [64][P1]
+    float* ws = sm;                    // [P1][DT]
+    float* ps = sm + P1 * DT;          // [64][P1]
     const long m0 = (long)blockIdx.x * 64;
-    const int d0 = blockIdx.y * 128;
-    for (int i = threadIdx.x; i < P1 * 128; i += 256) {
-        const int j = i / 128, d = i % 128;
+    const int d0 = blockIdx.y * DT;
+    for (int i = threadIdx.x; i < P1 * DT; i += 256) {
+        const int j = i / DT, d = i % DT;
         ws[i] = w[(size_t)(d0 + d) * P1 + j];
     }
     for (int i = threadIdx.x; i < 64 * P1; i += 256) {
@@ -44,12 +45,12 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
             if (m0 + tok < M) patches[(m0 + tok) * ldp + j] = f2bf(j < P1 ? ps[tok * P1 + j] : 0.f);
         }
     }
-    const int d = threadIdx.x & 127;
-    for (int tok = threadIdx.x >> 7; tok < 64; tok += 2) {
+    const int d = threadIdx.x % DT;
+    for (int tok = threadIdx.x / DT; tok < 64; tok += 256 / DT) {
         const long m = m0 + tok;
         if (m >= M) break;
         float a = 0.f;
-        for (int j = 0; j < P1; ++j) a += ps[tok * P1 + j] * ws[j * 128 + d];
+        for (int j = 0; j < P1; ++j) a += ps[tok * P1 + j] * ws[j * DT + d];
         out[m * D + d0 + d] = (a + pos[(size_t)(m % T) * D + d0 + d]) * C5;
     }
 }
@@ -174,9 +175,16 @@ extern "C" int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const 
     MD_CHECK(!patches || ldp >= P1, "patch_embed_fwd: ldp=%d too small", ldp);
     const long M = (long)N * T;
     const size_t shm = (size_t)(P1 * 128 + 64 * P1) * 4;
-    MD_CHECK(shm <= 64 * 1024, "patch_embed_fwd: patch dim %d too large", P1 - 1);
-    hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv(M, 64), D / 128), dim3(256), shm, (hipStream_t)stream, x, w_eff, pos,
-                       out, patches, ldp, C, S, p, D, M);
+    if (shm <= 64 * 1024) {
+        hipLaunchKernelGGL(patch_embed_fwd_kernel<128>, dim3(cdiv(M, 64), D / 128), dim3(256), shm, (hipStream_t)stream, x, w_eff,
+                           pos, out, patches, ldp, C, S, p, D, M);
+    } else {                                   // patch-8 models: 257-wide rows, 64-feature tiles, > 64 KiB of LDS
+        const size_t shm64 = (size_t)(P1 * 64 + 64 * P1) * 4;
+        MD_CHECK(shm64 <= 150 * 1024, "patch_embed_fwd: patch dim %d too large", P1 - 1);
+        (void)hipFuncSetAttribute((const void*)patch_embed_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64);
+        hipLaunchKernelGGL(patch_embed_fwd_kernel<64>, dim3(cdiv(M, 64), D / 64), dim3(256), shm64, (hipStream_t)stream, x, w_eff,
+                           pos, out, patches, ldp, C, S, p, D, M);
+    }
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -46,7 +46,8 @@ struct WeightImg {
 struct mapdit_engine {
     mapdit_config_t cfg;
     int train;
-    int T, P, P1, ldp, ldl, D, Hm, heads, M_max;
+    int T, P, P1, ldp, ldl, D, Hm, heads, hd, M_max;
+    bool generic_attn = false;
     int last_N = 0;
     int next_stage = 0;                   // backward stage expected next (stages run in order)
     bool have_saved = false;
@@ -190,11 +191,11 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c, "engine: null config");
     MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
-    MD_CHECK(c->hidden % c->num_heads == 0 && c->hidden / c->num_heads == 64,
-             "engine: head_dim=%d unsupported (64 only: DiT-XS/S/B/L; XL has 72)", c->hidden / (c->num_heads ? c->num_heads : 1));
+    MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
+             "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
     MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
     const int g = c->input_size / c->patch, T = g * g;
-    MD_CHECK(T == 64 || T == 128 || T == 256, "engine: %d tokens per sample unsupported (64, 128, 256)", T);
+    MD_CHECK(T >= 1 && T <= 256, "engine: %d tokens per sample unsupported (<= 256)", T);
     MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
     MD_CHECK(c->patch * c->patch * c->in_channels <= 256 && (c->patch * c->patch * c->in_channels) % 4 == 0,
              "engine: patch dim %d unsupported", c->patch * c->patch * c->in_channels);
@@ -212,6 +213,10 @@ void init_dims(mapdit_engine* e) {
     e->D = c.hidden;
     e->Hm = c.mlp_hidden;
     e->heads = c.num_heads;
+    e->hd = c.hidden / c.num_heads;
+    // MFMA attention kernels: head_dim 64 and 64/128/256 tokens; everything else (XL: 72, patch-8: 16 tokens) takes the
+    // generic fp32 path of attention_generic.hip
+    e->generic_attn = !(e->hd == 64 && (e->T == 64 || e->T == 128 || e->T == 256));
     e->M_max = c.max_batch * e->T;
 }
 
@@ -428,8 +433,13 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         // attention branch                                              (dit_block.py:35)
         TRY(mapdit_modulate_fwd(xin, b.mod, b.mod + D, 6 * D, gmsa, b.xm, N, T, D, st));
         TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
-        TRY(mapdit_qkv_split(b.qkv, N, T, H, 64, b.qn, b.kn, b.v, save ? b.qt : nullptr, save ? b.kt : nullptr, e->vt, st));
-        TRY(mapdit_attn_cos_fwd(b.qn, b.kn, e->vt, b.o, b.lse, N, T, H, 64, st));
+        if (e->generic_attn) {
+            TRY(mapdit_qkv_split_generic(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
+            TRY(mapdit_attn_generic_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        } else {
+            TRY(mapdit_qkv_split(b.qkv, N, T, H, 64, b.qn, b.kn, b.v, save ? b.qt : nullptr, save ? b.kt : nullptr, e->vt, st));
+            TRY(mapdit_attn_cos_fwd(b.qn, b.kn, e->vt, b.o, b.lse, N, T, H, 64, st));
+        }
         TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, b.mod + 2 * D, 6 * D, T, D), st));
         // MLP branch                                                    (dit_block.py:36)
@@ -537,9 +547,14 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
-        TRY(mapdit_attn_do_prep(e->dO, b.o, N, T, H, 64, e->doT, e->delta, st));
-        TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, b.qt, b.kt, e->dO, e->doT, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, 64, st));
-        TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, 64, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        if (e->generic_attn) {
+            TRY(mapdit_attn_generic_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
+            TRY(mapdit_qkv_merge_bwd_generic(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        } else {
+            TRY(mapdit_attn_do_prep(e->dO, b.o, N, T, H, 64, e->doT, e->delta, st));
+            TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, b.qt, b.kt, e->dO, e->doT, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, 64, st));
+            TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, 64, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        }
         TRY(gemm(MAPDIT_NN, M, D, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {

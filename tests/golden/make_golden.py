@@ -243,6 +243,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "optim3":
         optimizer_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        # shapes that take the generic attention path: head_dim 72 (the XL family) and 16 tokens (patch 8)
+        fixture("xl_d1", O.DiTConfig(depth=1, hidden_size=1152, patch_size=4, input_size=32, in_channels=4, num_heads=16,
+                                     num_classes=10), n=2, wseed=7, dseed=8, gains=0.3, perturb=0.3, full=False, check_tol=5e-5)
+        fixture("tiny_p8", O.DiTConfig(depth=1, hidden_size=128, patch_size=8, input_size=32, in_channels=4, num_heads=2,
+                                       num_classes=10), n=3, wseed=9, dseed=10, gains=0.3, perturb=0.3)
+        sys.exit(0)
     tiny = dict(in_channels=4, num_heads=2, num_classes=10)
     fixture("tiny_a", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=16, **tiny), n=4, wseed=1, dseed=2)
     fixture("tiny_b", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=16, **tiny), n=4, wseed=3, dseed=4,

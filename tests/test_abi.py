@@ -48,7 +48,13 @@ def test_workspace_query_and_config_errors():
     infer = lib.engine_workspace_bytes(ctypes.byref(cfg), 0)
     assert train > infer > 0
     assert train < 16 << 30
-    bad = L.Config(depth=28, hidden=1152, patch=2, input_size=32, in_channels=4, num_heads=16, mlp_hidden=4608,
-                   table_rows=1001, max_batch=2)
-    assert lib.engine_workspace_bytes(ctypes.byref(bad), 0) == 0           # head_dim 72: refused, not mis-computed
-    assert b"head_dim" in lib.last_error()
+    xl = L.Config(depth=28, hidden=1152, patch=2, input_size=32, in_channels=4, num_heads=16, mlp_hidden=4608,
+                  table_rows=1001, max_batch=2)
+    assert lib.engine_workspace_bytes(ctypes.byref(xl), 0) > 0             # head_dim 72: generic attention path
+    bad = L.Config(depth=2, hidden=200, patch=2, input_size=32, in_channels=4, num_heads=2, mlp_hidden=800,
+                   table_rows=11, max_batch=2)
+    assert lib.engine_workspace_bytes(ctypes.byref(bad), 0) == 0           # refused, not mis-computed
+    assert b"hidden" in lib.last_error()
+    big = L.Config(depth=2, hidden=256, patch=2, input_size=64, in_channels=4, num_heads=4, mlp_hidden=1024,
+                   table_rows=11, max_batch=2)
+    assert lib.engine_workspace_bytes(ctypes.byref(big), 0) == 0 and b"tokens" in lib.last_error()   # 1024 tokens

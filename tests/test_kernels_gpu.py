@@ -333,6 +333,39 @@ def test_attention_fwd_bwd(L, B, T, H):
     assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
 
 
+@pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 72), (1, 256, 2, 72), (3, 16, 2, 64), (2, 48, 1, 40)])
+def test_generic_attention_fwd_bwd(L, B, T, H, hd):
+    """The fp32 VALU path for head sizes / token counts the MFMA kernels do not take (DiT-XL head_dim 72, patch-8 T = 16)."""
+    from oracle.dit_oracle import normalize
+    D = H * hd
+    qkv = bf16_exact(B * T, 3 * D, seed=30)
+    dO = bf16_exact(B * T, D, seed=31)
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, hd).transpose(1, 2)
+    qn, kn = normalize(sp(q)), normalize(sp(k))
+    att = torch.softmax(qn @ kn.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ sp(v)
+    o_ref = att.transpose(1, 2).reshape(B * T, D)
+    o_ref.backward(dO)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    qkvd, dOd = to_bf(qkv), to_bf(dO)
+    qn_d, kn_d, v_d = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    lib = L.lib()
+    lib.qkv_split_generic(p(qkvd), B, T, H, hd, p(qn_d), p(kn_d), p(v_d), st())
+    o_d, lse, delta = mk(B * T, D), torch.zeros(B * H, T, device=DEV), torch.zeros(B * H, T, device=DEV)
+    lib.attn_generic_fwd(p(qn_d), p(kn_d), p(v_d), p(o_d), p(lse), B, T, H, hd, st())
+    dqn, dkn, dv, dqkv = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd), mk(B * T, 3 * D)
+    lib.attn_generic_bwd(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(dqn), p(dkn), p(dv), B, T, H, hd, st())
+    lib.qkv_merge_bwd_generic(p(qkvd), B, T, H, hd, p(dqn), p(dkn), p(dv), p(dqkv), st())
+    torch.cuda.synchronize()
+    assert rel_err(qn_d.float().cpu().numpy(), qn.detach().reshape(B * H, T, hd).numpy()) < 3e-3
+    assert rel_err(o_d.float().cpu().numpy(), o_ref.detach().numpy()) < 1e-2
+    got, ref = dqkv.float().cpu().view(B * T, 3, D), leaf.grad.view(B * T, 3, D)
+    assert rel_err(got[:, 2].numpy(), ref[:, 2].numpy()) < 1.5e-2
+    assert rel_err(got[:, 0].numpy(), ref[:, 0].numpy()) < 3e-2
+    assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2
+
+
 def test_attention_exact_small_integers(L):
     """Uniform attention (all logits equal) with integer V: O must be the exact key-mean of V."""
     B, T, H = 1, 64, 1
