@@ -63,11 +63,29 @@ __global__ void qkv_merge_bwd_generic_kernel(const bf16_t* __restrict__ qkv, int
     }
 }
 
-// Stage `rows` rows of `hd` bf16 (row stride ld elements) into LDS as fp32 [rows][hd].
+// Stage `rows` rows of `hd` bf16 (row stride ld elements) into LDS as fp32 [rows][HD], zero padded to the compile-time
+// row length HD (a multiple of 4), so the sweeps below are branch-free and read LDS 16 bytes at a time.
+template <int HD>
 __device__ __forceinline__ void stage_f32(float* dst, const bf16_t* __restrict__ src, long ld, int rows, int hd, int tid, int nth) {
-    for (int i = tid; i < rows * hd; i += nth) {
-        const int r = i / hd, d = i % hd;
-        dst[i] = bf2f(src[(size_t)r * ld + d]);
+    for (int i = tid; i < rows * HD; i += nth) {
+        const int r = i / HD, d = i % HD;
+        dst[i] = d < hd ? bf2f(src[(size_t)r * ld + d]) : 0.f;
+    }
+}
+template <int HD> __device__ __forceinline__ float dot_row(const float (&a)[HD], const float* __restrict__ row) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const float4 k = *(const float4*)(row + d);
+        s += a[d] * k.x + a[d + 1] * k.y + a[d + 2] * k.z + a[d + 3] * k.w;
+    }
+    return s;
+}
+template <int HD> __device__ __forceinline__ void axpy_row(float (&acc)[HD], float w, const float* __restrict__ row) {
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const float4 k = *(const float4*)(row + d);
+        acc[d] += w * k.x; acc[d + 1] += w * k.y; acc[d + 2] += w * k.z; acc[d + 3] += w * k.w;
     }
 }
 
@@ -78,10 +96,10 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __r
                                                              float* __restrict__ lse, int T, int H, int hd, float scale) {
     extern __shared__ float sm[];
     float* ks = sm;
-    float* vs = sm + (size_t)T * hd;
+    float* vs = sm + (size_t)T * HD;
     const size_t bh = blockIdx.x;
-    stage_f32(ks, kn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
-    stage_f32(vs, v + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(ks, kn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(vs, v + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
     __syncthreads();
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * hd;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
@@ -90,13 +108,9 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __r
         for (int d = 0; d < HD; ++d) { q[d] = d < hd ? bf2f(qn[(bh * T + i) * hd + d]) : 0.f; acc[d] = 0.f; }
         float l = 0.f;
         for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) s += q[d] * ks[j * hd + d];
-            const float p = __expf(s * scale);
+            const float p = __expf(dot_row<HD>(q, ks + j * HD) * scale);
             l += p;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) acc[d] += p * vs[j * hd + d];
+            axpy_row<HD>(acc, p, vs + j * HD);
         }
         const float il = 1.f / l;
 #pragma unroll
@@ -114,10 +128,10 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const bf16_t* __re
                                                             int hd, float scale) {
     extern __shared__ float sm[];
     float* ks = sm;
-    float* vs = sm + (size_t)T * hd;
+    float* vs = sm + (size_t)T * HD;
     const size_t bh = blockIdx.x;
-    stage_f32(ks, kn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
-    stage_f32(vs, v + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(ks, kn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(vs, v + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
     __syncthreads();
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * hd;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
@@ -133,12 +147,8 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const bf16_t* __re
         }
         const float ls = lse[bh * T + i];
         for (int j = 0; j < T; ++j) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) { s += q[d] * ks[j * hd + d]; dp += g[d] * vs[j * hd + d]; }
-            const float ds = __expf(s * scale - ls) * (dp - del) * scale;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) acc[d] += ds * ks[j * hd + d];
+            const float s = dot_row<HD>(q, ks + j * HD), dp = dot_row<HD>(g, vs + j * HD);
+            axpy_row<HD>(acc, __expf(s * scale - ls) * (dp - del) * scale, ks + j * HD);
         }
 #pragma unroll
         for (int d = 0; d < HD; ++d) if (d < hd) dqn[(bh * T + i) * hd + d] = f2bf(acc[d]);
@@ -155,13 +165,13 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const bf16_t* __r
                                                              float scale) {
     extern __shared__ float sm[];
     float* qs = sm;
-    float* gs = sm + (size_t)T * hd;
-    float* ls = gs + (size_t)T * hd;
+    float* gs = sm + (size_t)T * HD;
+    float* ls = gs + (size_t)T * HD;
     float* dl = ls + T;
     const size_t bh = blockIdx.x;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * hd;
-    stage_f32(qs, qn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
-    stage_f32(gs, dO + (size_t)b * T * D + hh * hd, D, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(qs, qn + bh * T * hd, hd, T, hd, threadIdx.x, blockDim.x);
+    stage_f32<HD>(gs, dO + (size_t)b * T * D + hh * hd, D, T, hd, threadIdx.x, blockDim.x);
     for (int i = threadIdx.x; i < T; i += blockDim.x) { ls[i] = lse[bh * T + i]; dl[i] = delta[bh * T + i]; }
     __syncthreads();
     for (int j = threadIdx.x; j < T; j += blockDim.x) {
@@ -173,13 +183,10 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const bf16_t* __r
             ak[d] = 0.f; av[d] = 0.f;
         }
         for (int i = 0; i < T; ++i) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) { s += qs[i * hd + d] * k[d]; dp += gs[i * hd + d] * vv[d]; }
+            const float s = dot_row<HD>(k, qs + i * HD), dp = dot_row<HD>(vv, gs + i * HD);
             const float p = __expf(s * scale - ls[i]);
-            const float ds = p * (dp - dl[i]) * scale;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) if (d < hd) { av[d] += p * gs[i * hd + d]; ak[d] += ds * qs[i * hd + d]; }
+            axpy_row<HD>(av, p, gs + i * HD);
+            axpy_row<HD>(ak, p * (dp - dl[i]) * scale, qs + i * HD);
         }
 #pragma unroll
         for (int d = 0; d < HD; ++d) if (d < hd) { dkn[(bh * T + j) * hd + d] = f2bf(ak[d]); dv[(bh * T + j) * hd + d] = f2bf(av[d]); }
@@ -224,7 +231,8 @@ extern "C" int mapdit_attn_generic_fwd(const uint16_t* qn, const uint16_t* kn, c
     MD_CHECK(qn && kn && v && o && lse, "attn_generic_fwd: null argument");
     if (check(T, head_dim) != MAPDIT_OK) return MAPDIT_ERR_ARG;
     const float scale = 1.f / sqrtf((float)head_dim);
-    const size_t shm = (size_t)2 * T * head_dim * 4;
+    const int hdp = head_dim <= 32 ? 32 : head_dim <= 64 ? 64 : head_dim <= 72 ? 72 : 96;      // = HDT of GEN_DISPATCH
+    const size_t shm = (size_t)2 * T * hdp * 4;
     const int nth = T < 256 ? ((T + 63) / 64) * 64 : 256;
     GEN_DISPATCH(head_dim, (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<HDT>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -241,7 +249,8 @@ extern "C" int mapdit_attn_generic_bwd(const uint16_t* qn, const uint16_t* kn, c
     if (check(T, head_dim) != MAPDIT_OK) return MAPDIT_ERR_ARG;
     const float scale = 1.f / sqrtf((float)head_dim);
     const int nth = T < 256 ? ((T + 63) / 64) * 64 : 256;
-    const size_t shm1 = (size_t)2 * T * head_dim * 4, shm2 = shm1 + (size_t)2 * T * 4;
+    const int hdp = head_dim <= 32 ? 32 : head_dim <= 64 ? 64 : head_dim <= 72 ? 72 : 96;
+    const size_t shm1 = (size_t)2 * T * hdp * 4, shm2 = shm1 + (size_t)2 * T * 4;
     GEN_DISPATCH(head_dim, (void)hipFuncSetAttribute((const void*)attn_generic_dq_kernel<HDT>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm1));
     GEN_DISPATCH(head_dim, (void)hipFuncSetAttribute((const void*)attn_generic_dkv_kernel<HDT>,
