@@ -41,7 +41,8 @@ enum {
     MAPDIT_EPI_STORE_F32 = 1,  /* out[m,n] = alpha*acc (+ out[m,n] if accumulate)                                   */
     MAPDIT_EPI_SILU2 = 2,      /* out = bf16(acc) [optional]; out2 = bf16(silu(acc)/0.596)   (mlp.py:18-20, mp_silu.py:7) */
     MAPDIT_EPI_RESID = 3,      /* out = bf16(acc) [optional]; out2[m,n] = alpha*aux[m,n] + beta*gate[m/rows,n]*acc
-                                  = mp_sum(x, gate*y, 0.3) of dit_block.py:35-36; aux/out2: fp32 residual stream       */
+                                  = mp_sum(x, gate*y, 0.3) of dit_block.py:35-36; aux/out2: fp32 residual stream;
+                                  optionally out3 = bf16(modulate(out2, ...)) for the next branch (utils.py:11-16)      */
     MAPDIT_EPI_DSILU = 4,      /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
     MAPDIT_EPI_SILU2_COND = 5  /* SILU2 under its own kernel symbol (timestep MLP, timestep_embedder.py:43)           */
 };
@@ -57,6 +58,12 @@ typedef struct {
     int rows_per_sample;
     float alpha, beta;
     int accumulate;
+    /* RESID only, optional: also write out3 = bf16(modulate(out2, shift2, scale2, *gain2)) — the next branch's GEMM operand */
+    void* out3;
+    const float* shift2;
+    const float* scale2;
+    const float* gain2;
+    int ld2;
     int split_k;       /* STORE_F32 only: K is cut into split_k ranges, partial sum z is stored at out + z*slab_stride */
     long slab_stride;  /* elements between slabs (the consumer adds the slabs: mapdit_weightnorm_bwd) */
 } mapdit_epilogue_t;
@@ -120,6 +127,9 @@ int mapdit_reduce_partials(const float* part, int count, float* out, int accumul
 
 int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream);          /* mp_silu.py:7 */
 int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void* stream);
+int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream);
+/* acc[i] += sum over nslabs of slabs[s*slab_stride + i], in slab order (deterministic split-K reduction). */
+int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Cosine attention (src/layers/attention.py:37-51).  head_dim must be 64; T in {64, 128, 256}.

@@ -23,7 +23,8 @@ class MapditError(RuntimeError):
 
 class Epilogue(C.Structure):
     _fields_ = [("kind", ci), ("out", vp), ("ldo", ci), ("out2", vp), ("aux", vp), ("gate", vp), ("ldg", ci),
-                ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci), ("split_k", ci), ("slab_stride", cl)]
+                ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci), ("out3", vp), ("shift2", vp), ("scale2", vp),
+                ("gain2", vp), ("ld2", ci), ("split_k", ci), ("slab_stride", cl)]
 
 
 class ResidModBwd(C.Structure):
@@ -58,6 +59,8 @@ _SIGS = {
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
     "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
+    "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
+    "mapdit_sum_slabs": [vp, vp, ci, cl, cl, vp],
     "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],

@@ -31,7 +31,6 @@ struct Carver {
 
 struct BlockBufs {
     // saved for backward (train) / scratch (eval)
-    float* mod;       // [N][6D]
     bf16_t *xm, *qkv, *qn, *kn, *v, *qt, *kt, *o, *y, *xm2, *hpre, *hact, *y2;
     float* lse;       // [N*H][T]
 };
@@ -68,6 +67,8 @@ struct mapdit_engine {
     bf16_t* patches;
     // final layer
     float *fmod, *lin, *a_mean, *a_sigma;
+    float* mod_all;                       // [N][L*6D]: every block's (shift, scale, gate) x 2, one batched GEMM
+    int ldm;                              // = L*6D
     bf16_t* xmodf;
     // backward scratch
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
@@ -103,12 +104,12 @@ size_t carve(mapdit_engine* e, void* base) {
     img(MAPDIT_P_F_MOD, 2 * D, D, 2 * D);
     img(MAPDIT_P_MS_LIN, NSCALE, D, NSCALE);
     img(MAPDIT_P_SS_LIN, NSCALE, D, NSCALE);
+    for (int i = 0; i < L; ++i) img(pidx_block(i, MAPDIT_B_MOD), 6 * D, D, 6 * D);   // contiguous: one [L*6D, D] operand
     for (int i = 0; i < L; ++i) {
         img(pidx_block(i, MAPDIT_B_QKV), 3 * D, D, 3 * D);
         img(pidx_block(i, MAPDIT_B_PROJ), D, D, D);
         img(pidx_block(i, MAPDIT_B_FC1), Hm, D, Hm);
         img(pidx_block(i, MAPDIT_B_FC2), D, Hm, D);
-        img(pidx_block(i, MAPDIT_B_MOD), 6 * D, D, 6 * D);
     }
     e->wx_eff = cv.take<float>((size_t)D * e->P1);
     e->table_eff = cv.take<float>((size_t)c.table_rows * D);
@@ -127,7 +128,6 @@ size_t carve(mapdit_engine* e, void* base) {
     e->blk.assign(nb, BlockBufs());
     for (int i = 0; i < nb; ++i) {
         BlockBufs& b = e->blk[i];
-        b.mod = cv.take<float>((size_t)N * 6 * D);
         b.xm = cv.take<bf16_t>(M * D);
         b.qkv = cv.take<bf16_t>(M * 3 * D);
         b.qn = cv.take<bf16_t>(M * D);
@@ -146,6 +146,8 @@ size_t carve(mapdit_engine* e, void* base) {
     e->vt = cv.take<bf16_t>(M * D);
     e->patches = e->train ? cv.take<bf16_t>(M * e->ldp) : nullptr;
     e->fmod = cv.take<float>((size_t)N * 2 * D);
+    e->mod_all = cv.take<float>((size_t)N * L * 6 * D);
+    e->ldm = L * 6 * D;
     e->lin = cv.take<float>(M * 2 * e->P);
     e->a_mean = cv.take<float>((size_t)N * NSCALE);
     e->a_sigma = cv.take<float>((size_t)N * NSCALE);
@@ -179,7 +181,7 @@ size_t carve(mapdit_engine* e, void* base) {
         e->dlin = cv.take<bf16_t>(M * e->ldl);
         e->zero_bytes_dlin = M * e->ldl * sizeof(bf16_t);
         e->da_bf = cv.take<bf16_t>((size_t)2 * N * NSCALE);
-        e->dmod_bf = cv.take<bf16_t>((size_t)N * 6 * D);
+        e->dmod_bf = cv.take<bf16_t>((size_t)N * L * 6 * D);
         e->dx0_bf = cv.take<bf16_t>(M * D);
         e->dtemb_bf = cv.take<bf16_t>((size_t)N * D);
         e->dh1_bf = cv.take<bf16_t>((size_t)N * D);
@@ -246,10 +248,13 @@ mapdit_epilogue_t epi_dsilu(bf16_t* out, const bf16_t* pre, int ldo) {
     e.kind = MAPDIT_EPI_DSILU; e.out = out; e.aux = pre; e.ldo = ldo; return e;
 }
 const float CA = 0.7f / sqrtf(0.58f), CB = 0.3f / sqrtf(0.58f);   // mp_sum(x, y, 0.3): src/utils.py:15-16
-mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo) {
+mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo,
+                            bf16_t* xm_next, const float* nshift, const float* nscale, int ldn, const float* ngain) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
     e.kind = MAPDIT_EPI_RESID; e.out = y; e.out2 = xout; e.aux = xin; e.gate = gate; e.ldg = ldg; e.rows_per_sample = rows;
-    e.ldo = ldo; e.alpha = CA; e.beta = CB; return e;
+    e.ldo = ldo; e.alpha = CA; e.beta = CB;
+    e.out3 = xm_next; e.shift2 = nshift; e.scale2 = nscale; e.ld2 = ldn; e.gain2 = ngain;   // modulate() of the next branch
+    return e;
 }
 
 // Largest divisor s of K/64 with tiles*s <= ~1024 blocks (4 per CU) and s <= max_slabs.
@@ -421,17 +426,22 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // patch embedding                                                  (dit.py:81-84)
     TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], save ? e->patches : nullptr, e->ldp, N,
                                c.in_channels, c.input_size, c.patch, D, st));
+    // (shift, scale, gate) x 2 of EVERY block = MPLinearChunk(MPSiLU(c)) (dit_block.py:33) as ONE GEMM against the
+    // contiguous [L*6D, D] weight image, plus the final layer's (shift, scale); all later modulate()s are fused into
+    // the residual GEMM epilogues that produce their inputs.
+    const int ldm = e->ldm;
+    TRY(gemm(MAPDIT_NT, N, ldm, D, e->c_silu, D, W(pidx_block(0, MAPDIT_B_MOD)), D, epi_f32(e->mod_all, ldm), st));
+    TRY(gemm(MAPDIT_NT, N, 2 * D, D, e->c_silu, D, W(MAPDIT_P_F_MOD), D, epi_f32(e->fmod, 2 * D), st));
+    TRY(mapdit_modulate_fwd(e->X[0], e->mod_all, e->mod_all + D, ldm, e->params[pidx_block(0, MAPDIT_B_GAIN_MSA)],
+                            e->blk[0].xm, N, T, D, st));
     for (int i = 0; i < L; ++i) {
         BlockBufs& b = e->blk[save ? i : 0];
+        const float* mod = e->mod_all + (size_t)i * 6 * D;
         float* xin = e->X[save ? 2 * i : (2 * i) % 3];
         float* xmid = e->X[save ? 2 * i + 1 : (2 * i + 1) % 3];
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
-        float* gmsa = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)];
         float* gmlp = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
-        // (shift, scale, gate) x 2 = MPLinearChunk(MPSiLU(c))            (dit_block.py:33)
-        TRY(gemm(MAPDIT_NT, N, 6 * D, D, e->c_silu, D, W(pidx_block(i, MAPDIT_B_MOD)), D, epi_f32(b.mod, 6 * D), st));
-        // attention branch                                              (dit_block.py:35)
-        TRY(mapdit_modulate_fwd(xin, b.mod, b.mod + D, 6 * D, gmsa, b.xm, N, T, D, st));
+        // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
         if (e->generic_attn) {
             TRY(mapdit_qkv_split_generic(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
@@ -441,20 +451,21 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
             TRY(mapdit_attn_cos_fwd(b.qn, b.kn, e->vt, b.o, b.lse, N, T, H, 64, st));
         }
         TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
-                 epi_resid(save ? b.y : nullptr, xin, xmid, b.mod + 2 * D, 6 * D, T, D), st));
-        // MLP branch                                                    (dit_block.py:36)
-        TRY(mapdit_modulate_fwd(xmid, b.mod + 3 * D, b.mod + 4 * D, 6 * D, gmlp, b.xm2, N, T, D, st));
+                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + 2 * D, ldm, T, D, b.xm2, mod + 3 * D, mod + 4 * D, ldm, gmlp), st));
+        // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2(save ? b.hpre : nullptr, b.hact, Hm), st));
         if (timed) hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
-                 epi_resid(save ? b.y2 : nullptr, xmid, xout, b.mod + 5 * D, 6 * D, T, D), st));
+                 i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->blk[save ? i + 1 : 0].xm, mod + 6 * D,
+                                       mod + 7 * D, ldm, e->params[pidx_block(i + 1, MAPDIT_B_GAIN_MSA)])
+                           : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
+                                       e->params[MAPDIT_P_F_GAIN]), st));
     }
     float* xL = e->X[save ? 2 * L : (2 * L) % 3];
     // final layer                                                       (final_layer.py:53-59, dit.py:96-101)
-    TRY(gemm(MAPDIT_NT, N, 2 * D, D, e->c_silu, D, W(MAPDIT_P_F_MOD), D, epi_f32(e->fmod, 2 * D), st));
-    TRY(mapdit_modulate_fwd(xL, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], e->xmodf, N, T, D, st));
+    (void)xL;   // xmodf = modulate(xL, ...) was written by the last block's fc2 epilogue
     TRY(gemm(MAPDIT_NT, M, 2 * e->P, D, e->xmodf, D, W(MAPDIT_P_F_LIN), D, epi_f32(e->lin, 2 * e->P), st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_MS_LIN), D, epi_f32(e->a_mean, NSCALE), st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_SS_LIN), D, epi_f32(e->a_sigma, NSCALE), st));
@@ -512,8 +523,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
         a.dxm = e->dxm; a.x = e->X[2 * L]; a.shift = e->fmod; a.scale = e->fmod + D; a.gain = e->params[MAPDIT_P_F_GAIN];
         a.ldmod = 2 * D; a.dshift = e->dfmod; a.dscale = e->dfmod + D; a.ldd = 2 * D; a.dgain_part = e->gain_part;
-        a.y_up = bl.y2; a.g_up = bl.mod + 5 * D; a.ldg_up = 6 * D; a.dy_up = e->dy;
-        a.dg_up = e->dmod + (size_t)(L - 1) * N * 6 * D + 5 * D; a.ldd_up = 6 * D;
+        a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * 6 * D + 5 * D; a.ldg_up = e->ldm; a.dy_up = e->dy;
+        a.dg_up = e->dmod + (size_t)(L - 1) * 6 * D + 5 * D; a.ldd_up = e->ldm;
         a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
         TRY(mapdit_resid_mod_bwd(&a, st));
         TRY(mapdit_reduce_partials(e->gain_part, npart, G(MAPDIT_P_F_GAIN), 0, st));
@@ -528,7 +539,9 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         const int stage = L - i;
         if (stage < stage_from || stage > stage_to) continue;
         const BlockBufs& b = e->blk[i];
-        float* dmod = e->dmod + (size_t)i * N * 6 * D;
+        float* dmod = e->dmod + (size_t)i * 6 * D;            // [N][L*6D] like mod_all
+        const float* mod = e->mod_all + (size_t)i * 6 * D;
+        const int ldm = e->ldm;
         // MLP branch
         TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_dsilu(e->dh, b.hpre, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
@@ -536,10 +549,10 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXa; a.dxm = e->dxm; a.x = e->X[2 * i + 1]; a.shift = b.mod + 3 * D; a.scale = b.mod + 4 * D;
-            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = 6 * D;
-            a.dshift = dmod + 3 * D; a.dscale = dmod + 4 * D; a.ldd = 6 * D; a.dgain_part = e->gain_part;
-            a.y_up = b.y; a.g_up = b.mod + 2 * D; a.ldg_up = 6 * D; a.dy_up = e->dy; a.dg_up = dmod + 2 * D; a.ldd_up = 6 * D;
+            a.dxo = e->DXa; a.dxm = e->dxm; a.x = e->X[2 * i + 1]; a.shift = mod + 3 * D; a.scale = mod + 4 * D;
+            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldm;
+            a.dshift = dmod + 3 * D; a.dscale = dmod + 4 * D; a.ldd = ldm; a.dgain_part = e->gain_part;
+            a.y_up = b.y; a.g_up = mod + 2 * D; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + 2 * D; a.ldd_up = ldm;
             a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
             TRY(mapdit_resid_mod_bwd(&a, st));
             TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), 0, st));
@@ -559,13 +572,13 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXb; a.dxm = e->dxm; a.x = e->X[2 * i]; a.shift = b.mod; a.scale = b.mod + D;
-            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = 6 * D;
-            a.dshift = dmod; a.dscale = dmod + D; a.ldd = 6 * D; a.dgain_part = e->gain_part;
+            a.dxo = e->DXb; a.dxm = e->dxm; a.x = e->X[2 * i]; a.shift = mod; a.scale = mod + D;
+            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldm;
+            a.dshift = dmod; a.dscale = dmod + D; a.ldd = ldm; a.dgain_part = e->gain_part;
             if (i > 0) {
                 const BlockBufs& bp = e->blk[i - 1];
-                a.y_up = bp.y2; a.g_up = bp.mod + 5 * D; a.ldg_up = 6 * D; a.dy_up = e->dy;
-                a.dg_up = e->dmod + (size_t)(i - 1) * N * 6 * D + 5 * D; a.ldd_up = 6 * D;
+                a.y_up = bp.y2; a.g_up = mod - D; a.ldg_up = ldm; a.dy_up = e->dy;     // gate_mlp of block i-1
+                a.dg_up = dmod - D; a.ldd_up = ldm;
                 a.dx = e->DXa;
             } else {
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
@@ -574,10 +587,19 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
             TRY(mapdit_resid_mod_bwd(&a, st));
             TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), 0, st));
         }
-        // modulation linear of this block (all six gradient chunks are complete now)
-        TRY(mapdit_f32_to_bf16(dmod, e->dmod_bf, (long)N * 6 * D, 1.f, st));
-        TRY(gemm(MAPDIT_NN, N, D, 6 * D, e->dmod_bf, 6 * D, W(pidx_block(i, MAPDIT_B_MOD)), D, epi_f32(e->dcs, D, 1.f, 1), st));
-        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf, 6 * D, e->c_silu, D, N, 1.f, st));
+        // modulation linear of this block (its six gradient chunks are complete now): dW here, so the block's gradient
+        // slice is final when its stage ends (the DP reducer relies on that); d c_silu for all blocks in one GEMM below
+        TRY(mapdit_f32_to_bf16_2d(dmod, ldm, e->dmod_bf + (size_t)i * 6 * D, ldm, N, 6 * D, 1.f, st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * 6 * D, ldm, e->c_silu, D, N, 1.f, st));
+        if (i == 0) {
+            // d c_silu += dmod_all W_mod_all: ONE split-K GEMM over K = L*6D, slabs summed into dcs
+            mapdit_epilogue_t ep = epi_f32(e->G, D, 1.f);
+            const long slab = (long)N * D;
+            ep.split_k = pick_split_k(N, D, ldm, e->G_cap / slab);
+            ep.slab_stride = slab;
+            TRY(gemm(MAPDIT_NN, N, D, ldm, e->dmod_bf, ldm, W(pidx_block(0, MAPDIT_B_MOD)), D, ep, st));
+            TRY(mapdit_sum_slabs(e->dcs, e->G, ep.split_k, slab, slab, st));
+        }
     }
 
     e->next_stage = stage_to + 1;

@@ -150,18 +150,35 @@ template <int TAG> struct EpiSilu2 {
 };
 struct EpiResid {
     bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
+    // optional fused modulate of the NEXT branch (src/utils.py:11-16): xm = bf16(((1-g) xout scale + g shift) / den)
+    bf16_t* xm; const float* nshift; const float* nscale; const float* ngain; int ldn;
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
-        const float4* g = (const float4*)(gate + (size_t)(m / rows) * ldg + n);
+        const int smp = m / rows;
+        const float4* g = (const float4*)(gate + (size_t)smp * ldg + n);
         const float4* xi = (const float4*)(xin + (size_t)m * ldo + n);
         float4 g0 = g[0], g1 = g[1], x0 = xi[0], x1 = xi[1];
-        float4 o0, o1;
-        o0.x = ca * x0.x + cb * g0.x * v[0]; o0.y = ca * x0.y + cb * g0.y * v[1];
-        o0.z = ca * x0.z + cb * g0.z * v[2]; o0.w = ca * x0.w + cb * g0.w * v[3];
-        o1.x = ca * x1.x + cb * g1.x * v[4]; o1.y = ca * x1.y + cb * g1.y * v[5];
-        o1.z = ca * x1.z + cb * g1.z * v[6]; o1.w = ca * x1.w + cb * g1.w * v[7];
+        float o[8];
+        o[0] = ca * x0.x + cb * g0.x * v[0]; o[1] = ca * x0.y + cb * g0.y * v[1];
+        o[2] = ca * x0.z + cb * g0.z * v[2]; o[3] = ca * x0.w + cb * g0.w * v[3];
+        o[4] = ca * x1.x + cb * g1.x * v[4]; o[5] = ca * x1.y + cb * g1.y * v[5];
+        o[6] = ca * x1.z + cb * g1.z * v[6]; o[7] = ca * x1.w + cb * g1.w * v[7];
         float4* xo = (float4*)(xout + (size_t)m * ldo + n);
-        xo[0] = o0; xo[1] = o1;
+        xo[0] = make_float4(o[0], o[1], o[2], o[3]);
+        xo[1] = make_float4(o[4], o[5], o[6], o[7]);
         if (y) store8_bf16(y + (size_t)m * ldo + n, v);
+        if (xm) {
+            const float gg = *ngain, den = sqrtf((1.f - gg) * (1.f - gg) + gg * gg);
+            const float ka = (1.f - gg) / den, kb = gg / den;
+            const float4* sc = (const float4*)(nscale + (size_t)smp * ldn + n);
+            const float4* sh = (const float4*)(nshift + (size_t)smp * ldn + n);
+            const float4 c0 = sc[0], c1 = sc[1], h0 = sh[0], h1 = sh[1];
+            float w[8];
+            w[0] = ka * o[0] * c0.x + kb * h0.x; w[1] = ka * o[1] * c0.y + kb * h0.y;
+            w[2] = ka * o[2] * c0.z + kb * h0.z; w[3] = ka * o[3] * c0.w + kb * h0.w;
+            w[4] = ka * o[4] * c1.x + kb * h1.x; w[5] = ka * o[5] * c1.y + kb * h1.y;
+            w[6] = ka * o[6] * c1.z + kb * h1.z; w[7] = ka * o[7] * c1.w + kb * h1.w;
+            store8_bf16(xm + (size_t)m * ldo + n, w);
+        }
     }
 };
 struct EpiDSilu {
@@ -573,9 +590,11 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
         case MAPDIT_EPI_RESID:
             MD_CHECK(e->out2 && e->aux && e->gate && e->rows_per_sample > 0, "gemm: RESID needs out2, aux, gate, rows_per_sample");
             MD_CHECK(e->ldg % 4 == 0, "gemm: ldg=%d must be a multiple of 4", e->ldg);
+            MD_CHECK(!e->out3 || (e->shift2 && e->scale2 && e->gain2 && e->ld2 % 4 == 0), "gemm: RESID fused modulate needs shift2, scale2, gain2, ld2 %% 4 == 0");
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
-                                   e->rows_per_sample, e->alpha, e->beta}, st);
+                                   e->rows_per_sample, e->alpha, e->beta, (bf16_t*)e->out3, e->shift2, e->scale2, e->gain2,
+                                   e->ld2}, st);
         case MAPDIT_EPI_DSILU:
             MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);

@@ -275,7 +275,38 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restri
     if (i < n) out[i] = f2bf(alpha * x[i]);
 }
 
+__global__ void f32_to_bf16_2d_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ out, int ldo, int rows, int cols,
+                                      float alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    out[(size_t)r * ldo + c] = f2bf(alpha * x[(size_t)r * ldx + c]);
+}
+// acc[i] += sum_s slabs[s*stride + i]   (fixed order: deterministic split-K reduction)
+__global__ void sum_slabs_kernel(float* __restrict__ acc, const float* __restrict__ slabs, int nslabs, long stride, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = acc[i];
+    for (int s = 0; s < nslabs; ++s) a += slabs[(size_t)s * stride + i];
+    acc[i] = a;
+}
+
 }  // namespace
+
+extern "C" int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream) {
+    MD_CHECK(x && out && rows > 0 && cols > 0 && ldx >= cols && ldo >= cols, "f32_to_bf16_2d: bad argument");
+    hipLaunchKernelGGL(f32_to_bf16_2d_kernel, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                       rows, cols, alpha);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream) {
+    MD_CHECK(acc && slabs && nslabs >= 1 && n > 0, "sum_slabs: bad argument");
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, acc, slabs, nslabs, slab_stride, n);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
 
 extern "C" int mapdit_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
                                    uint16_t* out, int n_samples, int T, int D, void* stream) {
