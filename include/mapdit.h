@@ -132,26 +132,24 @@ int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int r
 int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Cosine attention (src/layers/attention.py:37-51).  head_dim must be 64; T in {64, 128, 256}.
+ * Cosine attention (src/layers/attention.py:37-51).  Head-major operands are [B*H][T][head_dim] bf16, row-major.
+ * head_dim 64 with T in {64, 128, 256} runs on the MFMA kernels; any other head_dim <= 96 / T <= 256 (DiT-XL: 72,
+ * patch-8 models: 16 tokens) is dispatched to the generic fp32 path with the same interface.
  * ------------------------------------------------------------------------------------------------------------ */
-/* qkv [B*T, 3*H*64] -> qn, kn (cosine-normalised), v as [B*H][T][64]; optional transposes [B*H][64][T]. */
+/* qkv [B*T, 3*H*hd] -> qn, kn (cosine-normalised: q*sqrt(hd)/(|q|+eps)), v */
 int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
-                     uint16_t* qt, uint16_t* kt, uint16_t* vt, void* stream);
+                     void* stream);
 int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
                          const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
-/* o [B*T, H*64] = softmax(qn kn^T / 8) v ; lse [B*H][T] */
-int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* vt, uint16_t* o, float* lse, int B,
+/* o [B*T, H*hd] = softmax(qn kn^T / sqrt(hd)) v ; lse [B*H][T] */
+int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
                         int T, int H, int head_dim, void* stream);
-/* dO [B*T, H*64] -> doT [B*H][64][T], delta [B*H][T] = rowsum(dO*O) */
-int mapdit_attn_do_prep(const uint16_t* dO, const uint16_t* O, int B, int T, int H, int head_dim, uint16_t* doT,
-                        float* delta, void* stream);
-int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* qt,
-                        const uint16_t* kt, const uint16_t* dO, const uint16_t* doT, const float* lse,
-                        const float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+/* backward; also writes delta [B*H][T] = rowsum(dO * O) */
+int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                        const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                         int head_dim, void* stream);
 
-/* Generic-shape variants (any head_dim <= 96, any T <= 256; fp32 VALU): DiT-XL (head_dim 72), patch-8 models (T = 16).
- * Head-major buffers are [B*H][T][head_dim] without padding; no transposed images are needed. */
+/* The generic path, callable directly (any head_dim <= 96, any T <= 256; fp32 VALU). */
 int mapdit_qkv_split_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
                              void* stream);
 int mapdit_qkv_merge_bwd_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,

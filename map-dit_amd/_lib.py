@@ -61,11 +61,10 @@ _SIGS = {
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
     "mapdit_sum_slabs": [vp, vp, ci, cl, cl, vp],
-    "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+    "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    "mapdit_attn_do_prep": [vp, vp, ci, ci, ci, ci, vp, vp, vp],
-    "mapdit_attn_cos_bwd": [vp] * 12 + [ci, ci, ci, ci, vp],
+    "mapdit_attn_cos_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
     "mapdit_qkv_split_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_generic_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],

@@ -11,7 +11,8 @@
 //   backward dQ  S^T, dP^T = V dO^T -> dS^T -> dQ = (dS^T)^T K                              needs K^T  [d][key]
 //   backward dKV S = Q K^T (query on rows, key on lanes), dP = dO V^T -> dV = P^T dO, dK = dS^T Q
 //                                                                                  needs dO^T, Q^T [d][query]
-// Every operand is therefore read K-contiguous; the transposed images come from the head-split kernels.
+// Every operand is therefore read K-contiguous.  Transposed images are built in LDS while staging the row-major data
+// (16-byte global loads, 2-byte transposed LDS stores), so HBM holds each head tensor once, row-major.
 // The backward is two passes (7 products instead of 5) so no cross-wave reduction and no atomics are needed:
 // attention is ~5 % of the block's FLOPs.
 #include "common.h"
@@ -53,6 +54,23 @@ __device__ __forceinline__ void stage_tr(char* tile, const bf16_t* __restrict__ 
         d[1] = make_uint2(v.z, v.w);
     }
 }
+// Row-major global [rows = T][64] (row stride ld) -> row-major swizzled LDS tile (may be null) and/or the transposed
+// LDS image [64 d][T] (may be null), in one pass over the data.
+template <int T, int NTHREADS>
+__device__ __forceinline__ void stage_both(char* rows_tile, char* tr_tile, const bf16_t* __restrict__ src, long ld, int tid) {
+    constexpr int VLD = 2 * T + 8;
+    for (int i = tid; i < T * 8; i += NTHREADS) {
+        const int row = i >> 3, c = i & 7;
+        const uint4 v = *(const uint4*)(src + (size_t)row * ld + c * 8);
+        if (rows_tile) *(uint4*)(rows_tile + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+        if (tr_tile) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *(bf16_t*)(tr_tile + (8 * c + e) * VLD + row * 2) = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+        }
+    }
+}
 // B-operand fragment whose k order matches pack8() of an accumulator tile:
 // element j of lane (r, h) is [d = d0 + r][k = kbase + 8 (j >> 2) + 4 h + (j & 3)].
 template <int T>
@@ -79,7 +97,7 @@ template <int T> struct Geo {
 // ---- forward -----------------------------------------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
-                                                              const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                               float* __restrict__ lse, int H, float scale) {
     using G = Geo<T>;
     __shared__ __attribute__((aligned(16))) char smem[T * 128 + 64 * G::VLD];
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     const size_t bh = blockIdx.y;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
     stage_rows<G::NTH>(ks_, kn + bh * T * 64, 64, T, tid);
-    stage_tr<T, G::NTH>(vs_, vt + bh * 64 * T, tid);
+    stage_both<T, G::NTH>(nullptr, vs_, v + bh * T * 64, 64, tid);
     bf16x8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
@@ -135,9 +153,9 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
 // ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
-                                                                 const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt_,
-                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta, bf16_t* __restrict__ dqn,
+                                                                 const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                                 const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, bf16_t* __restrict__ dqn,
                                                                  int H, float scale) {
     using G = Geo<T>;
     __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 64 * G::VLD];
@@ -149,16 +167,22 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
-    stage_rows<G::NTH>(ks_, kn + bh * T * 64, 64, T, tid);
+    stage_both<T, G::NTH>(ks_, kts_, kn + bh * T * 64, 64, tid);
     stage_rows<G::NTH>(vs_, v + bh * T * 64, 64, T, tid);
-    stage_tr<T, G::NTH>(kts_, kt_ + bh * 64 * T, tid);
     bf16x8_t qf[4], dof[4];
+    float del_p = 0.f;                      // delta_q = rowsum(dO * O): this lane's 32 of the 64 features
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
-        dof[ks] = *(const bf16x8_t*)(dO + ((size_t)b * T + q0 + r) * D + hh * 64 + 16 * ks + 8 * h2);
+        const size_t mo = ((size_t)b * T + q0 + r) * D + hh * 64 + 16 * ks + 8 * h2;
+        dof[ks] = *(const bf16x8_t*)(dO + mo);
+        const bf16x8_t of = *(const bf16x8_t*)(O + mo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
     }
-    const float lse_q = lse[bh * T + q0 + r], del_q = delta[bh * T + q0 + r];
+    const float del_q = del_p + __shfl_xor(del_p, 32, 64);
+    if (h2 == 0) delta[bh * T + q0 + r] = del_q;       // consumed by the dK/dV pass (launched after this kernel)
+    const float lse_q = lse[bh * T + q0 + r];
     __syncthreads();
 
     f32x16_t dq[2] = {};
@@ -194,8 +218,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
 // ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
-                                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ qt_,
-                                                                  const bf16_t* __restrict__ dO, const bf16_t* __restrict__ doT,
+                                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
                                                                   float scale) {
@@ -212,10 +235,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int k0 = blockIdx.x * 32 * G::NW + wave * 32;
-    stage_rows<G::NTH>(qs_, qn + bh * T * 64, 64, T, tid);
-    stage_rows<G::NTH>(dos_, dO + (size_t)b * T * D + hh * 64, D, T, tid);
-    stage_tr<T, G::NTH>(qts_, qt_ + bh * 64 * T, tid);
-    stage_tr<T, G::NTH>(dots_, doT + bh * 64 * T, tid);
+    stage_both<T, G::NTH>(qs_, qts_, qn + bh * T * 64, 64, tid);
+    stage_both<T, G::NTH>(dos_, dots_, dO + (size_t)b * T * D + hh * 64, D, tid);
     for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
     bf16x8_t kf[4], vf[4];
 #pragma unroll
@@ -272,31 +293,37 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
         default: mapdit_set_error("attention: T=%d unsupported (64, 128, 256)", T_); return MAPDIT_ERR_ARG; \
     }
 
-extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* vt, uint16_t* o, float* lse,
+// Generic-shape path (attention_generic.hip): any head_dim <= 96, any T <= 256.
+extern "C" int mapdit_attn_generic_fwd(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, int, void*);
+extern "C" int mapdit_attn_generic_bwd(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*,
+                                       const float*, float*, uint16_t*, uint16_t*, uint16_t*, int, int, int, int, void*);
+
+static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 || T == 128 || T == 256); }
+
+extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse,
                                    int B, int T, int H, int head_dim, void* stream) {
-    MD_CHECK(qn && kn && vt && o && lse, "attn_cos_fwd: null argument");
-    MD_CHECK(head_dim == 64, "attn_cos_fwd: head_dim=%d unsupported (64 only: DiT-XS/S/B/L)", head_dim);
+    MD_CHECK(qn && kn && v && o && lse, "attn_cos_fwd: null argument");
+    if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_fwd(qn, kn, v, o, lse, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, vt, o, lse, H, scale));
+                                        qn, kn, v, o, lse, H, scale));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* qt,
-                                   const uint16_t* kt, const uint16_t* dO, const uint16_t* doT, const float* lse,
-                                   const float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
-                                   int head_dim, void* stream) {
-    MD_CHECK(qn && kn && v && qt && kt && dO && doT && lse && delta && dqn && dkn && dv, "attn_cos_bwd: null argument");
-    MD_CHECK(head_dim == 64, "attn_cos_bwd: head_dim=%d unsupported (64 only)", head_dim);
+extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
+                                   const uint16_t* O, const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn,
+                                   uint16_t* dv, int B, int T, int H, int head_dim, void* stream) {
+    MD_CHECK(qn && kn && v && dO && O && lse && delta && dqn && dkn && dv, "attn_cos_bwd: null argument");
+    if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_bwd(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, kt, dO, lse, delta, dqn, H, scale));
+                                        qn, kn, v, dO, O, lse, delta, dqn, H, scale));
     MD_LAUNCH_CHECK();
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, qt, dO, doT, lse, delta, dkn, dv, H, scale));
+                                        qn, kn, v, dO, lse, delta, dkn, dv, H, scale));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -31,7 +31,7 @@ struct Carver {
 
 struct BlockBufs {
     // saved for backward (train) / scratch (eval)
-    bf16_t *xm, *qkv, *qn, *kn, *v, *qt, *kt, *o, *y, *xm2, *hpre, *hact, *y2;
+    bf16_t *xm, *qkv, *qn, *kn, *v, *o, *y, *xm2, *hpre, *hact, *y2;
     float* lse;       // [N*H][T]
 };
 
@@ -63,7 +63,6 @@ struct mapdit_engine {
     // residual stream checkpoints
     std::vector<float*> X;
     std::vector<BlockBufs> blk;
-    bf16_t* vt;                           // scratch V^T
     bf16_t* patches;
     // final layer
     float *fmod, *lin, *a_mean, *a_sigma;
@@ -72,7 +71,7 @@ struct mapdit_engine {
     bf16_t* xmodf;
     // backward scratch
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
-    bf16_t *dy, *dh, *dxm, *dO, *doT, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
+    bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
     long G_cap = 0;                       // floats available in G (split-K slabs)
     // optional HIP-event timing of one kernel family (bench.py roofline)
@@ -133,8 +132,6 @@ size_t carve(mapdit_engine* e, void* base) {
         b.qn = cv.take<bf16_t>(M * D);
         b.kn = cv.take<bf16_t>(M * D);
         b.v = cv.take<bf16_t>(M * D);
-        b.qt = e->train ? cv.take<bf16_t>(M * D) : nullptr;
-        b.kt = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.o = cv.take<bf16_t>(M * D);
         b.y = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.xm2 = cv.take<bf16_t>(M * D);
@@ -143,7 +140,6 @@ size_t carve(mapdit_engine* e, void* base) {
         b.y2 = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.lse = cv.take<float>((size_t)N * c.num_heads * T);
     }
-    e->vt = cv.take<bf16_t>(M * D);
     e->patches = e->train ? cv.take<bf16_t>(M * e->ldp) : nullptr;
     e->fmod = cv.take<float>((size_t)N * 2 * D);
     e->mod_all = cv.take<float>((size_t)N * L * 6 * D);
@@ -173,7 +169,6 @@ size_t carve(mapdit_engine* e, void* base) {
         e->dh = cv.take<bf16_t>(M * Hm);
         e->dxm = cv.take<bf16_t>(M * D);
         e->dO = cv.take<bf16_t>(M * D);
-        e->doT = cv.take<bf16_t>(M * D);
         e->dqn = cv.take<bf16_t>(M * D);
         e->dkn = cv.take<bf16_t>(M * D);
         e->dv = cv.take<bf16_t>(M * D);
@@ -443,13 +438,8 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         float* gmlp = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
-        if (e->generic_attn) {
-            TRY(mapdit_qkv_split_generic(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
-            TRY(mapdit_attn_generic_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
-        } else {
-            TRY(mapdit_qkv_split(b.qkv, N, T, H, 64, b.qn, b.kn, b.v, save ? b.qt : nullptr, save ? b.kt : nullptr, e->vt, st));
-            TRY(mapdit_attn_cos_fwd(b.qn, b.kn, e->vt, b.o, b.lse, N, T, H, 64, st));
-        }
+        TRY(mapdit_qkv_split(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
+        TRY(mapdit_attn_cos_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + 2 * D, ldm, T, D, b.xm2, mod + 3 * D, mod + 4 * D, ldm, gmlp), st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
@@ -560,14 +550,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
-        if (e->generic_attn) {
-            TRY(mapdit_attn_generic_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
-            TRY(mapdit_qkv_merge_bwd_generic(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
-        } else {
-            TRY(mapdit_attn_do_prep(e->dO, b.o, N, T, H, 64, e->doT, e->delta, st));
-            TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, b.qt, b.kt, e->dO, e->doT, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, 64, st));
-            TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, 64, e->dqn, e->dkn, e->dv, e->dqkv, st));
-        }
+        TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
+        TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
         TRY(gemm(MAPDIT_NN, M, D, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {

@@ -140,14 +140,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int count
     if (threadIdx.x == 0) *out = accumulate ? *out + a : a;
 }
 
-// ---- head split + cosine normalise (+ transposed images) ---------------------------------------------------------
-// qkv [M, 3D] bf16 -> qn,kn,v [BH][T][64] and (optionally) their transposes [BH][64][T].
-// q^ = q*sqrt(hd)/(|q|+eps) (reference attention.py:44-45 via utils.py:19-23).  Block = (64 tokens, head, batch).
+// ---- head split + cosine normalise -------------------------------------------------------------------------------
+// qkv [M, 3D] bf16 -> qn, kn, v  [BH][T][64].  q^ = q*sqrt(hd)/(|q|+eps) (reference attention.py:44-45 via utils.py:19-23).
+// Block = (64 tokens, head, batch); 4 threads per token row, 16 features each.
 __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, int T, int H, bf16_t* __restrict__ qn,
-                                                      bf16_t* __restrict__ kn, bf16_t* __restrict__ v,
-                                                      bf16_t* __restrict__ qt, bf16_t* __restrict__ kt,
-                                                      bf16_t* __restrict__ vt) {
-    __shared__ bf16_t tile[64][72];
+                                                      bf16_t* __restrict__ kn, bf16_t* __restrict__ v) {
     const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int D = H * 64;
     const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
@@ -157,38 +154,22 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
         const bf16_t* src = qkv + ((size_t)b * T + t0 + row) * (3 * D) + which * D + h * 64 + qd * 16;
         uint4 u0 = ((const uint4*)src)[0], u1 = ((const uint4*)src)[1];
         uint32_t w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-        float f[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
         if (which < 2) {
+            float f[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ss += f[i] * f[i];
             ss += __shfl_xor(ss, 1, 64);
             ss += __shfl_xor(ss, 2, 64);
-            const float s = 8.f / (sqrtf(ss) + NORM_EPS);
+            const float sc = 8.f / (sqrtf(ss) + NORM_EPS);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] *= s;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+            for (int i = 0; i < 8; ++i) w[i] = pack2bf(f[2 * i] * sc, f[2 * i + 1] * sc);
         }
         bf16_t* dst = (which == 0 ? qn : which == 1 ? kn : v) + (bh * T + t0 + row) * 64 + qd * 16;
         ((uint4*)dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
         ((uint4*)dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        bf16_t* tdst = which == 0 ? qt : which == 1 ? kt : vt;
-        if (tdst) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *(uint32_t*)&tile[row][qd * 16 + 2 * i] = w[i];
-            __syncthreads();
-            // thread -> feature d = row, tokens qd*16 .. +15
-            uint32_t o[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (uint32_t)tile[qd * 16 + 2 * i][row] | ((uint32_t)tile[qd * 16 + 2 * i + 1][row] << 16);
-            bf16_t* td = tdst + (bh * 64 + row) * T + t0 + qd * 16;
-            ((uint4*)td)[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            ((uint4*)td)[1] = make_uint4(o[4], o[5], o[6], o[7]);
-        }
     }
 }
 
@@ -230,39 +211,6 @@ __global__ __launch_bounds__(256) void qkv_merge_bwd_kernel(const bf16_t* __rest
         ((uint4*)(dqkv + moff))[0] = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         ((uint4*)(dqkv + moff))[1] = make_uint4(gw[4], gw[5], gw[6], gw[7]);
     }
-}
-
-// dO prep for attention backward: do [M, D] (merged heads) -> doT [BH][64][T] and delta[BH][T] = sum_d do*o.
-__global__ __launch_bounds__(256) void do_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, int T,
-                                                    int H, bf16_t* __restrict__ doT, float* __restrict__ delta) {
-    __shared__ bf16_t tile[64][72];
-    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int D = H * 64;
-    const int row = threadIdx.x >> 2, qd = threadIdx.x & 3;
-    const size_t bh = (size_t)b * H + h;
-    const size_t moff = ((size_t)b * T + t0 + row) * D + h * 64 + qd * 16;
-    uint4 g0 = ((const uint4*)(dO + moff))[0], g1 = ((const uint4*)(dO + moff))[1];
-    uint4 o0 = ((const uint4*)(O + moff))[0], o1 = ((const uint4*)(O + moff))[1];
-    uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        dot += __uint_as_float(gw[i] << 16) * __uint_as_float(ow[i] << 16);
-        dot += __uint_as_float(gw[i] & 0xffff0000u) * __uint_as_float(ow[i] & 0xffff0000u);
-    }
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    if (qd == 0) delta[bh * T + t0 + row] = dot;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *(uint32_t*)&tile[row][qd * 16 + 2 * i] = gw[i];
-    __syncthreads();
-    uint32_t o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (uint32_t)tile[qd * 16 + 2 * i][row] | ((uint32_t)tile[qd * 16 + 2 * i + 1][row] << 16);
-    bf16_t* td = doT + (bh * 64 + row) * T + t0 + qd * 16;
-    ((uint4*)td)[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    ((uint4*)td)[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // mp_silu on a small fp32 matrix -> bf16 GEMM operand (conditioning path: MPSiLU(c), dit_block.py:24-25).
@@ -344,12 +292,15 @@ extern "C" int mapdit_reduce_partials(const float* part, int count, float* out, 
     return MAPDIT_OK;
 }
 
+extern "C" int mapdit_qkv_split_generic(const uint16_t*, int, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
+extern "C" int mapdit_qkv_merge_bwd_generic(const uint16_t*, int, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*,
+                                            uint16_t*, void*);
+
 extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
-                                uint16_t* v, uint16_t* qt, uint16_t* kt, uint16_t* vt, void* stream) {
+                                uint16_t* v, void* stream) {
     MD_CHECK(qkv && qn && kn && v, "qkv_split: null argument");
-    MD_CHECK(head_dim == 64, "qkv_split: head_dim=%d unsupported (64 only: DiT-XS/S/B/L)", head_dim);
-    MD_CHECK(T % 64 == 0, "qkv_split: T=%d must be a multiple of 64", T);
-    hipLaunchKernelGGL(qkv_split_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, qn, kn, v, qt, kt, vt);
+    if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_split_generic(qkv, B, T, H, head_dim, qn, kn, v, stream);
+    hipLaunchKernelGGL(qkv_split_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, qn, kn, v);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
@@ -357,17 +308,8 @@ extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int he
 extern "C" int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
                                     const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream) {
     MD_CHECK(qkv && dqn && dkn && dv && dqkv, "qkv_merge_bwd: null argument");
-    MD_CHECK(head_dim == 64 && T % 64 == 0, "qkv_merge_bwd: head_dim=%d T=%d unsupported", head_dim, T);
+    if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_merge_bwd_generic(qkv, B, T, H, head_dim, dqn, dkn, dv, dqkv, stream);
     hipLaunchKernelGGL(qkv_merge_bwd_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, dqn, dkn, dv, dqkv);
-    MD_LAUNCH_CHECK();
-    return MAPDIT_OK;
-}
-
-extern "C" int mapdit_attn_do_prep(const uint16_t* dO, const uint16_t* O, int B, int T, int H, int head_dim,
-                                   uint16_t* doT, float* delta, void* stream) {
-    MD_CHECK(dO && O && doT && delta, "attn_do_prep: null argument");
-    MD_CHECK(head_dim == 64 && T % 64 == 0, "attn_do_prep: head_dim=%d T=%d unsupported", head_dim, T);
-    hipLaunchKernelGGL(do_prep_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, dO, O, T, H, doT, delta);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
