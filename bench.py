@@ -96,6 +96,8 @@ def main():
     rank, world, local = init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product has no CPU path)"
+    if os.environ.get("MAPDIT_FORCE_DEVICE"):              # rehearsal of the N > 1 path on a one-GPU box (gloo backend)
+        local = int(os.environ["MAPDIT_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

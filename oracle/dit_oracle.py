@@ -123,7 +123,18 @@ def unpatchify(x: Tensor, input_size: int, p: int) -> Tensor:
     return x.reshape(b, h, w, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(b, c, h * p, w * p)
 
 
-def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
+def _ident(x: Tensor) -> Tensor:
+    return x
+
+
+def bf16_round(x: Tensor) -> Tensor:
+    """Round-to-nearest-even to bfloat16 and back: the storage rounding of the engine's GEMM / attention operands.
+    Passing it as ``rnd`` makes the oracle emulate the engine's precision plan (bf16 operands, fp32 accumulation,
+    fp32 residual stream and conditioning vectors) so that what is left between the two is accumulation order only."""
+    return x.bfloat16().to(x.dtype)
+
+
+def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_ident) -> Tensor:
     """MPLinear / MPLinearChunk forward (src/basic/mp_linear.py:31-46, 67-75), gain == 1.
     Training forward first overwrites the stored weight with its normalised value (F9)."""
     w = sd[key]
@@ -131,7 +142,7 @@ def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor
         with torch.no_grad():
             w.copy_(normalize(w))
     w_eff = normalize(w) / math.sqrt(w.shape[1])
-    return torch.nn.functional.linear(x, w_eff)
+    return torch.nn.functional.linear(rnd(x), rnd(w_eff))
 
 
 def mp_embedding(idx: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
@@ -234,56 +245,60 @@ def init_state_dict(cfg: DiTConfig, seed: int = 0, gains: Optional[float] = None
 # Network
 # ----------------------------------------------------------------------------------------------
 
-def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool) -> Tensor:
+def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_ident) -> Tensor:
     """src/layers/attention.py:29-51: cosine attention, logits = sqrt(hd)*cos(q,k)."""
     B, T, D = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
-    q, k, v = mp_linear(x, sd, prefix + "qkv_proj.weight", train).chunk(3, dim=-1)
+    q, k, v = rnd(mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd)).chunk(3, dim=-1)
     q = q.view(B, T, H, hd).transpose(1, 2)
     k = k.view(B, T, H, hd).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)
-    q, k = normalize(q), normalize(k)
+    q, k = rnd(normalize(q)), rnd(normalize(k))
     logits = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
-    out = torch.softmax(logits, dim=-1) @ v
+    if rnd is _ident:
+        out = torch.softmax(logits, dim=-1) @ v
+    else:   # the kernels keep exp(logit) un-normalised (cosine logits are bounded), round it for the PV product
+        p = torch.exp(logits)
+        out = (rnd(p) @ v) / p.sum(-1, keepdim=True)
     out = out.transpose(1, 2).reshape(B, T, D)
-    return mp_linear(out, sd, prefix + "out_proj.weight", train)
+    return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd)
 
 
-def mlp(x: Tensor, sd, prefix: str, train: bool) -> Tensor:
+def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
     """src/layers/mlp.py:16-25."""
-    h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train))
-    return mp_linear(h, sd, prefix + "net.2.weight", train)
+    h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
+    return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
 
 
-def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool) -> Tensor:
+def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
-    mod = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train)
+    mod = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
-    x = mp_sum(x, g_a.unsqueeze(1) * attention(modulate(x, sh_a, sc_a, sd[p + "gain_msa"]), sd, p + "attn.", cfg, train), RESIDUAL_T)
-    x = mp_sum(x, g_m.unsqueeze(1) * mlp(modulate(x, sh_m, sc_m, sd[p + "gain_mlp"]), sd, p + "mlp.", train), RESIDUAL_T)
+    x = mp_sum(x, g_a.unsqueeze(1) * attention(modulate(x, sh_a, sc_a, sd[p + "gain_msa"]), sd, p + "attn.", cfg, train, rnd), RESIDUAL_T)
+    x = mp_sum(x, g_m.unsqueeze(1) * mlp(modulate(x, sh_m, sc_m, sd[p + "gain_mlp"]), sd, p + "mlp.", train, rnd), RESIDUAL_T)
     return x
 
 
-def mp_scale(c: Tensor, sd, prefix: str, train: bool) -> Tensor:
+def mp_scale(c: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
     """src/blocks/final_layer.py:20-22."""
-    angle = torch.matmul(mp_linear(c, sd, prefix + "linear.weight", train), sd[prefix + "reference"]) / math.sqrt(SCALE_DIM)
+    angle = torch.matmul(mp_linear(c, sd, prefix + "linear.weight", train, rnd), sd[prefix + "reference"]) / math.sqrt(SCALE_DIM)
     return torch.sigmoid(angle)
 
 
-def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool):
+def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_ident):
     """src/blocks/final_layer.py:53-61.  Call order of the MPLinears follows the reference
     (modulation, linear, mean_scale, sigma_scale) — it matters only for forced-WN side effects,
     which are per-weight and order independent."""
     p = "final_layer."
-    shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train).chunk(2, dim=-1)
+    shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
     x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
-    out = mp_linear(x_mod, sd, p + "linear.weight", train)
+    out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd)
     if cfg.learn_sigma:
         mean, sigma = out.chunk(2, dim=-1)
-        return (mean * mp_scale(c, sd, p + "mean_scale.", train).view(-1, 1, 1),
-                sigma * mp_scale(c, sd, p + "sigma_scale.", train).view(-1, 1, 1))
-    return out * mp_scale(c, sd, p + "mean_scale.", train)
+        return (mean * mp_scale(c, sd, p + "mean_scale.", train, rnd).view(-1, 1, 1),
+                sigma * mp_scale(c, sd, p + "sigma_scale.", train, rnd).view(-1, 1, 1))
+    return out * mp_scale(c, sd, p + "mean_scale.", train, rnd)
 
 
 def effective_labels(y: Tensor, cfg: DiTConfig, train: bool, drop: Optional[Tensor]) -> Tensor:
@@ -296,28 +311,29 @@ def effective_labels(y: Tensor, cfg: DiTConfig, train: bool, drop: Optional[Tens
 
 
 def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor,
-                train: bool = False, drop: Optional[Tensor] = None) -> Tensor:
-    """src/dit.py:70-105."""
+                train: bool = False, drop: Optional[Tensor] = None, rnd=_ident) -> Tensor:
+    """src/dit.py:70-105.  ``rnd`` (default: identity = the reference's fp32 arithmetic) is applied wherever the HIP
+    engine stores a GEMM / attention operand in bf16; see bf16_round()."""
     dt = sd["x_embedder.weight"].dtype
     h = patchify(x.to(dt), cfg.patch_size)
     h = torch.cat([h, torch.ones_like(h[:, :, :1])], dim=-1)
-    h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)
+    h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)          # fp32 kernel in the engine
 
     four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
     four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
-    temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train)
-    temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train)
+    temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd)
+    temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
     yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train)
     c = mp_sum(temb, yemb, EMBED_T)
 
     for i in range(cfg.depth):
-        h = dit_block(h, c, sd, i, cfg, train)
+        h = dit_block(h, c, sd, i, cfg, train, rnd)
 
     if cfg.learn_sigma:
-        mean, sigma = final_layer(h, c, sd, cfg, train)
+        mean, sigma = final_layer(h, c, sd, cfg, train, rnd)
         return torch.cat([unpatchify(mean, cfg.input_size, cfg.patch_size),
                           unpatchify(sigma, cfg.input_size, cfg.patch_size)], dim=1)
-    return unpatchify(final_layer(h, c, sd, cfg, train), cfg.input_size, cfg.patch_size)
+    return unpatchify(final_layer(h, c, sd, cfg, train, rnd), cfg.input_size, cfg.patch_size)
 
 
 def dit_forward_with_cfg(sd, cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor, cfg_scale: float,
