@@ -243,6 +243,18 @@ enum { MAPDIT_PROF_FC1_FWD = 0 };
 int mapdit_engine_profile_begin(mapdit_engine_t* e, int which, int max_events);
 int mapdit_engine_profile_end(mapdit_engine_t* e, int* count, double* total_ms); /* synchronises on the events */
 
+/* Diagnostics: device address of an intermediate of the LAST forward that ran with save=1 (training engines keep every
+ * block's activations for backward).  Lets tests compare the engine stage by stage with the oracle instead of only at
+ * the logits.  *dtype: 0 = fp32, 1 = bf16.  `block` is ignored for the MAPDIT_PEEK_G_* ids.  Layouts:
+ *   G_FOUR [N,256] bf16 | G_TEMB [N,D] f32 | G_C [N,D] f32 | G_MOD_ALL [N, depth*6D] f32 | G_X0 [N*T,D] f32 (embedded tokens)
+ *   G_XMODF [N*T,D] bf16 (final modulate) | G_LIN [N*T, ldl] f32 (final linear, ldl = *ld)
+ *   B_XM / B_XM2 [N*T,D] bf16 (modulated inputs of the two branches) | B_QKV [N*T,3D] bf16 | B_QN / B_KN / B_V / B_O
+ *   ([N*H][T][hd] resp. [N*T,D]) bf16 | B_HACT [N*T,4D] bf16 | B_XMID / B_XOUT [N*T,D] f32 (residual stream). */
+enum { MAPDIT_PEEK_G_FOUR = 0, MAPDIT_PEEK_G_TEMB, MAPDIT_PEEK_G_C, MAPDIT_PEEK_G_MOD_ALL, MAPDIT_PEEK_G_X0, MAPDIT_PEEK_G_XMODF,
+       MAPDIT_PEEK_G_LIN, MAPDIT_PEEK_B_XM, MAPDIT_PEEK_B_QKV, MAPDIT_PEEK_B_QN, MAPDIT_PEEK_B_KN, MAPDIT_PEEK_B_V, MAPDIT_PEEK_B_O,
+       MAPDIT_PEEK_B_XM2, MAPDIT_PEEK_B_HACT, MAPDIT_PEEK_B_XMID, MAPDIT_PEEK_B_XOUT, MAPDIT_PEEK_COUNT };
+int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long* elems, int* ld, int* dtype);
+
 #ifdef __cplusplus
 }
 #endif

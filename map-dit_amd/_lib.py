@@ -42,6 +42,8 @@ class Config(C.Structure):
 NT, NN, TN = 0, 1, 2
 EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND = range(6)
 PROF_FC1_FWD = 0
+PEEK_IDS = {name: i for i, name in enumerate(
+    ["four", "temb", "c", "mod_all", "x0", "xmodf", "lin", "xm", "qkv", "qn", "kn", "v", "o", "xm2", "hact", "xmid", "xout"])}
 
 # parameter-table indices (mapdit.h)
 (P_X_EMB, P_T0, P_T2, P_Y_EMB, P_F_LIN, P_F_MOD, P_MS_LIN, P_MS_REF, P_SS_LIN, P_SS_REF, P_F_GAIN, P_FOURIER_SCALE,
@@ -88,6 +90,7 @@ _SIGS = {
     "mapdit_engine_backward_stages": [vp, vp, ci, ci, vp],
     "mapdit_engine_profile_begin": [vp, ci, ci],
     "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
+    "mapdit_engine_peek": [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(ci), C.POINTER(ci)],
 }
 # entry points that do not return a status
 _OTHER = {

@@ -61,7 +61,11 @@ __global__ void fourier_kernel(const long* __restrict__ t, const float* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * F) return;
     const int b = i / F, f = i % F;
-    const float arg = (float)t[b] * scale[f] + shift[f];
+    // torch rounds the product before the add (outer(), then +): the arguments reach ~1e4 rad, where a fused multiply-add
+    // would move cos() by up to 1e-3 - keep the two roundings
+    float prod = (float)t[b] * scale[f];
+    asm volatile("" : "+v"(prod));     // opaque to the optimiser: no contraction into v_fma (build uses -ffp-contract=fast)
+    const float arg = prod + shift[f];
     out[i] = f2bf(1.41421356237309515f * cosf(arg));
 }
 

@@ -467,6 +467,40 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     return MAPDIT_OK;
 }
 
+extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long* elems, int* ld, int* dtype) {
+    MD_CHECK(e && ptr && elems && ld && dtype, "engine_peek: null argument");
+    MD_CHECK(e->have_saved && e->last_N > 0, "engine_peek: needs a forward with save=1 first");
+    MD_CHECK(what >= 0 && what < MAPDIT_PEEK_COUNT, "engine_peek: unknown id %d", what);
+    const bool per_block = what >= MAPDIT_PEEK_B_XM;
+    MD_CHECK(!per_block || (block >= 0 && block < e->cfg.depth), "engine_peek: block %d outside 0..%d", block, e->cfg.depth - 1);
+    const long N = e->last_N, M = N * e->T, D = e->D;
+    const BlockBufs* b = per_block ? &e->blk[block] : nullptr;
+    void* p = nullptr;
+    long n = 0;
+    int l = (int)D, dt = 1;
+    switch (what) {
+        case MAPDIT_PEEK_G_FOUR: p = e->four; n = N * FOURIER; l = FOURIER; break;
+        case MAPDIT_PEEK_G_TEMB: p = e->temb; n = N * D; dt = 0; break;
+        case MAPDIT_PEEK_G_C: p = e->c; n = N * D; dt = 0; break;
+        case MAPDIT_PEEK_G_MOD_ALL: p = e->mod_all; n = N * e->ldm; l = e->ldm; dt = 0; break;
+        case MAPDIT_PEEK_G_X0: p = e->X[0]; n = M * D; dt = 0; break;
+        case MAPDIT_PEEK_G_XMODF: p = e->xmodf; n = M * D; break;
+        case MAPDIT_PEEK_G_LIN: p = e->lin; l = 2 * e->P; n = M * l; dt = 0; break;
+        case MAPDIT_PEEK_B_XM: p = b->xm; n = M * D; break;
+        case MAPDIT_PEEK_B_QKV: p = b->qkv; n = M * 3 * D; l = 3 * (int)D; break;
+        case MAPDIT_PEEK_B_QN: p = b->qn; n = M * D; l = e->hd; break;
+        case MAPDIT_PEEK_B_KN: p = b->kn; n = M * D; l = e->hd; break;
+        case MAPDIT_PEEK_B_V: p = b->v; n = M * D; l = e->hd; break;
+        case MAPDIT_PEEK_B_O: p = b->o; n = M * D; break;
+        case MAPDIT_PEEK_B_XM2: p = b->xm2; n = M * D; break;
+        case MAPDIT_PEEK_B_HACT: p = b->hact; n = M * e->Hm; l = e->Hm; break;
+        case MAPDIT_PEEK_B_XMID: p = e->X[2 * block + 1]; n = M * D; dt = 0; break;
+        case MAPDIT_PEEK_B_XOUT: p = e->X[2 * block + 2]; n = M * D; dt = 0; break;
+    }
+    *ptr = p; *elems = n; *ld = l; *dtype = dt;
+    return MAPDIT_OK;
+}
+
 extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* st) {
     MD_CHECK(e, "engine_backward: null argument");
     return mapdit_engine_backward_stages(e, dout, 0, e->cfg.depth + 1, st);

@@ -374,6 +374,20 @@ class DiT(nn.Module):
         rt.bind(self)
         return rt
 
+    def _peek(self, what: str, block: int = 0) -> torch.Tensor:
+        """Diagnostics (mapdit_engine_peek): a copy of an intermediate of the last training-mode forward, as a 2-d
+        [rows, ld] tensor (fp32 or bf16).  Names: _lib.PEEK_IDS."""
+        rt = self._rt.get(True)
+        if rt is None:
+            raise L.MapditError("_peek needs a training-mode forward first")
+        ptr, n, ld, dt = C.c_void_p(), C.c_long(), C.c_int(), C.c_int()
+        rt.lib.engine_peek(rt.handle, L.PEEK_IDS[what], block, C.byref(ptr), C.byref(n), C.byref(ld), C.byref(dt))
+        off = ptr.value - rt.workspace.data_ptr()
+        size = 2 if dt.value else 4
+        assert 0 <= off and off + n.value * size <= rt.workspace.numel()
+        flat = rt.workspace[off: off + n.value * size].view(torch.bfloat16 if dt.value else torch.float32)
+        return flat.view(-1, ld.value).clone()
+
     def _weights_key(self):
         return (self._w_epoch, sum(p._version for p in self.parameters()))
 

@@ -245,15 +245,23 @@ def init_state_dict(cfg: DiTConfig, seed: int = 0, gains: Optional[float] = None
 # Network
 # ----------------------------------------------------------------------------------------------
 
-def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_ident) -> Tensor:
+def _rec(trace, key, value):
+    if trace is not None:
+        trace[key] = value.detach().clone()
+
+
+def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/layers/attention.py:29-51: cosine attention, logits = sqrt(hd)*cos(q,k)."""
     B, T, D = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
-    q, k, v = rnd(mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd)).chunk(3, dim=-1)
+    qkv = rnd(mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd))
+    _rec(trace, prefix + "qkv", qkv)
+    q, k, v = qkv.chunk(3, dim=-1)
     q = q.view(B, T, H, hd).transpose(1, 2)
     k = k.view(B, T, H, hd).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)
     q, k = rnd(normalize(q)), rnd(normalize(k))
+    _rec(trace, prefix + "qn", q); _rec(trace, prefix + "kn", k); _rec(trace, prefix + "v", v)
     logits = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
     if rnd is _ident:
         out = torch.softmax(logits, dim=-1) @ v
@@ -261,22 +269,31 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
         p = torch.exp(logits)
         out = (rnd(p) @ v) / p.sum(-1, keepdim=True)
     out = out.transpose(1, 2).reshape(B, T, D)
+    _rec(trace, prefix + "o", rnd(out))
     return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd)
 
 
-def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
+def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/layers/mlp.py:16-25."""
     h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
+    _rec(trace, prefix + "hact", rnd(h))
     return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
 
 
-def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident) -> Tensor:
+def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
     mod = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd)
+    _rec(trace, p + "mod", mod)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
-    x = mp_sum(x, g_a.unsqueeze(1) * attention(modulate(x, sh_a, sc_a, sd[p + "gain_msa"]), sd, p + "attn.", cfg, train, rnd), RESIDUAL_T)
-    x = mp_sum(x, g_m.unsqueeze(1) * mlp(modulate(x, sh_m, sc_m, sd[p + "gain_mlp"]), sd, p + "mlp.", train, rnd), RESIDUAL_T)
+    xm = modulate(x, sh_a, sc_a, sd[p + "gain_msa"])
+    _rec(trace, p + "xm", rnd(xm))
+    x = mp_sum(x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace), RESIDUAL_T)
+    _rec(trace, p + "xmid", x)
+    xm2 = modulate(x, sh_m, sc_m, sd[p + "gain_mlp"])
+    _rec(trace, p + "xm2", rnd(xm2))
+    x = mp_sum(x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace), RESIDUAL_T)
+    _rec(trace, p + "xout", x)
     return x
 
 
@@ -286,14 +303,16 @@ def mp_scale(c: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
     return torch.sigmoid(angle)
 
 
-def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_ident):
+def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_ident, trace=None):
     """src/blocks/final_layer.py:53-61.  Call order of the MPLinears follows the reference
     (modulation, linear, mean_scale, sigma_scale) — it matters only for forced-WN side effects,
     which are per-weight and order independent."""
     p = "final_layer."
     shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
     x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
+    _rec(trace, p + "xmod", rnd(x_mod))
     out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd)
+    _rec(trace, p + "lin", out)
     if cfg.learn_sigma:
         mean, sigma = out.chunk(2, dim=-1)
         return (mean * mp_scale(c, sd, p + "mean_scale.", train, rnd).view(-1, 1, 1),
@@ -311,9 +330,10 @@ def effective_labels(y: Tensor, cfg: DiTConfig, train: bool, drop: Optional[Tens
 
 
 def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor,
-                train: bool = False, drop: Optional[Tensor] = None, rnd=_ident) -> Tensor:
+                train: bool = False, drop: Optional[Tensor] = None, rnd=_ident, trace: Optional[dict] = None) -> Tensor:
     """src/dit.py:70-105.  ``rnd`` (default: identity = the reference's fp32 arithmetic) is applied wherever the HIP
-    engine stores a GEMM / attention operand in bf16; see bf16_round()."""
+    engine stores a GEMM / attention operand in bf16; see bf16_round().  ``trace``: a dict that receives named
+    intermediates (for the stage-by-stage parity test against mapdit_engine_peek)."""
     dt = sd["x_embedder.weight"].dtype
     h = patchify(x.to(dt), cfg.patch_size)
     h = torch.cat([h, torch.ones_like(h[:, :, :1])], dim=-1)
@@ -321,19 +341,21 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: 
 
     four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
     four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
+    _rec(trace, "x0", h); _rec(trace, "four", rnd(four))
     temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd)
     temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
     yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train)
     c = mp_sum(temb, yemb, EMBED_T)
+    _rec(trace, "temb", temb); _rec(trace, "c", c)
 
     for i in range(cfg.depth):
-        h = dit_block(h, c, sd, i, cfg, train, rnd)
+        h = dit_block(h, c, sd, i, cfg, train, rnd, trace)
 
     if cfg.learn_sigma:
-        mean, sigma = final_layer(h, c, sd, cfg, train, rnd)
+        mean, sigma = final_layer(h, c, sd, cfg, train, rnd, trace)
         return torch.cat([unpatchify(mean, cfg.input_size, cfg.patch_size),
                           unpatchify(sigma, cfg.input_size, cfg.patch_size)], dim=1)
-    return unpatchify(final_layer(h, c, sd, cfg, train, rnd), cfg.input_size, cfg.patch_size)
+    return unpatchify(final_layer(h, c, sd, cfg, train, rnd, trace), cfg.input_size, cfg.patch_size)
 
 
 def dit_forward_with_cfg(sd, cfg: DiTConfig, x: Tensor, t: Tensor, y: Tensor, cfg_scale: float,

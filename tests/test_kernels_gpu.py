@@ -418,9 +418,11 @@ def test_conditioning_kernels(L):
     td, sd, hd = t.to(DEV), scale.to(DEV), shift.to(DEV)
     L.lib().fourier_fwd(p(td), p(sd), p(hd), p(four), N, 256, st())
     torch.cuda.synchronize()
-    # fp32 cos of arguments up to ~2e4 rad: device vs host libm differ by ~1e-3 abs on a few entries
-    assert float((four.float().cpu() - ref).abs().max()) < 2e-2
-    assert rel_err(four.float().cpu().numpy(), ref.numpy()) < 4e-3
+    # arguments reach ~2e4 rad: the kernel must round t*scale before adding shift exactly like torch (no fused multiply-add),
+    # then device cosf agrees with host cos to 1 ulp(fp32) and the bf16 results are identical up to rare 1-ulp(bf16) ties
+    got, want = four.float().cpu(), ref.bfloat16().float()
+    assert float((got != want).float().mean()) < 2e-3
+    assert float((got - want).abs().max()) < 2e-2
     temb, table = torch.randn(N, D, generator=g), torch.randn(11, D, generator=g)
     y = torch.randint(0, 11, (N,), generator=g)
     cref = (temb + table[y]) * 0.5 / math.sqrt(0.5)
