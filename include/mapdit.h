@@ -205,7 +205,11 @@ typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
     int max_batch;
+    int precision;  /* MAPDIT_PREC_BF16: bf16 MFMA operands (training + inference).  MAPDIT_PREC_BF16X3: fp32-accurate
+                     * forward - fp32 activations, every GEMM on the same MFMA kernel with operands split into hi+lo bf16
+                     * terms (3x the GEMM work, inference engines only); logits agree with the fp32 reference to <1e-3. */
 } mapdit_config_t;
+enum { MAPDIT_PREC_BF16 = 0, MAPDIT_PREC_BF16X3 = 1 };
 
 /* Parameter pointer table: MAPDIT_NUM_GLOBAL global entries followed by MAPDIT_NUM_BLOCK entries per block. */
 enum {

@@ -36,7 +36,10 @@ class ResidModBwd(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
-                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci)]
+                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci)]
+
+
+PRECISIONS = {"bf16": 0, "bf16x3": 1}
 
 
 NT, NN, TN = 0, 1, 2

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "precise.h"
 
 namespace {
 
@@ -73,6 +74,11 @@ struct mapdit_engine {
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
     bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
+    // fp32-accurate forward (cfg.precision == MAPDIT_PREC_BF16X3): fp32 activations + split operand staging
+    struct {
+        float *four, *h1, *t0, *qkv, *qn, *kn, *v, *o, *y, *h, *wtmp;
+        bf16_t* As;                       // [rows][3K] split A operand of the next GEMM
+    } px;
     long G_cap = 0;                       // floats available in G (split-K slabs)
     // optional HIP-event timing of one kernel family (bench.py roofline)
     int prof_which = -1;
@@ -92,8 +98,9 @@ size_t carve(mapdit_engine* e, void* base) {
     Carver cv(base);
     const int np = MAPDIT_NUM_GLOBAL + L * MAPDIT_NUM_BLOCK;
     e->wimg.assign(np, WeightImg());
+    const bool precise = c.precision == MAPDIT_PREC_BF16X3;
     auto img = [&](int idx, int rows, int cols, int rows_alloc) {
-        e->wimg[idx].img = cv.take<bf16_t>((size_t)rows_alloc * cols);
+        e->wimg[idx].img = cv.take<bf16_t>((size_t)rows_alloc * cols * (precise ? 3 : 1));
         e->wimg[idx].rows = rows;
         e->wimg[idx].cols = cols;
     };
@@ -148,6 +155,25 @@ size_t carve(mapdit_engine* e, void* base) {
     e->a_mean = cv.take<float>((size_t)N * NSCALE);
     e->a_sigma = cv.take<float>((size_t)N * NSCALE);
     e->xmodf = cv.take<bf16_t>(M * D);
+    if (precise) {
+        size_t wmax = (size_t)6 * D * D;
+        if ((size_t)Hm * D > wmax) wmax = (size_t)Hm * D;
+        if ((size_t)D * FOURIER > wmax) wmax = (size_t)D * FOURIER;
+        e->px.wtmp = cv.take<float>(wmax);
+        e->px.four = cv.take<float>((size_t)N * FOURIER);
+        e->px.h1 = cv.take<float>((size_t)N * D);
+        e->px.t0 = cv.take<float>(M * D);
+        e->px.qkv = cv.take<float>(M * 3 * D);
+        e->px.qn = cv.take<float>(M * D);
+        e->px.kn = cv.take<float>(M * D);
+        e->px.v = cv.take<float>(M * D);
+        e->px.o = cv.take<float>(M * D);
+        e->px.y = cv.take<float>(M * D);
+        e->px.h = cv.take<float>(M * Hm);
+        size_t amax = M * 3 * (size_t)(Hm > D ? Hm : D);
+        if ((size_t)N * 3 * FOURIER > amax) amax = (size_t)N * 3 * FOURIER;
+        e->px.As = cv.take<bf16_t>(amax);
+    }
     if (e->train) {
         size_t gmax = (size_t)6 * D * D;
         if ((size_t)Hm * D > gmax) gmax = (size_t)Hm * D;
@@ -187,6 +213,7 @@ size_t carve(mapdit_engine* e, void* base) {
 int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c, "engine: null config");
     MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
+    MD_CHECK(c->precision == MAPDIT_PREC_BF16 || c->precision == MAPDIT_PREC_BF16X3, "engine: unknown precision %d", c->precision);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
              "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
@@ -286,6 +313,10 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
 
 extern "C" size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int train) {
     if (check_cfg(cfg) != MAPDIT_OK) return 0;
+    if (train && cfg->precision != MAPDIT_PREC_BF16) {
+        mapdit_set_error("engine: precision bf16x3 is forward-only (inference engines)");
+        return 0;
+    }
     mapdit_engine tmp;
     tmp.cfg = *cfg;
     tmp.train = train;
@@ -297,6 +328,7 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
                                     mapdit_engine_t** out) {
     TRY(check_cfg(cfg));
     MD_CHECK(workspace && out, "engine_create: null argument");
+    MD_CHECK(!train || cfg->precision == MAPDIT_PREC_BF16, "engine: precision bf16x3 is forward-only (inference engines)");
     MD_CHECK(((uintptr_t)workspace & 255) == 0, "engine_create: workspace must be 256-byte aligned");
     mapdit_engine* e = new mapdit_engine();
     e->cfg = *cfg;
@@ -313,7 +345,8 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     e->grads.assign(np, nullptr);
     // Padding rows of the final-linear image and padding columns of dlin must be (and stay) zero.
     const WeightImg& fl = e->wimg[MAPDIT_P_F_LIN];
-    hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t), (hipStream_t)stream);
+    hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t) * (cfg->precision == MAPDIT_PREC_BF16X3 ? 3 : 1),
+                                   (hipStream_t)stream);
     if (he == hipSuccess && train) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
     if (he != hipSuccess) {
         delete e;
@@ -325,8 +358,8 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
 }
 
 static void prof_release(mapdit_engine* e) {
-    for (hipEvent_t ev : e->prof_start) hipEventDestroy(ev);
-    for (hipEvent_t ev : e->prof_stop) hipEventDestroy(ev);
+    for (hipEvent_t ev : e->prof_start) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->prof_stop) (void)hipEventDestroy(ev);
     e->prof_start.clear();
     e->prof_stop.clear();
     e->prof_used = 0;
@@ -387,11 +420,69 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
     for (size_t i = 0; i < e->wimg.size(); ++i) {
         const WeightImg& w = e->wimg[i];
         if (!w.img) continue;
+        if (c.precision == MAPDIT_PREC_BF16X3) {   // fp32 effective weight -> [hi | lo | hi] image, K' = 3K
+            TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, nullptr, e->px.wtmp, nullptr, st));
+            TRY(mapdit_split3(e->px.wtmp, w.cols, w.img, w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
+            continue;
+        }
         TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, w.img, nullptr, nullptr, st));
     }
     TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_X_EMB], e->D, e->P1, forced, 1.f, nullptr, e->wx_eff, nullptr, st));
     TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_Y_EMB], c.table_rows, e->D, forced, sqrtf((float)e->D), nullptr, e->table_eff,
                               nullptr, st));
+    return MAPDIT_OK;
+}
+
+// The fp32-accurate forward (see precise.hip): same sequence as mapdit_engine_forward, nothing fused, every linear as
+//   split(A) -> bf16 MFMA GEMM over K' = 3K -> fp32.
+static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, const int64_t* y_eff, int N, float* out, void* st) {
+    const mapdit_config_t& c = e->cfg;
+    const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, ldm = e->ldm;
+    const int M = N * T;
+    auto& px = e->px;
+    // out[rows, nout] = op(src)[rows, K] x W_idx^T
+    auto linear = [&](const float* src, int rows, int K, int op, int widx, int nout, float* dst, int ldo) -> int {
+        TRY(mapdit_split3(src, K, px.As, rows, K, MAPDIT_SPLIT_A, op, st));
+        return gemm(MAPDIT_NT, rows, nout, 3 * K, px.As, 3 * K, e->wimg[widx].img, 3 * K, epi_f32(dst, ldo), st);
+    };
+    const int NONE = MAPDIT_SPLIT_OP_NONE, SILU = MAPDIT_SPLIT_OP_MPSILU;
+    // conditioning (dit.py:86-88)
+    TRY(mapdit_fourier32(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], px.four, N, FOURIER, st));
+    TRY(linear(px.four, N, FOURIER, NONE, MAPDIT_P_T0, D, px.h1, D));
+    TRY(linear(px.h1, N, D, SILU, MAPDIT_P_T2, D, e->temb, D));
+    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));   // fp32 c; bf16 copies unused
+    TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], nullptr, e->ldp, N, c.in_channels, c.input_size,
+                               c.patch, D, st));
+    TRY(mapdit_split3(e->c, D, px.As, N, D, MAPDIT_SPLIT_A, SILU, st));
+    TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, px.As, 3 * D, e->wimg[pidx_block(0, MAPDIT_B_MOD)].img, 3 * D, epi_f32(e->mod_all, ldm), st));
+    TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_F_MOD].img, 3 * D, epi_f32(e->fmod, 2 * D), st));
+    float* xin = e->X[0];
+    float* xmid = e->X[1];
+    for (int i = 0; i < L; ++i) {
+        const float* mod = e->mod_all + (size_t)i * 6 * D;
+        // attention branch (dit_block.py:35)
+        TRY(mapdit_modulate32(xin, mod, mod + D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], px.t0, N, T, D, st));
+        TRY(linear(px.t0, M, D, NONE, pidx_block(i, MAPDIT_B_QKV), 3 * D, px.qkv, 3 * D));
+        TRY(mapdit_qkv_split32(px.qkv, N, T, H, e->hd, px.qn, px.kn, px.v, st));
+        TRY(mapdit_attn32(px.qn, px.kn, px.v, px.o, N, T, H, e->hd, st));
+        TRY(linear(px.o, M, D, NONE, pidx_block(i, MAPDIT_B_PROJ), D, px.y, D));
+        TRY(mapdit_resid32(xin, px.y, mod + 2 * D, ldm, xmid, N, T, D, 0.3f, st));
+        // MLP branch (dit_block.py:36)
+        TRY(mapdit_modulate32(xmid, mod + 3 * D, mod + 4 * D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], px.t0, N, T, D, st));
+        TRY(linear(px.t0, M, D, NONE, pidx_block(i, MAPDIT_B_FC1), Hm, px.h, Hm));
+        TRY(linear(px.h, M, Hm, SILU, pidx_block(i, MAPDIT_B_FC2), D, px.y, D));
+        TRY(mapdit_resid32(xmid, px.y, mod + 5 * D, ldm, xin, N, T, D, 0.3f, st));
+    }
+    // final layer (final_layer.py:53-59)
+    TRY(mapdit_modulate32(xin, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], px.t0, N, T, D, st));
+    TRY(linear(px.t0, M, D, NONE, MAPDIT_P_F_LIN, 2 * e->P, e->lin, 2 * e->P));
+    TRY(mapdit_split3(e->c, D, px.As, N, D, MAPDIT_SPLIT_A, NONE, st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_MS_LIN].img, 3 * D, epi_f32(e->a_mean, NSCALE), st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_SS_LIN].img, 3 * D, epi_f32(e->a_sigma, NSCALE), st));
+    TRY(mapdit_final_out_fwd(e->lin, 2 * e->P, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], out, N,
+                             c.in_channels, c.input_size, c.patch, st));
+    e->last_N = N;
+    e->have_saved = false;
     return MAPDIT_OK;
 }
 
@@ -401,6 +492,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     MD_CHECK(N > 0 && N <= e->cfg.max_batch, "engine_forward: batch %d outside 1..%d", N, e->cfg.max_batch);
     MD_CHECK(!save || e->train, "engine_forward: save requested on an inference-only engine");
     const mapdit_config_t& c = e->cfg;
+    if (c.precision == MAPDIT_PREC_BF16X3) return forward_precise(e, x, t, y_eff, N, out, st);
     const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads;
     const int M = N * T;
     auto W = [&](int idx) { return e->wimg[idx].img; };
@@ -444,9 +536,9 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + 2 * D, ldm, T, D, b.xm2, mod + 3 * D, mod + 4 * D, ldm, gmlp), st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
-        if (timed) hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
+        if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2(save ? b.hpre : nullptr, b.hact, Hm), st));
-        if (timed) hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
+        if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
                  i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->blk[save ? i + 1 : 0].xm, mod + 6 * D,
                                        mod + 7 * D, ldm, e->params[pidx_block(i + 1, MAPDIT_B_GAIN_MSA)])

@@ -177,14 +177,15 @@ def get_2d_sincos_pos_embed(embed_dim: int, grid_size: int) -> np.ndarray:
 class _Runtime:
     """Owns a mapdit engine handle and its workspace tensor."""
 
-    def __init__(self, model: "DiT", max_batch: int, train: bool):
+    def __init__(self, model: "DiT", max_batch: int, train: bool, precision: str = "bf16"):
         lib = L.lib()
-        self.lib, self.train, self.max_batch = lib, train, max_batch
+        self.lib, self.train, self.max_batch, self.precision = lib, train, max_batch, precision
         self.device = model.pos_embed.device
         rows = model.y_embedder.embedding.weight.shape[0]
         self.cfg = L.Config(depth=len(model.blocks), hidden=model.hidden_size, patch=model.patch_size,
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
-                            mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch)
+                            mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
+                            precision=L.PRECISIONS[precision])
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
             raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
@@ -281,7 +282,8 @@ class DiT(nn.Module):
         self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
 
-        self._rt = {}                 # {train: _Runtime}
+        self._rt = {}                 # {train (bool) | "bf16x3": _Runtime}
+        self.gemm_precision = "bf16"  # "bf16x3": fp32-accurate forward (inference only, ~3x slower), see mapdit.h
         self._pflat = None            # flat fp32 storage behind every parameter (views)
         self._gflat = None            # flat gradient buffer, p.grad are views of it
         self._gviews = None
@@ -365,12 +367,18 @@ class DiT(nn.Module):
             raise L.MapditError("MaP-DiT runs on the MI355X only: move the module to a cuda device (there is no CPU path)")
         if self._pflat.dtype != torch.float32:
             raise L.MapditError("master parameters must be fp32 (bf16 is the engine's internal GEMM operand type)")
-        rt = self._rt.get(train)
+        precision = getattr(self, "gemm_precision", "bf16")
+        if precision not in L.PRECISIONS:
+            raise L.MapditError(f"gemm_precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
+        if precision != "bf16" and train:
+            raise L.MapditError(f"gemm_precision={precision!r} is forward-only: run it under torch.no_grad()")
+        slot = train if precision == "bf16" else precision
+        rt = self._rt.get(slot)
         if rt is None or rt.max_batch < batch or rt.device != self._pflat.device:
             if rt is not None:
-                del self._rt[train]
-            rt = _Runtime(self, max(batch, 1), train)
-            self._rt[train] = rt
+                del self._rt[slot]
+            rt = _Runtime(self, max(batch, 1), train, precision)
+            self._rt[slot] = rt
         rt.bind(self)
         return rt
 

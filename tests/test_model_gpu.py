@@ -76,6 +76,38 @@ def test_eval_forward_matches_bf16_emulating_oracle(name):
     assert e_emul < 0.6 * e_fp32
 
 
+PRECISE_TOL = 1e-3      # BASELINE.json north_star: "forward logits within 1e-3 rel of reference"
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "s4_n8", "s2_n2", "b2_n2", "xl_d1", "tiny_p8"])
+def test_precise_forward_within_1e3_of_reference(name):
+    """gemm_precision="bf16x3": fp32 activations and every linear on the MFMA GEMM kernel with hi+lo split operands.
+    The logits must be within 1e-3 (norm-wise relative) of the reference's fp32 forward - the fixtures' ``eval_out`` were
+    produced by the reference itself (tests/golden/make_golden.py)."""
+    g = load_golden(name)
+    m, cfg, _ = build(g)
+    m.gemm_precision = "bf16x3"
+    x, t, y = dev(g, "x", "t", "y")
+    with torch.no_grad():
+        out = m(x, t, y)
+        again = m(x, t, y)
+    ref = g["eval_out"]
+    got = sub(out) if ref.shape != tuple(out.shape) else out.cpu().numpy()
+    e = rel_err(got, ref)
+    m.gemm_precision = "bf16"
+    with torch.no_grad():
+        fast = m(x, t, y)
+    e_fast = rel_err(sub(fast) if ref.shape != tuple(fast.shape) else fast.cpu().numpy(), ref)
+    print(f"{name}: bf16x3 logits rel err {e:.3e} (bf16: {e_fast:.3e})")
+    assert torch.equal(out, again)
+    assert e < PRECISE_TOL
+    # forward-only: asking for gradients in this mode must fail loudly, not silently fall back to bf16
+    import mapdit_amd._lib as L
+    m.gemm_precision = "bf16x3"
+    with pytest.raises(L.MapditError):
+        m(x, t, y)
+
+
 @pytest.mark.parametrize("name", ["tiny_a", "s2_n2"])
 def test_forward_stage_by_stage_against_emulating_oracle(name):
     """Every intermediate the engine keeps (mapdit_engine_peek) against the same quantity in the bf16-emulating oracle,
