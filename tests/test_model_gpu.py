@@ -108,6 +108,28 @@ def test_precise_forward_within_1e3_of_reference(name):
         m(x, t, y)
 
 
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_c", "s2_n2", "b2_n2"])
+def test_precise_training_mode_losses_match_reference(name):
+    """Training-mode forward (forced weight normalisation rewrites the weights, recorded label drop) + the loss
+    kernels in bf16x3 precision against the reference's per-sample loss / mse / vb: 1e-4."""
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden(name)
+    m, cfg, _ = build(g, train=True)
+    m.gemm_precision = "bf16x3"
+    x, t, y_eff, noise = dev(g, "x", "t", "y_eff", "noise")
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    diff = create_diffusion(timestep_respacing="")
+    with torch.no_grad():
+        losses = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)
+    for k in ("loss", "mse", "vb"):
+        e = rel_err(losses[k].cpu().numpy(), g["train_" + k])
+        print(f"{name}: bf16x3 {k} rel err {e:.3e}")
+        assert e < 1e-4, k
+    for k, p in m.named_parameters():
+        if "postw/" + k in g:
+            assert rel_err(sub(p.detach()), g["postw/" + k]) < 2e-6, k
+
+
 @pytest.mark.parametrize("name", ["tiny_a", "s2_n2"])
 def test_forward_stage_by_stage_against_emulating_oracle(name):
     """Every intermediate the engine keeps (mapdit_engine_peek) against the same quantity in the bf16-emulating oracle,
