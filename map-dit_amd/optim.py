@@ -85,6 +85,49 @@ class FusedAdamEMA:
                                   m._pflat.numel(), hyper.data_ptr(), b1, b2, self.eps, L.cur_stream())
         m.mark_weights_changed()
 
+    # ---- checkpoint interchange with the reference (train.py:125-132 stores torch.optim.Adam.state_dict()) -------
+    def _slots(self):
+        return [(o, p.numel(), p.shape) for p, o in zip(self.model.parameters(), self.model._poffs)]
+
+    def state_dict(self):
+        """Same layout as ``torch.optim.Adam(model.parameters()).state_dict()``: per-parameter ``step`` / ``exp_avg`` /
+        ``exp_avg_sq`` keyed by the parameter's index (the parameter order equals the reference's), one param group."""
+        state = {}
+        if self.step_count > 0:
+            for i, (o, n, shape) in enumerate(self._slots()):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + n].view(shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone()}
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "initial_lr": self.lr, "params": list(range(len(self.model._poffs)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts what ``state_dict`` above or the reference's ``opt.state_dict()`` holds."""
+        slots = self._slots()
+        group = sd["param_groups"][0]
+        assert len(sd["param_groups"]) == 1 and len(group["params"]) == len(slots), "optimizer state does not match the model"
+        self.betas, self.eps = tuple(group["betas"]), group["eps"]
+        self.lr = group.get("initial_lr", group["lr"])
+        steps = {int(v["step"]) for v in sd["state"].values()}
+        assert len(steps) <= 1, "per-parameter step counts differ"
+        self.step_count = steps.pop() if steps else 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, (o, n, shape) in enumerate(slots):
+            st = sd["state"].get(i) or sd["state"].get(str(i))
+            if st is None:
+                continue
+            self.exp_avg[o:o + n].view(shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + n].view(shape).copy_(st["exp_avg_sq"])
+
+    def load_ema_state_dict(self, std: float, sd):
+        """Restore one EMA copy from a snapshot's ``state_dict`` (resuming a run)."""
+        flat = self.ema[self.ema_stds.index(std)]
+        for (name, p), o in zip(self.model.named_parameters(), self.model._poffs):
+            flat[o:o + p.numel()].view(p.shape).copy_(sd[name].to(flat.dtype))
+
     def ema_state_dict(self, std: float):
         """EMA weights as a state_dict with the reference's keys (what src/ema.py:143-155 snapshots), fp32."""
         i = self.ema_stds.index(std)

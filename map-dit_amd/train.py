@@ -179,7 +179,7 @@ def main(argv=None):
             running.zero_()
             log_steps, start = 0, time()
         if rank == 0 and train_steps % args.ckpt_every == 0:
-            torch.save({"model": model.state_dict(), "opt": {"step": opt.step_count, "exp_avg": opt.exp_avg, "exp_avg_sq": opt.exp_avg_sq}},
+            torch.save({"model": model.state_dict(), "opt": opt.state_dict()},                 # reference train.py:125-132
                        os.path.join(exp, "checkpoints", f"{train_steps:07d}.pt"))
         if rank == 0 and args.ema_snapshot_every and train_steps % args.ema_snapshot_every == 0:
             for std in opt.ema_stds:                                   # reference src/ema.py:143-155

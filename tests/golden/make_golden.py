@@ -239,7 +239,44 @@ def optimizer_fixture():
     print("== optim3.npz written")
 
 
+from ema_fixture_data import ema_snapshot_set           # noqa: E402  (tests/golden/ema_fixture_data.py)
+
+
+def ema_fixture():
+    """Post-hoc EMA (reference src/ema.py:10-114): gammas, betas, solve_weights and full reconstructions; pins §8(f) N3."""
+    import tempfile
+    import src.ema as R
+    out = {}
+    stds = np.array([0.0075, 0.01, 0.05, 0.075, 0.1, 0.15, 0.2])
+    out["stds"] = stds
+    out["gammas"] = R.std_to_gamma(stds)
+    out["stds_back"] = R.gamma_to_std(out["gammas"])
+    out["beta_t"] = np.array([1, 2, 10, 1000, 400000])
+    out["betas_0.05"] = np.array([R.calc_beta(0.05, t) for t in out["beta_t"]], dtype=np.float64)
+    out["betas_0.1"] = np.array([R.calc_beta(0.1, t) for t in out["beta_t"]], dtype=np.float64)
+    ts = np.array([1000, 1000, 2000, 2000, 3000, 3000, 4000, 4000])
+    st = np.array([0.05, 0.1] * 4)
+    out["sw_ts"], out["sw_stds"] = ts, st
+    out["sw_targets"] = np.array([0.0075, 0.03, 0.075, 0.15])
+    out["sw_weights"] = R.solve_weights(ts, R.std_to_gamma(st), np.full(4, 4000), R.std_to_gamma(out["sw_targets"]))
+    snaps = ema_snapshot_set()
+    with tempfile.TemporaryDirectory() as d:
+        for std, t, sd in snaps:
+            torch.save({"std": std, "t": t, "state_dict": sd}, os.path.join(d, f"{std:.3f}_{t:07d}.pt"))
+        out["order"] = np.array(os.listdir(d))            # the reference accumulates in os.listdir order
+        for target in (0.075, 0.02, 0.1):
+            res = R.calculate_posthoc_ema(target, d, verbose=False)
+            for k, v in res.items():
+                out[f"posthoc_{target}/{k}"] = v.float().numpy()
+                out[f"posthoc_{target}_dtype/{k}"] = np.array(str(v.dtype))
+    np.savez_compressed(os.path.join(HERE, "ema.npz"), **out)
+    print("== ema.npz written")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ema":
+        ema_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "optim3":
         optimizer_fixture()
         sys.exit(0)
