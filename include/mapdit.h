@@ -44,7 +44,13 @@ enum {
                                   = mp_sum(x, gate*y, 0.3) of dit_block.py:35-36; aux/out2: fp32 residual stream;
                                   optionally out3 = bf16(modulate(out2, ...)) for the next branch (utils.py:11-16)      */
     MAPDIT_EPI_DSILU = 4,      /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
-    MAPDIT_EPI_SILU2_COND = 5  /* SILU2 under its own kernel symbol (timestep MLP, timestep_embedder.py:43)           */
+    MAPDIT_EPI_SILU2_COND = 5, /* SILU2 under its own kernel symbol (timestep MLP, timestep_embedder.py:43)           */
+    MAPDIT_EPI_QKV_HEADS = 6   /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
+                                * is (which, head, d) = (n / D, n % D / 64, n % 64); q and k rows are cosine-normalised per
+                                * head, x * s with s = 8 / (|x| + 1e-4) from the fp32 accumulators, and everything is written
+                                * head-major: out = q^, out2 = k^, out3 = v as bf16 [M/rows_per_sample * H][rows_per_sample][64],
+                                * out4 = s as fp32 [2][M/rows_per_sample * H][rows_per_sample] (q then k; the backward's
+                                * normalisation Jacobian needs nothing else).  head_dim 64 only; N = 3D, D % 64 == 0.       */
 };
 
 typedef struct {
@@ -66,6 +72,7 @@ typedef struct {
     int ld2;
     int split_k;       /* STORE_F32 only: K is cut into split_k ranges, partial sum z is stored at out + z*slab_stride */
     long slab_stride;  /* elements between slabs (the consumer adds the slabs: mapdit_weightnorm_bwd) */
+    void* out4;        /* QKV_HEADS only: the per-(token, head) normalisation scales */
 } mapdit_epilogue_t;
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
@@ -148,6 +155,12 @@ int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* 
 int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                         const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                         int head_dim, void* stream);
+/* Same backward with the normalisation Jacobian of q^ = q * s, k^ = k * s (s = 8 / (|.| + 1e-4), attention.py:43 through
+ * src/utils.py:19-23) and the head merge fused into the two passes: writes dqkv [B*T, 3*H*64] = grad of the QKV projection's
+ * output directly.  scales = the fp32 [2][B*H][T] array MAPDIT_EPI_QKV_HEADS wrote.  head_dim 64, T in {64, 128, 256}. */
+int mapdit_attn_cos_bwd_fused(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                              const float* lse, float* delta, const float* scales, uint16_t* dqkv, int B, int T, int H,
+                              int head_dim, void* stream);
 
 /* The generic path, callable directly (any head_dim <= 96, any T <= 256; fp32 VALU). */
 int mapdit_qkv_split_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
                                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                  const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dqn,
-                                                                 int H, float scale) {
+                                                                 int H, float scale, const float* __restrict__ sq,
+                                                                 bf16_t* __restrict__ dqkv) {
     using G = Geo<T>;
     __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 64 * G::VLD];
     char* ks_ = smem;
@@ -207,6 +208,24 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
                 dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
         }
     }
+    if (dqkv) {
+        // fused backward of q^ = q * s, s = 8 / (|q| + eps):  dq = s dq^ - q^ (dq^ . q^) / (8 |q|), written straight into
+        // the q section of dqkv [M, 3D] (no dq^ round trip through HBM, no separate merge kernel)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t rowg = bh * T + q0 + acc_row(i, lane);
+            const float qa = bf2f(qn[rowg * 64 + r]), qb = bf2f(qn[rowg * 64 + 32 + r]);
+            float dot = dq[0][i] * qa + dq[1][i] * qb;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            const float s = sq[rowg], n = 8.f / s - NORM_EPS;
+            const float c = dot / (8.f * fmaxf(n, 1e-30f));
+            bf16_t* dst = dqkv + ((size_t)b * T + q0 + acc_row(i, lane)) * (3 * D) + hh * 64;
+            dst[r] = f2bf(s * dq[0][i] - qa * c);
+            dst[32 + r] = f2bf(s * dq[1][i] - qb * c);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int qr = acc_row(i, lane);
@@ -221,7 +240,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
                                                                   const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
-                                                                  float scale) {
+                                                                  float scale, const float* __restrict__ sk,
+                                                                  bf16_t* __restrict__ dqkv) {
     using G = Geo<T>;
     __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 2 * 64 * G::VLD + 2 * T * 4];
     char* qs_ = smem;
@@ -272,6 +292,24 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
             }
         }
     }
+    if (dqkv) {                                        // as in the dQ pass: k section with the normalisation Jacobian, v as is
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t rowg = bh * T + k0 + acc_row(i, lane);
+            const float ka = bf2f(kn[rowg * 64 + r]), kb = bf2f(kn[rowg * 64 + 32 + r]);
+            float dot = dk[0][i] * ka + dk[1][i] * kb;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            const float s = sk[rowg], n = 8.f / s - NORM_EPS;
+            const float c = dot / (8.f * fmaxf(n, 1e-30f));
+            bf16_t* dst = dqkv + ((size_t)b * T + k0 + acc_row(i, lane)) * (3 * D) + D + hh * 64;
+            dst[r] = f2bf(s * dk[0][i] - ka * c);
+            dst[32 + r] = f2bf(s * dk[1][i] - kb * c);
+            dst[D + r] = f2bf(dvv[0][i]);
+            dst[D + 32 + r] = f2bf(dvv[1][i]);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int kr = acc_row(i, lane);
@@ -320,10 +358,28 @@ extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, O, lse, delta, dqn, H, scale));
+                                        qn, kn, v, dO, O, lse, delta, dqn, H, scale, (const float*)nullptr, (bf16_t*)nullptr));
     MD_LAUNCH_CHECK();
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, lse, delta, dkn, dv, H, scale));
+                                        qn, kn, v, dO, lse, delta, dkn, dv, H, scale, (const float*)nullptr, (bf16_t*)nullptr));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_attn_cos_bwd_fused(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
+                                         const uint16_t* O, const float* lse, float* delta, const float* scales,
+                                         uint16_t* dqkv, int B, int T, int H, int head_dim, void* stream) {
+    MD_CHECK(qn && kn && v && dO && O && lse && delta && scales && dqkv, "attn_cos_bwd_fused: null argument");
+    MD_CHECK(mfma_shape(T, head_dim), "attn_cos_bwd_fused: head_dim=%d, T=%d unsupported (64; 64/128/256)", head_dim, T);
+    const float scale = 0.125f;
+    const float* sq = scales;
+    const float* sk = scales + (size_t)B * H * T;
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, O, lse, delta, (bf16_t*)nullptr, H, scale, sq, dqkv));
+    MD_LAUNCH_CHECK();
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, lse, delta, (bf16_t*)nullptr, (bf16_t*)nullptr, H, scale, sk, dqkv));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

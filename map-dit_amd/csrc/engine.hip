@@ -34,6 +34,7 @@ struct BlockBufs {
     // saved for backward (train) / scratch (eval)
     bf16_t *xm, *qkv, *qn, *kn, *v, *o, *y, *xm2, *hpre, *hact, *y2;
     float* lse;       // [N*H][T]
+    float* qks;       // [2][N*H][T] cosine-normalisation scales of q, k (fused QKV epilogue; MFMA attention path only)
 };
 
 struct WeightImg {
@@ -135,7 +136,8 @@ size_t carve(mapdit_engine* e, void* base) {
     for (int i = 0; i < nb; ++i) {
         BlockBufs& b = e->blk[i];
         b.xm = cv.take<bf16_t>(M * D);
-        b.qkv = cv.take<bf16_t>(M * 3 * D);
+        b.qkv = e->generic_attn ? cv.take<bf16_t>(M * 3 * D) : nullptr;      // the fused QKV epilogue never writes qkv
+        b.qks = e->generic_attn ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
         b.qn = cv.take<bf16_t>(M * D);
         b.kn = cv.take<bf16_t>(M * D);
         b.v = cv.take<bf16_t>(M * D);
@@ -529,8 +531,18 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
         float* gmlp = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
-        TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
-        TRY(mapdit_qkv_split(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
+        if (e->generic_attn) {
+            TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
+            TRY(mapdit_qkv_split(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
+        } else {   // head split + cosine normalisation of q, k in the GEMM epilogue (attention.py:38-43)
+            mapdit_epilogue_t ep;
+            memset(&ep, 0, sizeof(ep));
+            ep.kind = MAPDIT_EPI_QKV_HEADS;
+            ep.out = b.qn; ep.out2 = b.kn; ep.out3 = b.v; ep.out4 = b.qks;
+            ep.rows_per_sample = T;
+            ep.alpha = 1.f;
+            TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
+        }
         TRY(mapdit_attn_cos_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + 2 * D, ldm, T, D, b.xm2, mod + 3 * D, mod + 4 * D, ldm, gmlp), st));
@@ -579,7 +591,9 @@ extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void*
         case MAPDIT_PEEK_G_XMODF: p = e->xmodf; n = M * D; break;
         case MAPDIT_PEEK_G_LIN: p = e->lin; l = 2 * e->P; n = M * l; dt = 0; break;
         case MAPDIT_PEEK_B_XM: p = b->xm; n = M * D; break;
-        case MAPDIT_PEEK_B_QKV: p = b->qkv; n = M * 3 * D; l = 3 * (int)D; break;
+        case MAPDIT_PEEK_B_QKV:
+            MD_CHECK(b->qkv, "engine_peek: the fused QKV epilogue writes q^, k^, v only (qkv exists on the generic attention path)");
+            p = b->qkv; n = M * 3 * D; l = 3 * (int)D; break;
         case MAPDIT_PEEK_B_QN: p = b->qn; n = M * D; l = e->hd; break;
         case MAPDIT_PEEK_B_KN: p = b->kn; n = M * D; l = e->hd; break;
         case MAPDIT_PEEK_B_V: p = b->v; n = M * D; l = e->hd; break;
@@ -676,8 +690,12 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
-        TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
-        TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        if (e->generic_attn) {
+            TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
+            TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
+        } else {   // normalisation Jacobian + head merge inside the attention backward passes
+            TRY(mapdit_attn_cos_bwd_fused(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, b.qks, e->dqkv, N, T, H, e->hd, st));
+        }
         TRY(gemm(MAPDIT_NN, M, D, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {

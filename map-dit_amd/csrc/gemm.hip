@@ -192,6 +192,37 @@ struct EpiDSilu {
     }
 };
 
+// QKV projection with the head split and the cosine normalisation of q, k fused in.  Every kernel above hands the 8
+// chunks of one 64-column head segment of a row to 8 consecutive lanes, so the per-head sum of squares is three
+// xor-shuffles.  (which, head) are uniform over those 8 lanes; the row's predicate too.
+struct EpiQkvHeads {
+    bf16_t *qn, *kn, *v; float* s; int T, H;          // D = 64 H
+    __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
+        const int D = 64 * H;
+        const int which = n / D, c = n - which * D, h = c >> 6, d = c & 63;
+        const int b = m / T, t = m - b * T;
+        const size_t row = ((size_t)b * H + h) * T + t;
+        float w[8];
+        if (which < 2) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            const float sc = 8.f / (sqrtf(ss) + NORM_EPS);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = a[i] * sc;
+            if (d == 0) s[(size_t)which * (size_t)rows_total + row] = sc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = a[i];
+        }
+        store8_bf16((which == 0 ? qn : which == 1 ? kn : v) + row * 64 + d, w);
+    }
+    long rows_total;                                    // samples * H * T = rows of the head-major tensors
+};
+
 // ---- the MFMA kernel -------------------------------------------------------------------------------------
 template <int AK, int BK, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
@@ -570,7 +601,7 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
     MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_SILU2_COND || e->kind == MAPDIT_EPI_RESID,
              "gemm: null output");
     MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
-    MD_CHECK(e->ldo % 8 == 0, "gemm: ldo=%d must be a multiple of 8", e->ldo);
+    MD_CHECK(e->ldo % 8 == 0 || e->kind == MAPDIT_EPI_QKV_HEADS, "gemm: ldo=%d must be a multiple of 8", e->ldo);
     hipStream_t st = (hipStream_t)stream;
     MD_CHECK(e->split_k <= 1 || e->kind == MAPDIT_EPI_STORE_F32, "gemm: split_k is only available with EPI_STORE_F32");
     switch (e->kind) {
@@ -598,6 +629,14 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
         case MAPDIT_EPI_DSILU:
             MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
+        case MAPDIT_EPI_QKV_HEADS: {
+            MD_CHECK(e->out2 && e->out3 && e->out4 && e->rows_per_sample > 0, "gemm: QKV_HEADS needs out2, out3, out4, rows_per_sample");
+            MD_CHECK(N % 192 == 0 && M % e->rows_per_sample == 0, "gemm: QKV_HEADS needs N = 3 * 64 * heads, M = samples * rows_per_sample");
+            const int H = N / 192;
+            return launch(layout, M, N, K, A, lda, B, ldb,
+                          EpiQkvHeads{(bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, (float*)e->out4, e->rows_per_sample, H,
+                                      (long)M * H}, st);
+        }
     }
     mapdit_set_error("gemm: unknown epilogue kind %d", e->kind);
     return MAPDIT_ERR_ARG;

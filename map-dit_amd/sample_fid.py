@@ -36,11 +36,11 @@ def build_parser():
     return p
 
 
+@torch.no_grad()          # the reference switches autograd off globally (torch.set_grad_enabled(False)); scoped here
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    torch.set_grad_enabled(False)
     device = torch.device("cuda")
     train_args = S.load_train_args(args.result_dir)
     model = get_model(train_args).to(device)

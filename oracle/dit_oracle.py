@@ -254,9 +254,14 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
     """src/layers/attention.py:29-51: cosine attention, logits = sqrt(hd)*cos(q,k)."""
     B, T, D = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
-    qkv = rnd(mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd))
+    qkv = mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd)
+    # engine: head_dim 64 with 64/128/256 tokens normalises q, k from the fp32 accumulators inside the QKV GEMM's epilogue
+    # (one rounding, after the normalisation); the generic attention path stores qkv in bf16 first
+    if not (hd == 64 and T in (64, 128, 256)):
+        qkv = rnd(qkv)
     _rec(trace, prefix + "qkv", qkv)
     q, k, v = qkv.chunk(3, dim=-1)
+    v = rnd(v)
     q = q.view(B, T, H, hd).transpose(1, 2)
     k = k.view(B, T, H, hd).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)

@@ -331,6 +331,66 @@ def test_attention_fwd_bwd(L, B, T, H):
     assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
 
 
+@pytest.mark.parametrize("B,T,H,K", [(2, 64, 2, 128), (1, 256, 3, 192), (8, 128, 4, 256), (3, 64, 1, 64)])
+def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
+    """QKV GEMM with the head split + cosine normalisation in its epilogue (MAPDIT_EPI_QKV_HEADS), attention forward, and
+    the backward that writes dqkv directly (normalisation Jacobian + head merge inside the two passes) against autograd
+    over the oracle ops.  The shapes cover the 256x256, the 128x128 and the generic GEMM kernel."""
+    from oracle.dit_oracle import normalize
+    D = H * 64
+    M = B * T
+    x = bf16_exact(M, K, seed=20, scale=0.25)
+    w = bf16_exact(3 * D, K, seed=21, scale=0.25)
+    dO = bf16_exact(M, D, seed=22)
+    qkv_ref = (x @ w.t()).requires_grad_(True)                    # fp32 product of bf16-exact operands
+    q, k, v = qkv_ref.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, 64).transpose(1, 2)
+    qn, kn = normalize(sp(q)), normalize(sp(k))
+    att = torch.softmax(qn @ kn.transpose(-1, -2) / 8.0, dim=-1) @ sp(v)
+    o_ref = att.transpose(1, 2).reshape(M, D)
+    o_ref.backward(dO)
+
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    xd, wd = to_bf(x), to_bf(w)
+    qn_d, kn_d, v_d = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
+    scales = torch.zeros(2, B * H, T, device=DEV)
+    run_gemm(L, 0, xd, wd, L.EPI_QKV_HEADS, M, 3 * D, K, out=p(qn_d), out2=p(kn_d), out3=p(v_d), out4=p(scales),
+             rows_per_sample=T, alpha=1.0)
+    qn_r, kn_r = qn.detach().reshape(B * H, T, 64), kn.detach().reshape(B * H, T, 64)
+    # one bf16 rounding of the fp32-normalised rows: 2^-9 relative per element
+    assert rel_err(qn_d.float().cpu().numpy(), qn_r.numpy()) < 2.5e-3
+    assert rel_err(kn_d.float().cpu().numpy(), kn_r.numpy()) < 2.5e-3
+    assert rel_err(v_d.float().cpu().numpy(), sp(v).detach().reshape(B * H, T, 64).numpy()) < 2.5e-3
+    s_ref = torch.stack([8.0 / (torch.linalg.vector_norm(sp(z).detach(), dim=-1) + 1e-4) for z in (q, k)]).reshape(2, B * H, T)
+    assert rel_err(scales.cpu().numpy(), s_ref.numpy()) < 1e-5
+
+    lib = L.lib()
+    o_d = mk(M, D)
+    lse = torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd(p(qn_d), p(kn_d), p(v_d), p(o_d), p(lse), B, T, H, 64, st())
+    dOd = to_bf(dO)
+    delta = torch.zeros(B * H, T, device=DEV)
+    dqkv = mk(M, 3 * D)
+    lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 64, st())
+    torch.cuda.synchronize()
+    assert rel_err(o_d.float().cpu().numpy(), o_ref.detach().numpy()) < 1e-2
+    got = dqkv.float().cpu().view(M, 3, D)
+    ref = qkv_ref.grad.view(M, 3, D)
+    assert rel_err(got[:, 2].numpy(), ref[:, 2].numpy()) < 1.5e-2     # dV
+    assert rel_err(got[:, 0].numpy(), ref[:, 0].numpy()) < 3e-2       # dQ through the cosine-norm Jacobian
+    assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
+    # the fused backward equals the two-kernel chain (attn_cos_bwd + qkv_merge_bwd on the bf16 qkv) up to its extra roundings
+    qkvd = to_bf(qkv_ref.detach())
+    dqn, dkn, dv = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
+    lib.attn_cos_bwd(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(dqn), p(dkn), p(dv), B, T, H, 64, st())
+    dqkv2 = mk(M, 3 * D)
+    lib.qkv_merge_bwd(p(qkvd), B, T, H, 64, p(dqn), p(dkn), p(dv), p(dqkv2), st())
+    torch.cuda.synchronize()
+    assert rel_err(dqkv.float().cpu().numpy(), dqkv2.float().cpu().numpy()) < 1e-2
+    with pytest.raises(L.MapditError):                                   # head_dim 72 has no fused path
+        lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 72, st())
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 72), (1, 256, 2, 72), (3, 16, 2, 64), (2, 48, 1, 40)])
 def test_generic_attention_fwd_bwd(L, B, T, H, hd):
     """The fp32 VALU path for head sizes / token counts the MFMA kernels do not take (DiT-XL head_dim 72, patch-8 T = 16)."""
