@@ -41,6 +41,7 @@ struct GemmP {
     int tiles;      // output tiles (grid = tiles * split_k)
     int split_k;    // K is cut into split_k equal ranges; slab z of the output holds the partial sum of range z
     int band;       // 256^2 kernel: column tiles per band of the band-major tile order (L2 residency of the B panel)
+    int phases;     // 256^2 kernel: 4 = one output quadrant per phase (16 MFMAs), 2 = one half per phase (32 MFMAs)
 };
 
 // Swizzle key of K-major row k.  One ds_read_b64_tr_b16 half-wave touches rows {8g+q, q = 0..3, g = 0..1} (then the
@@ -422,7 +423,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 0, b1 + OFF_A0, wave, lane);
         stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 0, b1 + OFF_B0, wave, lane);
         stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 1, b1 + OFF_B1, wave, lane);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0, B0 of tile 0 have landed; five half-tiles in flight
+        if (p.phases == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A0, B0, B1 of tile 0 have landed
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                  // A0, B0 of tile 0; five half-tiles in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -437,6 +439,47 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     // DMA issue order per wave: ... A1[t+1] (phase 1 of tile t), A0[t+2] (2), B0[t+2] (3), B1[t+2] (4), A1[t+2] ...
     // Every wait leaves the five youngest half-tiles in flight (vmcnt(10)) and retires what the NEXT phase reads:
     //   phase 1 -> B1[t] (read in 2)   phase 2 -> A1[t] (read in 3)   phase 4 -> A0[t+1], B0[t+1] (read in 1 of t+1)
+    if (p.phases == 2) {
+        // Two phases per K-tile: 32 MFMAs (512 cycles) per MFMA interval, half as many barriers.  Phase A reads A0, B0, B1
+        // of tile t and computes the upper half (quadrants (0,0), (0,1)); phase B reads A1 and computes the lower half from
+        // the held B fragments.  DMA issue order per wave: ... {A0 B0 B1}[t+2] in phase B of tile t (those slots were last read
+        // in phase A of t), A1[t+2] in phase A of t+1 (slot last read in phase B of t) ...  Waits leave the four youngest
+        // half-tiles in flight: phase A retires A1[t] (read in B), phase B retires {A0 B0 B1}[t+1] (read in A of t+1).
+        for (int t = 0; t < nk; ++t) {
+            char* cur = smem + (t & 1) * KBUF_BYTES;
+            char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
+            const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            load_a(cur + OFF_A0);
+            G256_LOAD_B(fb0, cur + OFF_B0);
+            G256_LOAD_B(fb1, cur + OFF_B1);
+            if (has1) {
+                stage_half<AK, 0>(p.A, p.lda, m0, p.M, k1, 1, nxt + OFF_A1, wave, lane);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_END_LOAD();
+            G256_MFMA(0, 0, fb0);
+            G256_MFMA(0, 1, fb1);
+            G256_END_MFMA();
+            load_a(cur + OFF_A1);
+            if (has2) {
+                stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 0, cur + OFF_A0, wave, lane);
+                stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 0, cur + OFF_B0, wave, lane);
+                stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (has1) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_END_LOAD();
+            G256_MFMA(1, 1, fb1);
+            G256_MFMA(1, 0, fb0);
+            G256_END_MFMA();
+        }
+    } else
     for (int t = 0; t < nk; ++t) {
         char* cur = smem + (t & 1) * KBUF_BYTES;
         char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
@@ -550,8 +593,10 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         return MAPDIT_ERR_ARG;
     }
     if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
+        const char* ph = getenv("MAPDIT_GEMM_PHASES");        // A/B switch for benchmarking: 4 = the quadrant-per-phase schedule
+        if (ph && atoi(ph) == 4) p.phases = 4;
         // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
         const char* be = getenv("MAPDIT_GEMM_BAND");
         long band = be ? atol(be) : (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);
@@ -565,7 +610,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
     } else if (mfma) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);

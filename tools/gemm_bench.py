@@ -69,13 +69,15 @@ def main():
         ("fc1  dW  TN split", 2, 4 * D, D, M, dh, 4 * D, x, D, None),
         ("proj dW  TN split", 2, D, D, M, dy, D, x, D, None),
     ]
-    print(f"{'case':20s} {'tile':>5s} {'ms':>8s} {'TFLOP/s':>9s}")
+    variants = [("128", 128, 4), ("256/4ph", 256, 4), ("256/2ph", 256, 2)]
+    print(f"{'case':20s} {'kernel':>8s} {'ms':>8s} {'TFLOP/s':>9s}")
     for name, layout, m, n, k, a, lda, b, ldb, e in cases:
         flops = 2.0 * m * n * k
-        res = {128: [], 256: []}
+        res = {v[0]: [] for v in variants}
         for _ in range(args.rounds):
-            for tile in (128, 256):
+            for vname, tile, phases in variants:
                 os.environ["MAPDIT_GEMM_TILE"] = str(tile)
+                os.environ["MAPDIT_GEMM_PHASES"] = str(phases)
                 ee = e
                 if ee is None:
                     tiles = ((m + tile - 1) // tile) * ((n + tile - 1) // tile)
@@ -83,10 +85,11 @@ def main():
                     units = k // 64
                     s = max(d for d in range(1, max(1, min(want, units // 4, 64)) + 1) if units % d == 0)
                     ee = ep(L.EPI_STORE_F32, out=out_f32.data_ptr(), ldo=n, alpha=1.0, split_k=s, slab_stride=m * n)
-                res[tile].append(run(layout, m, n, k, a, lda, b, ldb, ee, args.iters))
-        for tile in (128, 256):
-            ms = sorted(res[tile])[len(res[tile]) // 2]
-            print(f"{name:20s} {tile:5d} {ms:8.3f} {flops / ms / 1e9:9.1f}")
+                res[vname].append(run(layout, m, n, k, a, lda, b, ldb, ee, args.iters))
+        for vname, _, _ in variants:
+            ms = sorted(res[vname])[len(res[vname]) // 2]
+            print(f"{name:20s} {vname:>8s} {ms:8.3f} {flops / ms / 1e9:9.1f}")
+    os.environ.pop("MAPDIT_GEMM_PHASES", None)
     os.environ.pop("MAPDIT_GEMM_TILE", None)
 
 
