@@ -84,6 +84,74 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int d0, int kbase,
 }
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
+// A wave's 32 x 64 result tile, held as two accumulator tiles (columns r and 32 + r of rows acc_row(i)), leaves through a
+// private 32 x 136-byte LDS buffer so that each lane stores four 16-byte row chunks (8 lanes = one 128-byte row) instead of
+// thirty-two 2-byte column elements.  gdst = address of the tile's [0][0], row stride ld elements.
+constexpr int WT_LD = 136;                                  // bytes; 34 dwords: rows 4 apart land 8 banks apart
+constexpr int WT_BYTES = 32 * WT_LD;
+__device__ __forceinline__ void store_wave_tile(char* wbuf, const float (&c0)[16], const float (&c1)[16], bf16_t* gdst, size_t ld,
+                                                int lane) {
+    const int r = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        char* row = wbuf + acc_row(i, lane) * WT_LD;
+        *(bf16_t*)(row + 2 * r) = f2bf(c0[i]);
+        *(bf16_t*)(row + 64 + 2 * r) = f2bf(c1[i]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int id = lane + 64 * k, row = id >> 3, c = id & 7;
+        const uint2 lo = *(const uint2*)(wbuf + row * WT_LD + c * 16);
+        const uint2 hi = *(const uint2*)(wbuf + row * WT_LD + c * 16 + 8);
+        *(uint4*)(gdst + (size_t)row * ld + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// The same exit for a gradient tile g = dL/dx^ of cosine-normalised rows x^ = x * s, s = 8 / (|x| + eps): the tile is parked in
+// LDS as fp32 [32][68], then 8 lanes per row apply  dx = s g - x^ (g . x^) / (8 |x|)  on 8-column chunks (one 16-byte load of
+// x^, three xor-shuffles for the row dot product) and store 16 bytes each.  xhat = the wave's 32 rows of x^ ([32][64] bf16),
+// srow = their 32 scales.
+constexpr int WF_LD = 68;                                   // floats per row: rows 4 apart land 16 banks apart
+constexpr int WF_BYTES = 32 * WF_LD * 4;
+__device__ __forceinline__ void store_wave_tile_jac(float* wbuf, const f32x16_t& g0, const f32x16_t& g1, bf16_t* gdst, size_t ld,
+                                                    const bf16_t* __restrict__ xhat, const float* __restrict__ srow, int lane) {
+    const int r = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float* row = wbuf + acc_row(i, lane) * WF_LD;
+        row[r] = g0[i];
+        row[32 + r] = g1[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int id = lane + 64 * k, row = id >> 3, c = id & 7;
+        const f32x4_t a = *(const f32x4_t*)(wbuf + row * WF_LD + c * 8), b = *(const f32x4_t*)(wbuf + row * WF_LD + c * 8 + 4);
+        const uint4 xv = *(const uint4*)(xhat + row * 64 + c * 8);
+        const float g[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+        float x[8], dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] = __uint_as_float((e & 1) ? (xw[e >> 1] & 0xffff0000u) : (xw[e >> 1] << 16));
+            dot += g[e] * x[e];
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        const float sc = srow[row], n = 8.f / sc - NORM_EPS;
+        const float cc = dot / (8.f * fmaxf(n, 1e-30f));
+        uint4 out;
+        out.x = pack2bf(sc * g[0] - x[0] * cc, sc * g[1] - x[1] * cc);
+        out.y = pack2bf(sc * g[2] - x[2] * cc, sc * g[3] - x[3] * cc);
+        out.z = pack2bf(sc * g[4] - x[4] * cc, sc * g[5] - x[5] * cc);
+        out.w = pack2bf(sc * g[6] - x[6] * cc, sc * g[7] - x[7] * cc);
+        *(uint4*)(gdst + (size_t)row * ld + c * 8) = out;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int T> struct Geo {
     // One workgroup per head: T/32 waves (8 at T = 256), 32 owner rows each, all sharing one LDS copy of the head's
     // operands.  The backward images fill most of the LDS (one workgroup per CU), so the wave count per workgroup IS
@@ -114,39 +182,38 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
     __syncthreads();
 
-    f32x16_t s[G::NT];
+    // one pass over the keys: cosine logits are bounded (|q^.k^| / 8 <= 8), so exp() needs no running maximum and every
+    // 32-key tile goes S -> exp -> P V straight from registers; nothing but the 32x64 output tile and the row sum is carried
+    f32x16_t oa[2] = {};
     float lsum = 0.f;
-#pragma unroll
+#pragma unroll 2
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
-        s[kt] = a;
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-
-    f32x16_t oa[2] = {};
-#pragma unroll
-    for (int kt = 0; kt < G::NT; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t pa = pack8(s[kt], 8 * s2);
+            const bf16x8_t pa = pack8(a, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
                 oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
         }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
     const int b = (int)(bh / H), hh = (int)(bh % H);
     const int D = H * 64;
     const float inv_l = 1.f / lsum;
+    float c0[16], c1[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int qr = acc_row(i, lane);
-        const float il = __shfl(inv_l, qr, 64);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[((size_t)b * T + q0 + qr) * D + hh * 64 + 32 * dt + r] = f2bf(oa[dt][i] * il);
+        const float il = __shfl(inv_l, acc_row(i, lane), 64);
+        c0[i] = oa[0][i] * il;
+        c1[i] = oa[1][i] * il;
     }
+    __syncthreads();                                   // K / V images are dead: reuse them as store buffers
+    store_wave_tile(smem + wave * WT_BYTES, c0, c1, o + ((size_t)b * T + q0) * D + hh * 64, D, lane);
     if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
 }
 
@@ -208,30 +275,19 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
                 dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
         }
     }
+    __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
     if (dqkv) {
-        // fused backward of q^ = q * s, s = 8 / (|q| + eps):  dq = s dq^ - q^ (dq^ . q^) / (8 |q|), written straight into
-        // the q section of dqkv [M, 3D] (no dq^ round trip through HBM, no separate merge kernel)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const size_t rowg = bh * T + q0 + acc_row(i, lane);
-            const float qa = bf2f(qn[rowg * 64 + r]), qb = bf2f(qn[rowg * 64 + 32 + r]);
-            float dot = dq[0][i] * qa + dq[1][i] * qb;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
-            const float s = sq[rowg], n = 8.f / s - NORM_EPS;
-            const float c = dot / (8.f * fmaxf(n, 1e-30f));
-            bf16_t* dst = dqkv + ((size_t)b * T + q0 + acc_row(i, lane)) * (3 * D) + hh * 64;
-            dst[r] = f2bf(s * dq[0][i] - qa * c);
-            dst[32 + r] = f2bf(s * dq[1][i] - qb * c);
-        }
+        // fused backward of q^ = q * s: straight into the q section of dqkv [M, 3D] (no dq^ round trip through HBM, no
+        // separate merge kernel)
+        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dq[0], dq[1], dqkv + ((size_t)b * T + q0) * (3 * D) + hh * 64, 3 * D,
+                            qn + (bh * T + q0) * 64, sq + bh * T + q0, lane);
         return;
     }
+    char* wbuf = smem + wave * WT_BYTES;
+    float c0[16], c1[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int qr = acc_row(i, lane);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dqn[(bh * T + q0 + qr) * 64 + 32 * dt + r] = f2bf(dq[dt][i]);
-    }
+    for (int i = 0; i < 16; ++i) { c0[i] = dq[0][i]; c1[i] = dq[1][i]; }
+    store_wave_tile(wbuf, c0, c1, dqn + (bh * T + q0) * 64, 64, lane);
 }
 
 // ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
@@ -292,33 +348,24 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
             }
         }
     }
+    __syncthreads();                                   // Q / dO images are dead: reuse them as store buffers
+    char* wbuf = smem + wave * WT_BYTES;
+    float c0[16], c1[16];
     if (dqkv) {                                        // as in the dQ pass: k section with the normalisation Jacobian, v as is
+        bf16_t* dst = dqkv + ((size_t)b * T + k0) * (3 * D) + D + hh * 64;
+        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dk[0], dk[1], dst, 3 * D, kn + (bh * T + k0) * 64, sk + bh * T + k0, lane);
+        wbuf = smem + wave * WF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const size_t rowg = bh * T + k0 + acc_row(i, lane);
-            const float ka = bf2f(kn[rowg * 64 + r]), kb = bf2f(kn[rowg * 64 + 32 + r]);
-            float dot = dk[0][i] * ka + dk[1][i] * kb;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
-            const float s = sk[rowg], n = 8.f / s - NORM_EPS;
-            const float c = dot / (8.f * fmaxf(n, 1e-30f));
-            bf16_t* dst = dqkv + ((size_t)b * T + k0 + acc_row(i, lane)) * (3 * D) + D + hh * 64;
-            dst[r] = f2bf(s * dk[0][i] - ka * c);
-            dst[32 + r] = f2bf(s * dk[1][i] - kb * c);
-            dst[D + r] = f2bf(dvv[0][i]);
-            dst[D + 32 + r] = f2bf(dvv[1][i]);
-        }
+        for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
+        store_wave_tile(wbuf, c0, c1, dst + D, 3 * D, lane);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int kr = acc_row(i, lane);
+    for (int i = 0; i < 16; ++i) { c0[i] = dk[0][i]; c1[i] = dk[1][i]; }
+    store_wave_tile(wbuf, c0, c1, dkn + (bh * T + k0) * 64, 64, lane);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            dkn[(bh * T + k0 + kr) * 64 + 32 * dt + r] = f2bf(dk[dt][i]);
-            dv[(bh * T + k0 + kr) * 64 + 32 * dt + r] = f2bf(dvv[dt][i]);
-        }
-    }
+    for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
+    store_wave_tile(wbuf, c0, c1, dv + (bh * T + k0) * 64, 64, lane);
 }
 
 }  // namespace
