@@ -71,6 +71,33 @@ __device__ __forceinline__ void stage_both(char* rows_tile, char* tr_tile, const
         }
     }
 }
+// The same staging split into "issue every global load" and "write LDS", so that a kernel can put the loads of all its
+// operands in flight before the first of them is consumed (with one workgroup per CU nothing else hides that latency).
+template <int T, int NTHREADS> struct Staged {
+    static constexpr int N = T * 8 / NTHREADS;             // 16-byte chunks per thread
+    uint4 v[N];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ src, long ld, int tid) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = tid + k * NTHREADS, row = i >> 3, c = i & 7;
+            v[k] = *(const uint4*)(src + (size_t)row * ld + c * 8);
+        }
+    }
+    __device__ __forceinline__ void store(char* rows_tile, char* tr_tile, int tid) const {
+        constexpr int VLD = 2 * T + 8;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = tid + k * NTHREADS, row = i >> 3, c = i & 7;
+            if (rows_tile) *(uint4*)(rows_tile + row * 128 + ((c ^ (row & 7)) << 4)) = v[k];
+            if (tr_tile) {
+                const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *(bf16_t*)(tr_tile + (8 * c + e) * VLD + row * 2) = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    }
+};
 // B-operand fragment whose k order matches pack8() of an accumulator tile:
 // element j of lane (r, h) is [d = d0 + r][k = kbase + 8 (j >> 2) + 4 h + (j & 3)].
 template <int T>
@@ -175,11 +202,14 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     const int r = lane & 31, h2 = lane >> 5;
     const size_t bh = blockIdx.y;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
-    stage_rows<G::NTH>(ks_, kn + bh * T * 64, 64, T, tid);
-    stage_both<T, G::NTH>(nullptr, vs_, v + bh * T * 64, 64, tid);
+    Staged<T, G::NTH> sk_, sv_;
+    sk_.load(kn + bh * T * 64, 64, tid);
+    sv_.load(v + bh * T * 64, 64, tid);
     bf16x8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
+    sk_.store(ks_, nullptr, tid);
+    sv_.store(nullptr, vs_, tid);
     __syncthreads();
 
     // one pass over the keys: cosine logits are bounded (|q^.k^| / 8 <= 8), so exp() needs no running maximum and every
@@ -235,8 +265,9 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
-    stage_both<T, G::NTH>(ks_, kts_, kn + bh * T * 64, 64, tid);
-    stage_rows<G::NTH>(vs_, v + bh * T * 64, 64, T, tid);
+    Staged<T, G::NTH> sk_, sv_;
+    sk_.load(kn + bh * T * 64, 64, tid);
+    sv_.load(v + bh * T * 64, 64, tid);
     bf16x8_t qf[4], dof[4];
     float del_p = 0.f;                      // delta_q = rowsum(dO * O): this lane's 32 of the 64 features
 #pragma unroll
@@ -248,9 +279,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
         for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
     }
+    const float lse_q = lse[bh * T + q0 + r];
+    sk_.store(ks_, kts_, tid);
+    sv_.store(vs_, nullptr, tid);
     const float del_q = del_p + __shfl_xor(del_p, 32, 64);
     if (h2 == 0) delta[bh * T + q0 + r] = del_q;       // consumed by the dK/dV pass (launched after this kernel)
-    const float lse_q = lse[bh * T + q0 + r];
     __syncthreads();
 
     f32x16_t dq[2] = {};
@@ -311,15 +344,18 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int k0 = blockIdx.x * 32 * G::NW + wave * 32;
-    stage_both<T, G::NTH>(qs_, qts_, qn + bh * T * 64, 64, tid);
-    stage_both<T, G::NTH>(dos_, dots_, dO + (size_t)b * T * D + hh * 64, D, tid);
-    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
+    Staged<T, G::NTH> sq_, sdo_;
+    sq_.load(qn + bh * T * 64, 64, tid);
+    sdo_.load(dO + (size_t)b * T * D + hh * 64, D, tid);
     bf16x8_t kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         kf[ks] = *(const bf16x8_t*)(kn + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
         vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
     }
+    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
+    sq_.store(qs_, qts_, tid);
+    sdo_.store(dos_, dots_, tid);
     __syncthreads();
 
     f32x16_t dk[2] = {}, dvv[2] = {};
