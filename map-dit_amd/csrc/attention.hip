@@ -15,6 +15,8 @@
 // (16-byte global loads, 2-byte transposed LDS stores), so HBM holds each head tensor once, row-major.
 // The backward is two passes (7 products instead of 5) so no cross-wave reduction and no atomics are needed:
 // attention is ~5 % of the block's FLOPs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -28,51 +30,16 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
     return r.v;
 }
 
-// Row-major [rows][64] bf16 tile in LDS, 128-B rows, 16-B chunks XOR-swizzled by (row & 7).
-template <int NTHREADS>
-__device__ __forceinline__ void stage_rows(char* tile, const bf16_t* __restrict__ src, long ld, int rows, int tid) {
-    for (int i = tid; i < rows * 8; i += NTHREADS) {
-        const int row = i >> 3, c = i & 7;
-        uint4 v = *(const uint4*)(src + (size_t)row * ld + c * 8);
-        *(uint4*)(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-    }
-}
+// Row-major [rows][64] bf16 tiles in LDS have 128-B rows with 16-B chunks XOR-swizzled by (row & 7).
 // A-operand fragment of 32x32x16: lane (r, h) holds [row0 + r][16 ks + 8 h + 0..7].
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int ks, int lane) {
     const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
     return *(const bf16x8_t*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
 }
-// Transposed image [64 d][T] bf16 in LDS with rows padded to 2T+8 bytes (conflict-free 8-byte column reads).
-template <int T, int NTHREADS>
-__device__ __forceinline__ void stage_tr(char* tile, const bf16_t* __restrict__ src, int tid) {
-    constexpr int VLD = 2 * T + 8, VC = T / 8;
-    for (int i = tid; i < 64 * VC; i += NTHREADS) {
-        const int row = i / VC, c = i % VC;
-        uint4 v = *(const uint4*)(src + (size_t)row * T + c * 8);
-        uint2* d = (uint2*)(tile + row * VLD + c * 16);
-        d[0] = make_uint2(v.x, v.y);
-        d[1] = make_uint2(v.z, v.w);
-    }
-}
-// Row-major global [rows = T][64] (row stride ld) -> row-major swizzled LDS tile (may be null) and/or the transposed
-// LDS image [64 d][T] (may be null), in one pass over the data.
-template <int T, int NTHREADS>
-__device__ __forceinline__ void stage_both(char* rows_tile, char* tr_tile, const bf16_t* __restrict__ src, long ld, int tid) {
-    constexpr int VLD = 2 * T + 8;
-    for (int i = tid; i < T * 8; i += NTHREADS) {
-        const int row = i >> 3, c = i & 7;
-        const uint4 v = *(const uint4*)(src + (size_t)row * ld + c * 8);
-        if (rows_tile) *(uint4*)(rows_tile + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-        if (tr_tile) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *(bf16_t*)(tr_tile + (8 * c + e) * VLD + row * 2) = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
-        }
-    }
-}
-// The same staging split into "issue every global load" and "write LDS", so that a kernel can put the loads of all its
-// operands in flight before the first of them is consumed (with one workgroup per CU nothing else hides that latency).
+// Staging of one head's [T][64] operand (row stride ld in HBM) into LDS: row-major swizzled tile (may be null) and/or the
+// transposed image [64 d][T] with rows padded to 2T+8 bytes (conflict-free 8-byte column reads; may be null), split into
+// "issue every global load" and "write LDS" so that a kernel can put the loads of all its operands in flight before the first
+// of them is consumed (with one workgroup per CU nothing else hides that latency).
 template <int T, int NTHREADS> struct Staged {
     static constexpr int N = T * 8 / NTHREADS;             // 16-byte chunks per thread
     uint4 v[N];
@@ -420,10 +387,20 @@ extern "C" int mapdit_attn_generic_bwd(const uint16_t*, const uint16_t*, const u
                                        const float*, float*, uint16_t*, uint16_t*, uint16_t*, int, int, int, int, void*);
 
 static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 || T == 128 || T == 256); }
+// head_dim 72 (DiT-XL): MFMA kernels of attention72.hip; an escape hatch keeps the generic path reachable for A/B runs
+int mapdit_attn72_fwd(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
+int mapdit_attn72_bwd(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
+                      uint16_t*, uint16_t*, uint16_t*, int, int, int, void*);
+static bool mfma72_shape(int T, int head_dim) {
+    if (head_dim != 72 || !(T == 64 || T == 128 || T == 256)) return false;
+    const char* e = getenv("MAPDIT_ATTN72");
+    return !(e && e[0] == '0');
+}
 
 extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse,
                                    int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && o && lse, "attn_cos_fwd: null argument");
+    if (mfma72_shape(T, head_dim)) return mapdit_attn72_fwd(qn, kn, v, o, lse, B, T, H, stream);
     if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_fwd(qn, kn, v, o, lse, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
@@ -437,6 +414,7 @@ extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const
                                    const uint16_t* O, const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn,
                                    uint16_t* dv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && dqn && dkn && dv, "attn_cos_bwd: null argument");
+    if (mfma72_shape(T, head_dim)) return mapdit_attn72_bwd(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, stream);
     if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_bwd(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,490 @@
+// Cosine attention forward/backward for head_dim 72 (the DiT-XL family: 1152 / 16 heads) on v_mfma_f32_32x32x16_bf16.
+// Same mathematics, same register-resident product chain and same two-pass backward as attention.hip (head_dim 64);
+// what changes is the geometry:
+//   * reductions over the head dimension (S = Q K^T, dP = dO V^T) run 5 k-steps of 16 = 80 columns; columns 72..79 are
+//     ZERO on both sides (zero chunk in the LDS rows, zero-filled register fragments);
+//   * products with the head dimension on the output side (O, dQ, dK, dV) run 3 tiles of 32 = 96 columns; columns 72..95
+//     come from unwritten LDS rows and are simply not stored;
+//   * row-major LDS tiles use a 176-byte row stride (11 x 16-byte chunks: an odd chunk count makes the 16-lane groups of a
+//     ds_read_b128 conflict-free without a swizzle): chunks 0..8 data, chunk 9 zeros;
+//   * the dK/dV pass cannot hold Q, dO and both transposed images of all 256 queries in 160 KiB, so it keeps the row-major
+//     tiles whole and builds the transposed images for half of the queries at a time (the second half from the LDS rows).
+// Layouts: qn, kn, v, dqn, dkn, dv [B*H][T][72] bf16; o, dO [B*T][H*72] bf16; lse, delta [B*H][T] fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 72, CH = 9;                 // valid columns, 16-byte chunks per row
+constexpr int KS = 5, DT = 3;                  // k-steps over the head dim (80), 32-column output tiles (96)
+constexpr int RS = 176;                        // row stride of row-major LDS tiles (bytes)
+constexpr int IMG_ROWS = 96;                   // rows a transposed image is read at (72 written)
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
+    union { uint32_t u[4]; bf16x8_t v; } r;
+    r.u[0] = pack2bf(a[base + 0], a[base + 1]);
+    r.u[1] = pack2bf(a[base + 2], a[base + 3]);
+    r.u[2] = pack2bf(a[base + 4], a[base + 5]);
+    r.u[3] = pack2bf(a[base + 6], a[base + 7]);
+    return r.v;
+}
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// A-operand fragment of 32x32x16 from a row-major tile: lane (r, h) holds [row0 + r][16 ks + 8 h + 0..7].
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int ks, int lane) {
+    return *(const bf16x8_t*)(tile + (row0 + (lane & 31)) * RS + ((2 * ks + (lane >> 5)) << 4));
+}
+// B-operand fragment from a transposed image [d][TC] (row stride 2 TC + 8 bytes) in the k order of pack8():
+// element j of lane (r, h) is [d = d0 + r][k = kbase + 8 (j >> 2) + 4 h + (j & 3)].
+template <int TC>
+__device__ __forceinline__ bf16x8_t frag_tr(const char* img, int d0, int kbase, int lane) {
+    constexpr int VLD = 2 * TC + 8;
+    const char* p = img + (d0 + (lane & 31)) * VLD + (kbase + 4 * (lane >> 5)) * 2;
+    union { uint2 u[2]; bf16x8_t v; } r;
+    r.u[0] = *(const uint2*)p;
+    r.u[1] = *(const uint2*)(p + 16);
+    return r.v;
+}
+// Register fragment of one row of a [.][72] tensor: columns 16 ks + 8 h .. + 7, zero beyond column 71.
+__device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ row, int ks, int h2) {
+    const int c = 16 * ks + 8 * h2;
+    if (c < HD) return *(const bf16x8_t*)(row + c);
+    return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+// One head's [T][72] operand: all global loads first, LDS writes later (see attention.hip).
+template <int T, int NTHREADS> struct Staged {
+    static constexpr int TOTAL = T * CH;
+    static constexpr int N = (TOTAL + NTHREADS - 1) / NTHREADS;
+    uint4 v[N];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ src, long ld, int tid) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = tid + k * NTHREADS;
+            if (i < TOTAL) {
+                const int row = i / CH, c = i - row * CH;
+                v[k] = *(const uint4*)(src + (size_t)row * ld + c * 8);
+            }
+        }
+    }
+    // rows_tile: row-major tile (may be null); img: transposed image of rows [row_base, row_base + TC) (may be null)
+    template <int TC>
+    __device__ __forceinline__ void store(char* rows_tile, char* img, int row_base, int tid) const {
+        constexpr int VLD = 2 * TC + 8;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = tid + k * NTHREADS;
+            if (i < TOTAL) {
+                const int row = i / CH, c = i - row * CH;
+                if (rows_tile) {
+                    *(uint4*)(rows_tile + row * RS + c * 16) = v[k];
+                    if (c == CH - 1) *(uint4*)(rows_tile + row * RS + CH * 16) = make_uint4(0, 0, 0, 0);   // columns 72..79
+                }
+                if (img && row >= row_base && row < row_base + TC) {
+                    const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        *(bf16_t*)(img + (8 * c + e) * VLD + (row - row_base) * 2) = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+                }
+            }
+        }
+    }
+};
+// Rebuild a transposed image of rows [row_base, row_base + TC) from the row-major LDS tile.
+template <int TC, int NTHREADS>
+__device__ __forceinline__ void image_from_rows(const char* rows_tile, char* img, int row_base, int tid) {
+    constexpr int VLD = 2 * TC + 8;
+    for (int i = tid; i < TC * CH; i += NTHREADS) {
+        const int row = i / CH, c = i - row * CH;
+        const uint4 v = *(const uint4*)(rows_tile + (row_base + row) * RS + c * 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(bf16_t*)(img + (8 * c + e) * VLD + row * 2) = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+    }
+}
+
+// A wave's 32 x 72 result tile (three accumulator tiles: columns r, 32 + r, 64 + r < 72) leaves through a private LDS buffer
+// as 16-byte row chunks.  gdst = address of the tile's [0][0], row stride ld elements.
+constexpr int WT_LD = 152;                     // bytes per buffered row (38 dwords)
+constexpr int WT_BYTES = 32 * WT_LD;
+__device__ __forceinline__ void store_wave_tile(char* wbuf, const f32x16_t (&acc)[DT], const float (&rs)[16], bf16_t* gdst, size_t ld,
+                                                int lane) {
+    const int r = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        char* row = wbuf + acc_row(i, lane) * WT_LD;
+        *(bf16_t*)(row + 2 * r) = f2bf(acc[0][i] * rs[i]);
+        *(bf16_t*)(row + 64 + 2 * r) = f2bf(acc[1][i] * rs[i]);
+        if (r < HD - 64) *(bf16_t*)(row + 128 + 2 * r) = f2bf(acc[2][i] * rs[i]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int id = lane + 64 * k;
+        if (id < 32 * CH) {
+            const int row = id / CH, c = id - row * CH;
+            const uint2 lo = *(const uint2*)(wbuf + row * WT_LD + c * 16);
+            const uint2 hi = *(const uint2*)(wbuf + row * WT_LD + c * 16 + 8);
+            *(uint4*)(gdst + (size_t)row * ld + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int T> struct Geo {
+    static constexpr int NW = T / 32;          // waves = 32-row owner groups; one workgroup per head
+    static constexpr int NTH = NW * 64;
+    static constexpr int NT = T / 32;
+    static constexpr int VLD = 2 * T + 8;
+    static constexpr int HALVES = T > 128 ? 2 : 1;      // dK/dV pass: transposed images of T / HALVES queries at a time
+    static constexpr int TH = T / HALVES;
+    static constexpr int VLDH = 2 * TH + 8;
+};
+
+// ---- forward -----------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+                                                                float* __restrict__ lse, int H, float scale) {
+    using G = Geo<T>;
+    constexpr int SM = T * RS + IMG_ROWS * G::VLD;
+    __shared__ __attribute__((aligned(16))) char smem[SM > G::NW * WT_BYTES ? SM : G::NW * WT_BYTES];
+    char* ks_ = smem;
+    char* vts_ = smem + T * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.x;
+    const int q0 = wave * 32;
+    Staged<T, G::NTH> sk_, sv_;
+    sk_.load(kn + bh * T * HD, HD, tid);
+    sv_.load(v + bh * T * HD, HD, tid);
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(qn + (bh * T + q0 + r) * HD, ks, h2);
+    sk_.template store<T>(ks_, nullptr, 0, tid);
+    sv_.template store<T>(nullptr, vts_, 0, tid);
+    __syncthreads();
+
+    f32x16_t oa[DT] = {};
+    float lsum = 0.f;
+#pragma unroll 2
+    for (int kt = 0; kt < G::NT; ++kt) {
+        f32x16_t a = {};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pa = pack8(a, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(vts_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const int b = (int)(bh / H), hh = (int)(bh % H);
+    const int D = H * HD;
+    const float inv_l = 1.f / lsum;
+    float rs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rs[i] = __shfl(inv_l, acc_row(i, lane), 64);
+    __syncthreads();                                   // K / V images are dead: reuse them as store buffers
+    store_wave_tile(smem + wave * WT_BYTES, oa, rs, o + ((size_t)b * T + q0) * D + hh * HD, D, lane);
+    if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
+}
+
+// ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                   const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                                   const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                                   float* __restrict__ delta, bf16_t* __restrict__ dqn, int H,
+                                                                   float scale) {
+    using G = Geo<T>;
+    constexpr int SM = 2 * T * RS + IMG_ROWS * G::VLD;
+    __shared__ __attribute__((aligned(16))) char smem[SM > G::NW * WT_BYTES ? SM : G::NW * WT_BYTES];
+    char* ks_ = smem;
+    char* vs_ = smem + T * RS;
+    char* kts_ = smem + 2 * T * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.x;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * HD;
+    const int q0 = wave * 32;
+    Staged<T, G::NTH> sk_, sv_;
+    sk_.load(kn + bh * T * HD, HD, tid);
+    sv_.load(v + bh * T * HD, HD, tid);
+    bf16x8_t qf[KS], dof[KS];
+    float del_p = 0.f;                      // delta_q = rowsum(dO * O): this lane's share of the 72 features
+    const bf16_t* dorow = dO + ((size_t)b * T + q0 + r) * D + hh * HD;
+    const bf16_t* orow = O + ((size_t)b * T + q0 + r) * D + hh * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = frag_global(qn + (bh * T + q0 + r) * HD, ks, h2);
+        dof[ks] = frag_global(dorow, ks, h2);
+        const bf16x8_t of = frag_global(orow, ks, h2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+    }
+    const float lse_q = lse[bh * T + q0 + r];
+    sk_.template store<T>(ks_, kts_, 0, tid);
+    sv_.template store<T>(vs_, nullptr, 0, tid);
+    const float del_q = del_p + __shfl_xor(del_p, 32, 64);
+    if (h2 == 0) delta[bh * T + q0 + r] = del_q;       // consumed by the dK/dV pass (launched after this kernel)
+    __syncthreads();
+
+    f32x16_t dq[DT] = {};
+#pragma unroll 1
+    for (int kt = 0; kt < G::NT; ++kt) {
+        f32x16_t st = {}, dp = {};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __expf(st[i] * scale - lse_q);
+            st[i] = p * (dp[i] - del_q) * scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t a = pack8(st, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
+        }
+    }
+    float one[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) one[i] = 1.f;
+    __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
+    store_wave_tile(smem + wave * WT_BYTES, dq, one, dqn + (bh * T + q0) * HD, HD, lane);
+}
+
+// ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dkv_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                    const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
+                                                                    float scale) {
+    using G = Geo<T>;
+    constexpr int IMG = IMG_ROWS * G::VLDH;
+    __shared__ __attribute__((aligned(16))) char smem[2 * T * RS + 2 * IMG + 2 * T * 4];
+    char* qs_ = smem;
+    char* dos_ = smem + T * RS;
+    char* qts_ = smem + 2 * T * RS;
+    char* dots_ = qts_ + IMG;
+    float* lse_s = (float*)(dots_ + IMG);
+    float* del_s = lse_s + T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.x;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * HD;
+    const int k0 = wave * 32;
+    Staged<T, G::NTH> sq_, sdo_;
+    sq_.load(qn + bh * T * HD, HD, tid);
+    sdo_.load(dO + (size_t)b * T * D + hh * HD, D, tid);
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = frag_global(kn + (bh * T + k0 + r) * HD, ks, h2);
+        vf[ks] = frag_global(v + (bh * T + k0 + r) * HD, ks, h2);
+    }
+    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
+    sq_.template store<G::TH>(qs_, qts_, 0, tid);
+    sdo_.template store<G::TH>(dos_, dots_, 0, tid);
+    __syncthreads();
+
+    f32x16_t dk[DT] = {}, dvv[DT] = {};
+#pragma unroll 1
+    for (int half = 0; half < G::HALVES; ++half) {
+        if (half > 0) {                                // second half of the queries: rebuild both images from the LDS rows
+            __syncthreads();
+            image_from_rows<G::TH, G::NTH>(qs_, qts_, half * G::TH, tid);
+            image_from_rows<G::TH, G::NTH>(dos_, dots_, half * G::TH, tid);
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int qh = 0; qh < G::NT / G::HALVES; ++qh) {
+            const int qt = half * (G::NT / G::HALVES) + qh;
+            f32x16_t s = {}, dp = {};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qr = 32 * qt + acc_row(i, lane);
+                const float p = __expf(s[i] * scale - lse_s[qr]);
+                s[i] = p;
+                dp[i] = p * (dp[i] - del_s[qr]) * scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dvv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<G::TH>(dots_, 32 * dt, 32 * qh + 16 * s2, lane), dvv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<G::TH>(qts_, 32 * dt, 32 * qh + 16 * s2, lane), dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float one[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) one[i] = 1.f;
+    __syncthreads();                                   // Q / dO tiles are dead: reuse them as store buffers
+    char* wbuf = smem + wave * WT_BYTES;
+    store_wave_tile(wbuf, dk, one, dkn + (bh * T + k0) * HD, HD, lane);
+    store_wave_tile(wbuf, dvv, one, dv + (bh * T + k0) * HD, HD, lane);
+}
+
+// ---- head split / merge around the attention for head_dim 72 ---------------------------------------------------------
+// One thread per 16-byte chunk: thread (which, head, c) of a token row, so consecutive threads touch consecutive 16 bytes of
+// qkv [M, 3D] and 9 consecutive threads write one 144-byte row of the head-major tensors.  The per-(token, head) reductions
+// (sum of squares; q . dq^) go through LDS.  TOK tokens per workgroup.
+constexpr int TOK = 8;
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8f(const float* f) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+__global__ void qkv_split72_kernel(const bf16_t* __restrict__ qkv, int M, int T, int H, bf16_t* __restrict__ qn,
+                                   bf16_t* __restrict__ kn, bf16_t* __restrict__ v) {
+    extern __shared__ float red[];                     // [3 * H * 9]
+    const int per = H * CH, tid = threadIdx.x;
+    const bool live = tid < 3 * per;
+    const int which = live ? tid / per : 0, rem = tid - which * per, h = rem / CH, c = rem - h * CH;
+    const int D = H * HD;
+    const float rt = sqrtf((float)HD);
+    for (int j = 0; j < TOK; ++j) {
+        const int m = blockIdx.x * TOK + j;
+        if (m >= M) break;                             // uniform over the workgroup
+        float f[8];
+        if (live) {
+            unpack8(*(const uint4*)(qkv + (size_t)m * 3 * D + which * D + h * HD + c * 8), f);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+            red[tid] = ss;
+        }
+        __syncthreads();
+        if (live) {
+            if (which < 2) {
+                float tot = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) tot += red[which * per + h * CH + i];
+                const float sc = rt / (sqrtf(tot) + NORM_EPS);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] *= sc;
+            }
+            const int b = m / T, t = m - b * T;
+            bf16_t* dst = (which == 0 ? qn : which == 1 ? kn : v) + (((size_t)b * H + h) * T + t) * HD + c * 8;
+            *(uint4*)dst = pack8f(f);
+        }
+        __syncthreads();
+    }
+}
+
+// dqn, dkn, dv + saved qkv -> dqkv [M, 3D]:  dq = s (dq^ - q (dq^ . q) / (n (n + eps))),  s = sqrt(72) / (n + eps).
+__global__ void qkv_merge72_kernel(const bf16_t* __restrict__ qkv, int M, int T, int H, const bf16_t* __restrict__ dqn,
+                                   const bf16_t* __restrict__ dkn, const bf16_t* __restrict__ dv, bf16_t* __restrict__ dqkv) {
+    extern __shared__ float red[];                     // [2][3 * H * 9]: sum of squares, dot products
+    const int per = H * CH, tid = threadIdx.x;
+    const bool live = tid < 3 * per;
+    const int which = live ? tid / per : 0, rem = tid - which * per, h = rem / CH, c = rem - h * CH;
+    const int D = H * HD;
+    const float rt = sqrtf((float)HD);
+    float* red2 = red + 3 * per;
+    for (int j = 0; j < TOK; ++j) {
+        const int m = blockIdx.x * TOK + j;
+        if (m >= M) break;
+        const int b = m / T, t = m - b * T;
+        const size_t moff = (size_t)m * 3 * D + which * D + h * HD + c * 8;
+        float x[8], g[8];
+        if (live) {
+            const bf16_t* gp = (which == 0 ? dqn : which == 1 ? dkn : dv) + (((size_t)b * H + h) * T + t) * HD + c * 8;
+            unpack8(*(const uint4*)gp, g);
+            if (which < 2) {
+                unpack8(*(const uint4*)(qkv + moff), x);
+                float ss = 0.f, dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { ss += x[i] * x[i]; dot += x[i] * g[i]; }
+                red[tid] = ss;
+                red2[tid] = dot;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            if (which < 2) {
+                float ss = 0.f, dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { ss += red[which * per + h * CH + i]; dot += red2[which * per + h * CH + i]; }
+                const float n = sqrtf(ss), sc = rt / (n + NORM_EPS), cc = dot / (fmaxf(n, 1e-30f) * (n + NORM_EPS));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = sc * (g[i] - x[i] * cc);
+            }
+            *(uint4*)(dqkv + moff) = pack8f(g);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int mapdit_qkv_split72(const uint16_t* qkv, int B, int T, int H, uint16_t* qn, uint16_t* kn, uint16_t* v, void* stream) {
+    const int threads = (3 * H * CH + 63) / 64 * 64, M = B * T;
+    MD_CHECK(threads <= 1024, "qkv_split (head_dim 72): %d heads unsupported (<= 37)", H);
+    hipLaunchKernelGGL(qkv_split72_kernel, dim3((M + TOK - 1) / TOK), dim3(threads), 3 * H * CH * sizeof(float), (hipStream_t)stream, qkv,
+                       M, T, H, qn, kn, v);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+int mapdit_qkv_merge_bwd72(const uint16_t* qkv, int B, int T, int H, const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv,
+                           uint16_t* dqkv, void* stream) {
+    const int threads = (3 * H * CH + 63) / 64 * 64, M = B * T;
+    MD_CHECK(threads <= 1024, "qkv_merge_bwd (head_dim 72): %d heads unsupported (<= 37)", H);
+    hipLaunchKernelGGL(qkv_merge72_kernel, dim3((M + TOK - 1) / TOK), dim3(threads), 2 * 3 * H * CH * sizeof(float), (hipStream_t)stream,
+                       qkv, M, T, H, dqn, dkn, dv, dqkv);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+#define ATTN72_DISPATCH(T_, CALL)                                                       \
+    switch (T_) {                                                                       \
+        case 64: { constexpr int TT = 64; CALL; break; }                                \
+        case 128: { constexpr int TT = 128; CALL; break; }                              \
+        case 256: { constexpr int TT = 256; CALL; break; }                              \
+        default: mapdit_set_error("attention72: T=%d unsupported (64, 128, 256)", T_); return MAPDIT_ERR_ARG; \
+    }
+
+// Internal entry points (dispatched to from mapdit_attn_cos_fwd / _bwd for head_dim 72).
+int mapdit_attn72_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                      void* stream) {
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, o, lse, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+int mapdit_attn72_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                      const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H, void* stream) {
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_bwd_dq_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, dO, O, lse,
+                                          delta, dqn, H, scale));
+    MD_LAUNCH_CHECK();
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_bwd_dkv_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, dO, lse,
+                                          delta, dkn, dv, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}

@@ -296,9 +296,14 @@ extern "C" int mapdit_qkv_split_generic(const uint16_t*, int, int, int, int, uin
 extern "C" int mapdit_qkv_merge_bwd_generic(const uint16_t*, int, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*,
                                             uint16_t*, void*);
 
+// head_dim 72 (DiT-XL): coalesced chunk-per-thread kernels of attention72.hip
+int mapdit_qkv_split72(const uint16_t*, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
+int mapdit_qkv_merge_bwd72(const uint16_t*, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, void*);
+
 extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
                                 uint16_t* v, void* stream) {
     MD_CHECK(qkv && qn && kn && v, "qkv_split: null argument");
+    if (head_dim == 72 && H <= 37) return mapdit_qkv_split72(qkv, B, T, H, qn, kn, v, stream);
     if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_split_generic(qkv, B, T, H, head_dim, qn, kn, v, stream);
     hipLaunchKernelGGL(qkv_split_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, qn, kn, v);
     MD_LAUNCH_CHECK();
@@ -308,6 +313,7 @@ extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int he
 extern "C" int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
                                     const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream) {
     MD_CHECK(qkv && dqn && dkn && dv && dqkv, "qkv_merge_bwd: null argument");
+    if (head_dim == 72 && H <= 37) return mapdit_qkv_merge_bwd72(qkv, B, T, H, dqn, dkn, dv, dqkv, stream);
     if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_merge_bwd_generic(qkv, B, T, H, head_dim, dqn, dkn, dv, dqkv, stream);
     hipLaunchKernelGGL(qkv_merge_bwd_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, dqn, dkn, dv, dqkv);
     MD_LAUNCH_CHECK();

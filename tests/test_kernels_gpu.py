@@ -424,6 +424,59 @@ def test_generic_attention_fwd_bwd(L, B, T, H, hd):
     assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2
 
 
+@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (1, 128, 3), (2, 256, 2), (1, 256, 16)])
+def test_attention_head_dim_72_mfma(L, B, T, H):
+    """DiT-XL's head_dim 72 on the MFMA kernels (attention72.hip; zero-padded to 80 on the reduction side, 96 on the output
+    side) through the public entry points: against autograd over the oracle ops AND against the generic fp32 kernels on
+    the same bf16 inputs (same rounding points, so the two agree much tighter than either agrees with fp32 autograd)."""
+    from oracle.dit_oracle import normalize
+    hd = 72
+    D = H * hd
+    qkv = bf16_exact(B * T, 3 * D, seed=40)
+    dO = bf16_exact(B * T, D, seed=41)
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, hd).transpose(1, 2)
+    qn, kn = normalize(sp(q)), normalize(sp(k))
+    att = torch.softmax(qn @ kn.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ sp(v)
+    o_ref = att.transpose(1, 2).reshape(B * T, D)
+    o_ref.backward(dO)
+    mk = lambda *s: torch.full(s, float("nan"), device=DEV, dtype=torch.bfloat16)      # NaN-filled: every element must be written
+    qkvd, dOd = to_bf(qkv), to_bf(dO)
+    qn_d, kn_d, v_d = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    lib = L.lib()
+    lib.qkv_split(p(qkvd), B, T, H, hd, p(qn_d), p(kn_d), p(v_d), st())
+    outs = {}
+    for path in ("mfma", "generic"):
+        o_d = mk(B * T, D)
+        lse = torch.full((B * H, T), float("nan"), device=DEV)
+        delta = torch.full((B * H, T), float("nan"), device=DEV)
+        dqn, dkn, dv, dqkv = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd), mk(B * T, 3 * D)
+        if path == "mfma":
+            lib.attn_cos_fwd(p(qn_d), p(kn_d), p(v_d), p(o_d), p(lse), B, T, H, hd, st())
+            lib.attn_cos_bwd(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(dqn), p(dkn), p(dv), B, T, H, hd, st())
+        else:
+            lib.attn_generic_fwd(p(qn_d), p(kn_d), p(v_d), p(o_d), p(lse), B, T, H, hd, st())
+            lib.attn_generic_bwd(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(dqn), p(dkn), p(dv), B, T, H, hd, st())
+        lib.qkv_merge_bwd(p(qkvd), B, T, H, hd, p(dqn), p(dkn), p(dv), p(dqkv), st())
+        torch.cuda.synchronize()
+        outs[path] = tuple(t.float().cpu() for t in (o_d, lse, delta, dqn, dkn, dv, dqkv))
+        for t in outs[path]:
+            assert torch.isfinite(t).all()
+    o_d, lse, delta, dqn, dkn, dv, dqkv = outs["mfma"]
+    assert rel_err(o_d.numpy(), o_ref.detach().numpy()) < 1e-2
+    got, ref = dqkv.view(B * T, 3, D), leaf.grad.view(B * T, 3, D)
+    assert rel_err(got[:, 2].numpy(), ref[:, 2].numpy()) < 1.5e-2
+    assert rel_err(got[:, 0].numpy(), ref[:, 0].numpy()) < 3e-2
+    assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2
+    g = outs["generic"]
+    assert rel_err(lse.numpy(), g[1].numpy()) < 1e-5
+    assert rel_err(delta.numpy(), g[2].numpy()) < 1e-2                     # delta = rowsum(dO * O) of each path's own O
+    assert rel_err(o_d.numpy(), g[0].numpy()) < 6e-3                       # MFMA rounds P to bf16, the generic path does not
+    for a, b_ in zip((dqn, dkn, dv), g[3:6]):
+        assert rel_err(a.numpy(), b_.numpy()) < 1.2e-2
+
+
 def test_attention_exact_small_integers(L):
     """Uniform attention (all logits equal) with integer V: O must be the exact key-mean of V."""
     B, T, H = 1, 64, 1
