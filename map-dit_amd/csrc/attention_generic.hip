@@ -1,8 +1,7 @@
-// Generic cosine attention for the head sizes the MFMA kernels do not take (DiT-XL: head_dim 72; patch-8 models:
-// 16 tokens).  Same maths and interfaces as attention.hip / the head-split kernels, on the fp32 VALU: one thread owns
-// one query row (forward, dQ) or one key row (dK, dV) of a head and sweeps the other index with the head's K, V (or
-// Q, dO) rows broadcast from LDS.  Attention is ~5 % of a block's FLOPs, so this path costs XL roughly +35 % step
-// time; an MFMA path with head_dim padded to 80 is the planned replacement.
+// Generic cosine attention for the shapes the MFMA kernels do not take (patch-8 models: 16 tokens; any head_dim <= 96 that is
+// neither 64 nor 72).  Same maths and interfaces as attention.hip / attention72.hip, on the fp32 VALU: one thread owns one
+// query row (forward, dQ) or one key row (dK, dV) of a head and sweeps the other index with the head's K, V (or Q, dO) rows
+// broadcast from LDS.  Also the reference implementation the head_dim-72 MFMA kernels are tested against.
 // Layout: qn, kn, v, dqn, dkn, dv  [B*H][T][hd] bf16 (no padding); o, dO [B*T][H*hd] bf16; lse, delta [B*H][T] fp32.
 #include "common.h"
 
