@@ -73,6 +73,19 @@ def cpu_baseline(model_name: str, batch: int, steps: int):
                       f"torch {torch.__version__}, {dt / steps:.2f} s/step"}
 
 
+def pmc_traffic(model, batch):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
+    guide's gfx950 correction + WRITE_SIZE; profiles/r01_fc1_pmc_traffic.json).  The counters cannot be collected from
+    inside this process; they hold for the kernel and shape they were taken on (DiT-B/2, 256 samples) and are null otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fc1_pmc_traffic.json")
+    if model != "DiT-B/2" or batch != 256 or not os.path.exists(path):
+        return {"traffic": None}
+    with open(path) as f:
+        d = json.load(f)
+    return {"traffic": d["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+            "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": "profiles/r01_fc1_pmc_traffic.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +180,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_mfma256_kernel<0, 0, EpiSilu2<0>> (NT, block-MLP fc1: "
                                                   f"[{B * T},{D}]x[{Hm},{D}]^T)",
                      "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, "traffic": None,
+                     "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, **pmc_traffic(args.model, B),
                      "launches_timed": cnt.value, "avg_launch_ms": fc1_ms, "flops_per_launch": fc1_flops},
     }
     if rank == 0:

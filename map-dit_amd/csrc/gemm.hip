@@ -101,10 +101,16 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, 
 
 // ---- epilogues ----------------------------------------------------------------------------------------
 // operator()(m, n, v): v[0..7] are C[m][n..n+7]; n is a multiple of 8 and the chunk is fully in range.
+// Epilogue outputs are streams far larger than the L2 that nothing re-reads soon: non-temporal stores (`nt`) so that the
+// output stream is first in line for eviction and does not push out the operand panels the XCD's other workgroups still read.
+// (An `sc1` write-through store, which does not keep the line in L2 at all, was 5 % faster still but let a following kernel
+// read stale contents of a reused buffer now and then, even behind s_waitcnt vmcnt(0): not used.)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ void store16_stream(void* p, u32x4_t v) { __builtin_nontemporal_store(v, (u32x4_t*)p); }
 __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
-    uint4 u;
+    u32x4_t u;
     u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
-    *(uint4*)p = u;
+    store16_stream(p, u);
 }
 __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {
     uint4 u = *(const uint4*)p;
