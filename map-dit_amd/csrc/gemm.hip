@@ -112,8 +112,8 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
     u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
     store16_stream(p, u);
 }
-__device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {
-    uint4 u = *(const uint4*)p;
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // read-once stream (epilogue operand): nt
+    const u32x4_t u = __builtin_nontemporal_load((const u32x4_t*)p);
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
     v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
