@@ -89,6 +89,17 @@ int mapdit_gemm_tile_size(int M, int N);
  * ------------------------------------------------------------------------------------------------------------ */
 int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16, float* w_f32,
                           float* inv, void* stream);
+/* The same pass for many weights in one launch (the engine's per-step re-imaging of every linear: ~70 weights).  jobs_dev is a
+ * DEVICE array; first_block = number of 4-row workgroups of all earlier jobs; total_blocks = their sum over all jobs. */
+typedef struct {
+    float* W;
+    int rows, cols;
+    float out_scale;
+    int first_block;
+    uint16_t* w_bf16; /* may be NULL */
+    float* w_f32;     /* may be NULL */
+} mapdit_wn_job_t;
+int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream);
 /* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)).  G rows have stride ldg; G may be
  * given as nslabs partial sums slab_stride elements apart (split-K GEMM output), added here in a fixed order.
  * G is scratch: with nslabs > 1 its slab 0 is overwritten with the sum. */

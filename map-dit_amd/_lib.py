@@ -34,6 +34,10 @@ class ResidModBwd(C.Structure):
                 ("n_samples", ci), ("T", ci), ("D", ci), ("ca", cf), ("cb", cf)]
 
 
+class WnJob(C.Structure):          # mapdit_wn_job_t
+    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp)]
+
+
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
                 ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci)]
@@ -58,6 +62,7 @@ _SIGS = {
     "mapdit_gemm_bf16": [ci, ci, ci, ci, vp, ci, vp, ci, C.POINTER(Epilogue), vp],
     "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
+    "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],

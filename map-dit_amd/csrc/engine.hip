@@ -75,6 +75,11 @@ struct mapdit_engine {
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
     bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
+    // one-launch weight pass: job table (host copy + device copy in the workspace), rebuilt by engine_bind
+    std::vector<mapdit_wn_job_t> wn_jobs;
+    mapdit_wn_job_t* wn_jobs_dev = nullptr;
+    int wn_blocks = 0;
+    bool wn_table_ready = false;
     // fp32-accurate forward (cfg.precision == MAPDIT_PREC_BF16X3): fp32 activations + split operand staging
     struct {
         float *four, *h1, *t0, *qkv, *qn, *kn, *v, *o, *y, *h, *wtmp;
@@ -118,6 +123,7 @@ size_t carve(mapdit_engine* e, void* base) {
         img(pidx_block(i, MAPDIT_B_FC1), Hm, D, Hm);
         img(pidx_block(i, MAPDIT_B_FC2), D, Hm, D);
     }
+    e->wn_jobs_dev = cv.take<mapdit_wn_job_t>((size_t)np + 2);
     e->wx_eff = cv.take<float>((size_t)D * e->P1);
     e->table_eff = cv.take<float>((size_t)c.table_rows * D);
     e->four = cv.take<bf16_t>((size_t)N * FOURIER);
@@ -413,12 +419,37 @@ extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host,
         e->params[i] = params_host[i];
         e->grads[i] = grads_host ? grads_host[i] : nullptr;
     }
+    // job table of the one-launch weight pass (bf16 engines; the bf16x3 path re-images weight by weight)
+    e->wn_jobs.clear();
+    e->wn_blocks = 0;
+    e->wn_table_ready = false;
+    auto job = [&](float* W, int rows, int cols, float out_scale, bf16_t* wb, float* wf) {
+        mapdit_wn_job_t j;
+        j.W = W; j.rows = rows; j.cols = cols; j.out_scale = out_scale; j.first_block = e->wn_blocks; j.w_bf16 = wb; j.w_f32 = wf;
+        e->wn_jobs.push_back(j);
+        e->wn_blocks += (rows + 3) / 4;
+    };
+    if (e->cfg.precision == MAPDIT_PREC_BF16) {
+        for (size_t i = 0; i < e->wimg.size(); ++i)
+            if (e->wimg[i].img) job(e->params[i], e->wimg[i].rows, e->wimg[i].cols, 1.f, e->wimg[i].img, nullptr);
+        job(e->params[MAPDIT_P_X_EMB], e->D, e->P1, 1.f, nullptr, e->wx_eff);
+        job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff);
+    }
     return MAPDIT_OK;
 }
 
 extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, void* st) {
     MD_CHECK(e && e->params[0], "engine_prepare_weights: parameters not bound");
     const mapdit_config_t& c = e->cfg;
+    if (!e->wn_jobs.empty()) {
+        if (!e->wn_table_ready) {              // first use after a (re)bind: the host vector outlives the async copy
+            hipError_t he = hipMemcpyAsync(e->wn_jobs_dev, e->wn_jobs.data(), e->wn_jobs.size() * sizeof(mapdit_wn_job_t),
+                                           hipMemcpyHostToDevice, (hipStream_t)st);
+            MD_CHECK(he == hipSuccess, "engine_prepare_weights: job table upload failed: %s", hipGetErrorString(he));
+            e->wn_table_ready = true;
+        }
+        return mapdit_weightnorm_fwd_batch(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st);
+    }
     for (size_t i = 0; i < e->wimg.size(); ++i) {
         const WeightImg& w = e->wimg[i];
         if (!w.img) continue;

@@ -8,11 +8,9 @@ namespace {
 // One wave per row.  Pass 1: sum of squares.  Pass 2 (row is L1/L2-hot): rewrite the master weight
 // (forced weight norm, reference mp_linear.py:38-40 / mp_embedding.py:17-19) and emit the effective
 // weight  w = out_scale * Wn / (|Wn| + eps)  (mp_linear.py:44: normalize(W)/sqrt(in) == W/(|W|+eps)).
-__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__ W, int rows, int cols, int forced,
-                                                           float out_scale, bf16_t* __restrict__ wb,
-                                                           float* __restrict__ wf, float* __restrict__ inv) {
+__device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int row, int rows, int cols, int forced, float out_scale,
+                                                   bf16_t* __restrict__ wb, float* __restrict__ wf, float* __restrict__ inv) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float* w = W + (size_t)row * cols;
     float ss = 0.f;
@@ -56,6 +54,26 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__
             if (wb) wb[(size_t)row * cols + c] = f2bf(v * e);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(float* __restrict__ W, int rows, int cols, int forced,
+                                                           float out_scale, bf16_t* __restrict__ wb,
+                                                           float* __restrict__ wf, float* __restrict__ inv) {
+    weightnorm_fwd_row(W, blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, forced, out_scale, wb, wf, inv);
+}
+
+// Every weight of the model in ONE launch: a workgroup finds its job by binary search over the jobs' first-workgroup
+// prefix (the table lives in device memory, built once per binding).
+__global__ __launch_bounds__(256) void weightnorm_fwd_batch_kernel(const mapdit_wn_job_t* __restrict__ jobs, int njobs, int forced) {
+    int lo = 0, hi = njobs - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const mapdit_wn_job_t j = jobs[lo];
+    weightnorm_fwd_row(j.W, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, forced, j.out_scale, j.w_bf16, j.w_f32,
+                       nullptr);
 }
 
 // Backward of w = out_scale * W / (n + eps), n = |W|:  dW = out_scale * (G/(n+eps) - W (G.W) / (n (n+eps)^2)).
@@ -165,6 +183,13 @@ extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, f
     MD_CHECK((cols & 3) != 0 || (((uintptr_t)W | (uintptr_t)w_f32) & 15) == 0, "weightnorm_fwd: unaligned pointer");
     hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, rows, cols,
                        forced, out_scale, w_bf16, w_f32, inv);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream) {
+    MD_CHECK(jobs_dev && njobs > 0 && total_blocks > 0, "weightnorm_fwd_batch: null/empty argument");
+    hipLaunchKernelGGL(weightnorm_fwd_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs, forced);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -205,6 +205,36 @@ def test_weightnorm(L, rows, cols, forced):
     assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
 
 
+def test_weightnorm_batch_equals_single_launches(L):
+    """mapdit_weightnorm_fwd_batch (one launch for every weight, device job table) against one launch per weight: bit-equal
+    rewritten masters and images, for ragged row counts (rows % 4 != 0) and both output kinds."""
+    import numpy as np
+    shapes = [(384, 128, 1.0, "bf"), (10, 257, 1.0, "f32"), (1001, 64, 8.0, "f32"), (7, 128, 1.0, "bf"), (2304, 768, 1.0, "bf")]
+    g = torch.Generator().manual_seed(5)
+    masters = [torch.randn(r, c, generator=g) for r, c, _, _ in shapes]
+    for forced in (0, 1):
+        singles, batch = [], []
+        for which in ("single", "batch"):
+            Ws = [m.clone().to(DEV) for m in masters]
+            outs = [torch.zeros(r, c, device=DEV, dtype=torch.bfloat16 if kind == "bf" else torch.float32) for r, c, _, kind in shapes]
+            if which == "single":
+                for W, o, (r, c, sc, kind) in zip(Ws, outs, shapes):
+                    L.lib().weightnorm_fwd(p(W), r, c, forced, sc, p(o) if kind == "bf" else None, p(o) if kind == "f32" else None, None, st())
+            else:
+                jobs = (L.WnJob * len(shapes))()
+                blocks = 0
+                for j, (W, o, (r, c, sc, kind)) in enumerate(zip(Ws, outs, shapes)):
+                    jobs[j] = L.WnJob(W=p(W), rows=r, cols=c, out_scale=sc, first_block=blocks, w_bf16=p(o) if kind == "bf" else None,
+                                      w_f32=p(o) if kind == "f32" else None)
+                    blocks += (r + 3) // 4
+                raw = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(DEV)
+                L.lib().weightnorm_fwd_batch(p(raw), len(shapes), blocks, forced, st())
+            torch.cuda.synchronize()
+            (singles if which == "single" else batch).extend([w.cpu() for w in Ws] + [o.cpu() for o in outs])
+        for a, b in zip(singles, batch):
+            assert torch.equal(a, b)
+
+
 def test_adam_ema(L):
     from oracle.dit_oracle import adam_step, ema_beta
     n = 4096 + 64
