@@ -221,6 +221,11 @@ int mapdit_loss_bwd(const float* G, const float* g_loss, const float* g_mse, con
 int mapdit_psample_step(const float* model_out, const float* x, const float* noise, const int64_t* t, const float* tab,
                         int nsteps, int clip_denoised, float* sample, float* pred_xstart, int N, int per_sample,
                         void* stream);
+/* ddim_sample / ddim_reverse_sample (:513-605), same conventions; dtab = fp32 [3][nsteps]: alphas_cumprod, alphas_cumprod_prev,
+ * alphas_cumprod_next of the (respaced) schedule.  reverse != 0: the deterministic reverse-ODE step (eta must be 0, noise unused). */
+int mapdit_ddim_step(const float* model_out, const float* x, const float* noise, const int64_t* t, const float* tab,
+                     const float* dtab, int nsteps, int clip_denoised, float eta, int reverse, float* sample, float* pred_xstart,
+                     int N, int per_sample, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).

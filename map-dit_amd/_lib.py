@@ -91,6 +91,7 @@ _SIGS = {
     "mapdit_loss_fwd": [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp],
     "mapdit_loss_bwd": [vp, vp, vp, vp, vp, ci, ci, vp],
     "mapdit_psample_step": [vp, vp, vp, vp, vp, ci, ci, vp, vp, ci, ci, vp],
+    "mapdit_ddim_step": [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp, ci, ci, vp],
     "mapdit_engine_create": [C.POINTER(Config), ci, vp, C.c_size_t, vp, C.POINTER(vp)],
     "mapdit_engine_bind": [vp, C.POINTER(vp), C.POINTER(vp)],
     "mapdit_engine_prepare_weights": [vp, ci, vp],

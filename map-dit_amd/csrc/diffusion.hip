@@ -129,7 +129,50 @@ __global__ void p_sample_kernel(const float* __restrict__ mo, const float* __res
     if (xstart) xstart[i] = xs;
 }
 
+// DDIM step (reference gaussian_diffusion.py:513-567) and its reverse ODE step (:569-605) for EPSILON / LEARNED_RANGE models:
+// x0^ from the predicted noise (clipped on request), the noise re-derived from x0^ (_predict_eps_from_xstart), then Eq. 12 of
+// Song et al. 2020.  dtab = [alphas_cumprod | alphas_cumprod_prev | alphas_cumprod_next] (fp32 rows of the respaced schedule).
+__global__ void ddim_kernel(const float* __restrict__ mo, const float* __restrict__ x, const float* __restrict__ noise,
+                            const long* __restrict__ t, const float* __restrict__ tab, const float* __restrict__ dtab, int nsteps,
+                            int clip, float eta, int reverse, float* __restrict__ sample, float* __restrict__ xstart, long total,
+                            int per) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / per, e = i % per;
+    const long tt = t[n];
+    const float epsm = mo[n * 2 * per + e], x_t = x[i];
+    const float ra = tab[2 * nsteps + tt], rm1 = tab[3 * nsteps + tt];
+    float xs = ra * x_t - rm1 * epsm;
+    if (clip) xs = fminf(fmaxf(xs, -1.f), 1.f);
+    const float eps = (ra * x_t - xs) / rm1;
+    float out;
+    if (reverse) {
+        const float abn = dtab[2 * nsteps + tt];
+        out = xs * sqrtf(abn) + sqrtf(1.f - abn) * eps;
+    } else {
+        const float ab = dtab[tt], abp = dtab[nsteps + tt];
+        const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+        out = xs * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * eps;
+        if (tt != 0) out += sigma * noise[i];
+    }
+    sample[i] = out;
+    if (xstart) xstart[i] = xs;
+}
+
 }  // namespace
+
+extern "C" int mapdit_ddim_step(const float* model_out, const float* x, const float* noise, const int64_t* t, const float* tab,
+                                const float* dtab, int nsteps, int clip_denoised, float eta, int reverse, float* sample,
+                                float* pred_xstart, int N, int per_sample, void* stream) {
+    MD_CHECK(model_out && x && t && tab && dtab && sample && N > 0, "ddim_step: null/empty argument");
+    MD_CHECK(reverse || noise, "ddim_step: the forward step needs the noise tensor");
+    MD_CHECK(!reverse || eta == 0.f, "ddim_step: the reverse ODE is deterministic (eta must be 0)");
+    const long total = (long)N * per_sample;
+    hipLaunchKernelGGL(ddim_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, model_out, x, noise, (const long*)t, tab,
+                       dtab, nsteps, clip_denoised, eta, reverse, sample, pred_xstart, total, per_sample);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
 
 extern "C" int mapdit_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab, int nsteps, float* xt,
                                int N, int per_sample, void* stream) {

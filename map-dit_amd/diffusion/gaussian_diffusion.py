@@ -124,6 +124,14 @@ class GaussianDiffusion:
             self._tab_cache[device] = tab
         return tab
 
+    def _ddim_tables(self, device):
+        tab = self._tab_cache.get(("ddim", device))
+        if tab is None:
+            rows = [self.alphas_cumprod, self.alphas_cumprod_prev, self.alphas_cumprod_next]
+            tab = torch.from_numpy(np.stack(rows)).float().to(device).contiguous()
+            self._tab_cache[("ddim", device)] = tab
+        return tab
+
     def _supported(self):
         if (self.model_mean_type != ModelMeanType.EPSILON or self.model_var_type != ModelVarType.LEARNED_RANGE
                 or self.loss_type != LossType.MSE):
@@ -214,6 +222,70 @@ class GaussianDiffusion:
         noise = torch.randn_like(x)
         sample, xstart = self._step_math(model_output, x, t, noise, clip_denoised)
         return {"sample": sample, "pred_xstart": xstart}
+
+    # ---- DDIM (reference gaussian_diffusion.py:513-680; no reference script uses it) ----------------------------------
+    def _ddim_math(self, model_output, x, t, noise, clip_denoised, eta, reverse):
+        x = self._prep(x)
+        mo = self._prep(model_output)
+        sample, xstart = torch.empty_like(x), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            L.lib().ddim_step(mo.data_ptr(), x.data_ptr(), L.ptr(noise), t.data_ptr(), self._tables(x.device).data_ptr(),
+                              self._ddim_tables(x.device).data_ptr(), self.num_timesteps, int(bool(clip_denoised)), float(eta),
+                              int(bool(reverse)), sample.data_ptr(), xstart.data_ptr(), x.shape[0], x[0].numel(), L.cur_stream())
+        return sample, xstart
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        """reference gaussian_diffusion.py:513-567."""
+        self._supported()
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn are not built")
+        x = self._prep(x)
+        t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        model_output = self._wrap_model(model)(x, t, **(model_kwargs or {}))
+        noise = torch.randn_like(x)
+        sample, xstart = self._ddim_math(model_output, x, t, noise, clip_denoised, eta, False)
+        return {"sample": sample, "pred_xstart": xstart}
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        """reference gaussian_diffusion.py:569-605: x_{t+1} along the deterministic reverse ODE."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        self._supported()
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn are not built")
+        x = self._prep(x)
+        t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        model_output = self._wrap_model(model)(x, t, **(model_kwargs or {}))
+        sample, xstart = self._ddim_math(model_output, x, t, None, clip_denoised, 0.0, True)
+        return {"sample": sample, "pred_xstart": xstart}
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=False, eta=0.0):
+        """reference gaussian_diffusion.py:607-636."""
+        final = None
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
+                                                        device=device, progress=progress, eta=eta):
+            final = sample
+        return final["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0):
+        """reference gaussian_diffusion.py:638-680."""
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            t = torch.full((shape[0],), i, device=device, dtype=torch.int64)
+            with torch.no_grad():
+                out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                       model_kwargs=model_kwargs, eta=eta)
+                yield out
+                img = out["sample"]
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False):

@@ -178,6 +178,22 @@ class DiffusionOracle:
         return {"sample": p["mean"] + nz * torch.exp(0.5 * p["log_variance"]) * noise,
                 "pred_xstart": p["pred_xstart"], "model_output": out}
 
+    def ddim_sample(self, model: Callable, x: Tensor, t: Tensor, noise: Optional[Tensor], clip_denoised=False, model_kwargs=None,
+                    eta: float = 0.0, reverse: bool = False):
+        """gaussian_diffusion.py:513-567 (and :569-605 with ``reverse``), with the N(0,1) draw passed in."""
+        out = model(x, self.map_t(t), **(model_kwargs or {}))
+        xs = self.p_mean_variance_from_output(out, x, t, clip_denoised)["pred_xstart"]
+        ext = lambda a: torch.from_numpy(a)[t].float().view(-1, *([1] * (x.dim() - 1)))
+        eps = (ext(self.sqrt_recip_alphas_cumprod) * x - xs) / ext(self.sqrt_recipm1_alphas_cumprod)
+        if reverse:
+            abn = ext(np.append(self.alphas_cumprod[1:], 0.0))
+            return {"sample": xs * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps, "pred_xstart": xs}
+        ab, abp = ext(self.alphas_cumprod), ext(self.alphas_cumprod_prev)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        mean = xs * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+        nz = (t != 0).to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
+        return {"sample": mean + nz * sigma * noise, "pred_xstart": xs}
+
     def p_sample_loop(self, model: Callable, shape: Sequence[int], noise: Tensor, step_noise: Sequence[Tensor],
                       clip_denoised=False, model_kwargs=None, max_steps: Optional[int] = None) -> List[Tensor]:
         """gaussian_diffusion.py:419-511; returns the sample after each executed step

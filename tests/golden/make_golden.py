@@ -273,7 +273,40 @@ def ema_fixture():
     print("== ema.npz written")
 
 
+def ddim_fixture():
+    """DDIM step, reverse-ODE step and a short loop of the reference (gaussian_diffusion.py:513-680) on fixed model outputs:
+    the 'model' is a stub that returns a recorded tensor, so the fixture pins the step mathematics alone."""
+    out = {}
+    d = ref_create("250")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 4, 8, 8, generator=g)
+    mo = torch.randn(4, 8, 8, 8, generator=g)
+    t = torch.tensor([0, 1, 120, 249])
+    out["x"], out["mo"], out["t"] = x.numpy(), mo.numpy(), t.numpy()
+    stub = lambda xx, tt, **kw: mo
+    for tag, kw in (("eta0", dict(eta=0.0, clip_denoised=False)), ("eta0_clip", dict(eta=0.0, clip_denoised=True)),
+                    ("eta07", dict(eta=0.7, clip_denoised=False))):
+        torch.manual_seed(5)
+        r = d.ddim_sample(stub, x, t, **kw)
+        torch.manual_seed(5)
+        out[f"{tag}/noise"] = torch.randn_like(x).numpy()            # the draw ddim_sample made
+        out[f"{tag}/sample"], out[f"{tag}/xstart"] = r["sample"].numpy(), r["pred_xstart"].numpy()
+    r = d.ddim_reverse_sample(stub, x, t, clip_denoised=False)
+    out["rev/sample"], out["rev/xstart"] = r["sample"].numpy(), r["pred_xstart"].numpy()
+    # deterministic loop on a 5-step schedule; the stub's output depends on (x, t) so every step matters
+    d5 = ref_create("5")
+    stub5 = lambda xx, tt, **kw: torch.cat([0.3 * xx + 0.01 * tt.float().view(-1, 1, 1, 1), 0.1 * xx], dim=1)
+    out["loop_noise"] = torch.randn(2, 4, 8, 8, generator=g).numpy()
+    out["loop_final"] = d5.ddim_sample_loop(stub5, (2, 4, 8, 8), noise=torch.from_numpy(out["loop_noise"]), clip_denoised=False,
+                                            device="cpu", eta=0.0).numpy()
+    np.savez_compressed(os.path.join(HERE, "ddim.npz"), **out)
+    print("== ddim.npz written")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ddim":
+        ddim_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ema":
         ema_fixture()
         sys.exit(0)

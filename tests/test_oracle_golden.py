@@ -134,3 +134,18 @@ def test_optimizer_fixture():
             assert rel_err(sub(sd[k]), g[f"s{step}/w/{k}"]) < 2e-4, (step, k)
             assert rel_err(sub(emas[0.05][k]), g[f"s{step}/ema0.05/{k}"]) < 2e-4, (step, k)
             assert rel_err(sub(emas[0.1][k]), g[f"s{step}/ema0.1/{k}"]) < 2e-4, (step, k)
+
+
+def test_ddim_oracle_matches_reference():
+    """DDIM step / reverse step (reference gaussian_diffusion.py:513-605) on recorded model outputs."""
+    from oracle.diffusion_oracle import DiffusionOracle
+    g = load_golden("ddim")
+    d = DiffusionOracle("250")
+    x, mo, t = (torch.from_numpy(g[k]) for k in ("x", "mo", "t"))
+    stub = lambda xx, tt, **kw: mo
+    for tag, eta, clip in (("eta0", 0.0, False), ("eta0_clip", 0.0, True), ("eta07", 0.7, False)):
+        r = d.ddim_sample(stub, x, t, torch.from_numpy(g[f"{tag}/noise"]), clip_denoised=clip, eta=eta)
+        assert rel_err(r["sample"].numpy(), g[f"{tag}/sample"]) < 1e-6, tag
+        assert rel_err(r["pred_xstart"].numpy(), g[f"{tag}/xstart"]) < 1e-6, tag
+    r = d.ddim_sample(stub, x, t, None, clip_denoised=False, reverse=True)
+    assert rel_err(r["sample"].numpy(), g["rev/sample"]) < 1e-6
