@@ -46,6 +46,8 @@ def main():
     h, dy, dh = rnd(M, 4 * D), rnd(M, D), rnd(M, 4 * D)
     out_bf = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16)
     out_bf2 = torch.empty_like(out_bf)
+    out_bf3 = torch.empty_like(out_bf)
+    scales = torch.empty(2 * M * (D // 64), device=dev)
     out_f32 = torch.empty(64, 4 * D * D, device=dev)
     xres = torch.randn(M, D, device=dev)
     xout = torch.empty_like(xres)
@@ -60,6 +62,9 @@ def main():
 
     cases = [
         ("qkv  fwd NT store", 0, M, 3 * D, D, x, D, w_qkv, D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=3 * D, alpha=1.0)),
+        ("qkv  fwd NT heads", 0, M, 3 * D, D, x, D, w_qkv, D,
+         ep(L.EPI_QKV_HEADS, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), out3=out_bf3.data_ptr(), out4=scales.data_ptr(),
+            rows_per_sample=256, alpha=1.0)),
         ("fc1  fwd NT silu2", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_SILU2, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), ldo=4 * D)),
         ("fc2  fwd NT resid", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D,
          ep(L.EPI_RESID, out=out_bf.data_ptr(), out2=xout.data_ptr(), aux=xres.data_ptr(), gate=gate.data_ptr(), ldg=6 * D,
