@@ -132,3 +132,29 @@ def test_staged_backward_equals_monolithic(monkeypatch):
         grads.append(m._gflat.clone())
     # identical up to the float-atomic order of the tiny label-table / MPScale-reference gradients
     assert rel_err(grads[1].cpu().numpy(), grads[0].cpu().numpy()) < 1e-6
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path of bench.py end to end (rendezvous, per-rank data seeds, staged backward with one all-reduce per stage,
+    fused optimiser with the 1/world gradient scale, max-over-ranks timing, rank-0 JSON) with two ranks sharing this box's one
+    GPU.  The collective runs on gloo here (RCCL needs one GPU per rank); everything else is the code the 8-GPU run executes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAPDIT_DIST_BACKEND="gloo", MAPDIT_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch-per-gpu", "16", "--model", "DiT-S/2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["steps"] == 2 and "cpu_baseline" not in d
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
