@@ -50,8 +50,12 @@ struct GemmP {
 __device__ __forceinline__ int kswz(int k) { return (k & 3) | ((k >> 1) & 4); }
 
 // ---- staging: HBM -> LDS by LDS-DMA --------------------------------------------------------------
-template <int KIND>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0,
+// K need not be a multiple of the 64-deep K-tile (only of 8): a 16-byte piece that lies beyond K is fetched from this zero
+// word instead, so the tail of the last K-tile contributes nothing.
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int KIND, bool KTAIL>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, int kmax,
                                            char* tile, int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -63,12 +67,14 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
             int grow = idx0 + row;
             grow = grow < idx_max ? grow : idx_max - 1;     // ragged edge: re-read a valid row, result is masked
             src = G + (size_t)grow * ld + k0 + c * 8;
+            if (KTAIL && k0 + c * 8 >= kmax) src = (const bf16_t*)g_zero16;
         } else {
             const int krow = seg * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (kswz(krow) << 1);
             int col = idx0 + c * 8;
             col = col < idx_max ? col : 0;
             src = G + (size_t)(k0 + krow) * ld + col;
+            if (KTAIL && k0 + krow >= kmax) src = (const bf16_t*)g_zero16;
         }
         __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(tile + seg * 1024), 16, 0, 0);
     }
@@ -231,7 +237,7 @@ struct EpiQkvHeads {
 };
 
 // ---- the MFMA kernel -------------------------------------------------------------------------------------
-template <int AK, int BK, class Epi>
+template <int AK, int BK, class Epi, bool KTAIL = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     const int z = wg / p.tiles, tile = wg - z * p.tiles;      // z-major: neighbouring blocks share operand panels
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     // slab z owns K-tiles [z*base + min(z, rem), +base (+1 if z < rem)): any split_k <= K/64 works
-    const int nkt = p.K / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    const int nkt = (p.K + BKT - 1) / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
     const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
 
     f32x4_t acc[4][4];
@@ -255,15 +261,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = kbase + (z < krem ? 1 : 0);
-    stage_tile<AK>(p.A, p.lda, m0, p.M, kbeg, smem, wave, lane);
-    stage_tile<BK>(p.B, p.ldb, n0, p.N, kbeg, smem + TILE_BYTES, wave, lane);
+    stage_tile<AK, KTAIL>(p.A, p.lda, m0, p.M, kbeg, p.K, smem, wave, lane);
+    stage_tile<BK, KTAIL>(p.B, p.ldb, n0, p.N, kbeg, p.K, smem + TILE_BYTES, wave, lane);
     for (int t = 0; t < nk; ++t) {
         __syncthreads();   // tile t has landed (vmcnt(0) + barrier); everyone is done with the other buffer
         char* cur = smem + (t & 1) * BUF_BYTES;
         if (t + 1 < nk) {
             char* nxt = smem + ((t + 1) & 1) * BUF_BYTES;
-            stage_tile<AK>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BKT, nxt, wave, lane);
-            stage_tile<BK>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BKT, nxt + TILE_BYTES, wave, lane);
+            stage_tile<AK, KTAIL>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BKT, p.K, nxt, wave, lane);
+            stage_tile<BK, KTAIL>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BKT, p.K, nxt + TILE_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -333,8 +339,8 @@ template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
     return SIDE == 0 ? ((i >> 6) * 128 + h * 64 + (i & 63)) : ((i >> 5) * 64 + h * 32 + (i & 31));
 }
 
-template <int KIND, int SIDE>
-__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, int h,
+template <int KIND, int SIDE, bool KTAIL>
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, int kmax, int h,
                                            char* slot, int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -346,12 +352,14 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
             int g = idx0 + half_map<SIDE>(row, h);
             g = g < idx_max ? g : idx_max - 1;
             src = G + (size_t)g * ld + k0 + c * 8;
+            if (KTAIL && k0 + c * 8 >= kmax) src = (const bf16_t*)g_zero16;
         } else {
             const int krow = seg * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (kswz(krow) << 1);
             int col = idx0 + half_map<SIDE>(c * 8, h);
             col = col < idx_max ? col : 0;
             src = G + (size_t)(k0 + krow) * ld + col;
+            if (KTAIL && k0 + krow >= kmax) src = (const bf16_t*)g_zero16;
         }
         __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(slot + seg * 1024), 16, 0, 0);
     }
@@ -367,7 +375,7 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
     __builtin_amdgcn_s_barrier();                         \
     __builtin_amdgcn_sched_barrier(0)
 
-template <int AK, int BK, class Epi>
+template <int AK, int BK, class Epi, bool KTAIL = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     const int bidx = tile / bsz, rem = tile - bidx * bsz;
     const int bw = (bidx + 1) * p.band <= p.tiles_n ? p.band : p.tiles_n - bidx * p.band;   // last band may be narrower
     const int m0 = (rem / bw) * BM2, n0 = (bidx * p.band + rem % bw) * BN2;
-    const int nkt = p.K / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    const int nkt = (p.K + BKT - 1) / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
     const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
     const int nk = kbase + (z < krem ? 1 : 0);
 
@@ -420,15 +428,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
     // prologue, in steady-state issue order: A0 B0 B1 A1 of tile 0, then A0 B0 B1 of tile 1 (its A1 is phase 1's DMA)
-    stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg, 0, smem + OFF_A0, wave, lane);
-    stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 0, smem + OFF_B0, wave, lane);
-    stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg, 1, smem + OFF_B1, wave, lane);
-    stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg, 1, smem + OFF_A1, wave, lane);
+    stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, kbeg, p.K, 0, smem + OFF_A0, wave, lane);
+    stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, kbeg, p.K, 0, smem + OFF_B0, wave, lane);
+    stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, kbeg, p.K, 1, smem + OFF_B1, wave, lane);
+    stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, kbeg, p.K, 1, smem + OFF_A1, wave, lane);
     if (nk > 1) {
         char* b1 = smem + KBUF_BYTES;
-        stage_half<AK, 0>(p.A, p.lda, m0, p.M, kbeg + BKT, 0, b1 + OFF_A0, wave, lane);
-        stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 0, b1 + OFF_B0, wave, lane);
-        stage_half<BK, 1>(p.B, p.ldb, n0, p.N, kbeg + BKT, 1, b1 + OFF_B1, wave, lane);
+        stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, kbeg + BKT, p.K, 0, b1 + OFF_A0, wave, lane);
+        stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, kbeg + BKT, p.K, 0, b1 + OFF_B0, wave, lane);
+        stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, kbeg + BKT, p.K, 1, b1 + OFF_B1, wave, lane);
         if (p.phases == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A0, B0, B1 of tile 0 have landed
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                  // A0, B0 of tile 0; five half-tiles in flight
     } else {
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             G256_LOAD_B(fb0, cur + OFF_B0);
             G256_LOAD_B(fb1, cur + OFF_B1);
             if (has1) {
-                stage_half<AK, 0>(p.A, p.lda, m0, p.M, k1, 1, nxt + OFF_A1, wave, lane);
+                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -471,9 +479,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             G256_END_MFMA();
             load_a(cur + OFF_A1);
             if (has2) {
-                stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 0, cur + OFF_A0, wave, lane);
-                stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 0, cur + OFF_B0, wave, lane);
-                stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane);
+                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane);
+                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else if (has1) {
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -494,26 +502,26 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         // phase 1: quadrant (0,0); slot A1 of the other buffer was last read in phase 3 of tile t-1
         load_a(cur + OFF_A0);
         G256_LOAD_B(fb0, cur + OFF_B0);
-        if (has1) stage_half<AK, 0>(p.A, p.lda, m0, p.M, k1, 1, nxt + OFF_A1, wave, lane);
+        if (has1) stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane);
         G256_WAIT_DMA(has2);
         G256_END_LOAD();
         G256_MFMA(0, 0, fb0);
         G256_END_MFMA();
         // phase 2: quadrant (0,1); slot A0 was last read in phase 1
         G256_LOAD_B(fb1, cur + OFF_B1);
-        if (has2) stage_half<AK, 0>(p.A, p.lda, m0, p.M, k2, 0, cur + OFF_A0, wave, lane);
+        if (has2) stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane);
         G256_WAIT_DMA(has2);
         G256_END_LOAD();
         G256_MFMA(0, 1, fb1);
         G256_END_MFMA();
         // phase 3: quadrant (1,1); slot B0 was last read in phase 1 (its fragments live on in fb0)
         load_a(cur + OFF_A1);
-        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 0, cur + OFF_B0, wave, lane);
+        if (has2) stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane);
         G256_END_LOAD();
         G256_MFMA(1, 1, fb1);
         G256_END_MFMA();
         // phase 4: quadrant (1,0) from registers only; slot B1 was last read in phase 2
-        if (has2) stage_half<BK, 1>(p.B, p.ldb, n0, p.N, k2, 1, cur + OFF_B1, wave, lane);
+        if (has2) stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane);
         G256_WAIT_DMA(has2);
         G256_END_LOAD();
         G256_MFMA(1, 0, fb0);
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }
 }
 
-// ---- generic fallback for shapes the MFMA tiling does not take (K % 64 != 0: tiny conditioning GEMMs) --------
+// ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
 // One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
 template <class Epi>
 __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long sak, const bf16_t* __restrict__ B,
@@ -584,18 +592,24 @@ extern "C" int mapdit_gemm_tile_size(int M, int N) {
 
 namespace {
 
+template <class Epi> constexpr bool kHasTail = false;
+template <> constexpr bool kHasTail<EpiStoreF32> = true;
+
 template <class Epi>
 int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, Epi epi,
            hipStream_t st, int split_k = 1) {
     const bool a_kmaj = layout == MAPDIT_TN, b_kmaj = layout != MAPDIT_NT;
-    bool mfma = (K % BKT == 0) && (N % 8 == 0) && K > 0;
+    // K % 64 != 0 (zero-sourced K tail) is compiled for the fp32-store epilogue only: that is where such shapes occur (weight
+    // gradients over a batch that is not a multiple of 64, the bf16x3 path); the hot instantiations carry no tail check
+    const bool ktail = K % BKT != 0;
+    bool mfma = (K % 8 == 0) && (N % 8 == 0) && K > 0 && (!ktail || kHasTail<Epi>);
     if (a_kmaj && (M % 8 != 0 || lda % 8 != 0)) mfma = false;
     if (b_kmaj && (ldb % 8 != 0)) mfma = false;
     if (!a_kmaj && lda % 8 != 0) mfma = false;
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
-    if (split_k > 1 && (!mfma || split_k > K / BKT)) {
-        mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= K/64 (K=%d)", split_k, K);
+    if (split_k > 1 && (!mfma || split_k > (K + BKT - 1) / BKT)) {
+        mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= ceil(K/64) (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
     if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
@@ -612,6 +626,15 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
         const int grid = p.tiles * split_k;
+        if constexpr (kHasTail<Epi>) {
+            if (ktail) {
+                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                MD_LAUNCH_CHECK();
+                return MAPDIT_OK;
+            }
+        }
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
@@ -619,6 +642,15 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;
+        if constexpr (kHasTail<Epi>) {
+            if (ktail) {
+                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi, true>), dim3(grid), dim3(256), 0, st, p, epi);
+                else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_KMAJ, Epi, true>), dim3(grid), dim3(256), 0, st, p, epi);
+                else hipLaunchKernelGGL((gemm_mfma_kernel<OP_KMAJ, OP_KMAJ, Epi, true>), dim3(grid), dim3(256), 0, st, p, epi);
+                MD_LAUNCH_CHECK();
+                return MAPDIT_OK;
+            }
+        }
         if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);

@@ -60,9 +60,13 @@ def run_gemm(L, layout, a, b, kind, M, N, K, **kw):
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 128), (200, 136, 192), (1024, 768, 768), (77, 32, 64),
                                    (64, 24, 256), (8, 128, 32), (130, 128, 8),
                                    # 256x256 staggered kernel (M >= 512, N >= 256): 1..7 K-tiles, ragged edges
-                                   (512, 256, 64), (512, 256, 128), (768, 512, 192), (600, 264, 448), (2048, 3072, 768)])
+                                   (512, 256, 64), (512, 256, 128), (768, 512, 192), (600, 264, 448), (2048, 3072, 768),
+                                   # K not a multiple of the 64-deep K-tile (zero-sourced tail): both MFMA kernels
+                                   (512, 256, 32), (640, 384, 96), (1024, 768, 200), (96, 64, 40), (4608, 768, 32),
+                                   # K % 8 != 0: the scalar fallback
+                                   (64, 32, 12)])
 def test_gemm_layouts(L, layout, shape):
-    """C = A B^T in the three storage layouts, incl. ragged M/N and the non-MFMA fallback (K % 64 != 0)."""
+    """C = A B^T in the three storage layouts, incl. ragged M/N, K tails (K % 64 != 0) and the non-MFMA fallback (K % 8 != 0)."""
     M, N, K = shape
     if layout == 2 and M % 8:
         pytest.skip("TN needs M % 8 == 0 (rows of the K-major operand are 16-byte chunks)")
