@@ -334,6 +334,22 @@ constexpr int SLOT_BYTES = 16384, KBUF_BYTES = 4 * SLOT_BYTES;
 constexpr int OFF_A0 = 0, OFF_A1 = SLOT_BYTES, OFF_B0 = 2 * SLOT_BYTES, OFF_B1 = 3 * SLOT_BYTES;
 constexpr int CS2_LD = 260;                               // fp32 row stride of the epilogue image (1040 B)
 constexpr int SMEM2_BYTES = 128 * CS2_LD * 4;             // 133,120 B >= 2 x 64 KiB staging
+#ifdef MAPDIT_GEMM_STAMPS
+// Timeline instrumentation (tools/gemm_stamps.py builds this variant into its own library; never part of libmapdit_hip.so):
+// lane 0 of waves 0 and 4 of workgroup 0 stamps the shader clock at 11 points of every K-tile into spare LDS, and copies the
+// stamps out when the tile is done.
+constexpr int STAMP_TILES = 12, STAMP_POINTS = 11;
+__device__ long long* g_stamps = nullptr;
+extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p) { g_stamps = p; }
+#define G256_STAMP(PT)                                                                              \
+    if (stamp_on && t < STAMP_TILES) {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        stamp_lds[(wm * STAMP_TILES + t) * STAMP_POINTS + (PT)] = (long long)__builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+#else
+#define G256_STAMP(PT)
+#endif
 
 template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
     return SIDE == 0 ? ((i >> 6) * 128 + h * 64 + (i & 63)) : ((i >> 5) * 64 + h * 32 + (i & 31));
@@ -377,10 +393,18 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
 
 template <int AK, int BK, class Epi, bool KTAIL = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
+#ifdef MAPDIT_GEMM_STAMPS
+    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES + 2 * STAMP_TILES * STAMP_POINTS * 8];
+    long long* stamp_lds = (long long*)(smem + SMEM2_BYTES);
+#else
     __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;               // wm doubles as the stagger group (waves 4-7 run behind)
+#ifdef MAPDIT_GEMM_STAMPS
+    const bool stamp_on = g_stamps && blockIdx.x == 8 && (wave == 0 || wave == 4) && lane == 0;
+#endif
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -464,35 +488,50 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
             const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            G256_STAMP(0);
             load_a(cur + OFF_A0);
             G256_LOAD_B(fb0, cur + OFF_B0);
             G256_LOAD_B(fb1, cur + OFF_B1);
             if (has1) {
                 stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane);
+                G256_STAMP(1);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            G256_STAMP(2);
             G256_END_LOAD();
+            G256_STAMP(3);
             G256_MFMA(0, 0, fb0);
             G256_MFMA(0, 1, fb1);
+            G256_STAMP(4);
             G256_END_MFMA();
+            G256_STAMP(5);
             load_a(cur + OFF_A1);
             if (has2) {
                 stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane);
                 stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane);
                 stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane);
+                G256_STAMP(6);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else if (has1) {
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            G256_STAMP(7);
             G256_END_LOAD();
+            G256_STAMP(8);
             G256_MFMA(1, 1, fb1);
             G256_MFMA(1, 0, fb0);
+            G256_STAMP(9);
             G256_END_MFMA();
+            G256_STAMP(10);
         }
+#ifdef MAPDIT_GEMM_STAMPS
+        if (stamp_on)
+            for (int i = 0; i < STAMP_TILES * STAMP_POINTS; ++i) g_stamps[wm * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[wm * STAMP_TILES * STAMP_POINTS + i];
+#endif
     } else
     for (int t = 0; t < nk; ++t) {
         char* cur = smem + (t & 1) * KBUF_BYTES;
@@ -583,6 +622,13 @@ __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long 
 
 // Output tile edge the dispatcher uses for an [M, N] result: 256 (8-wave staggered kernel, one workgroup per CU) for
 // token-sized problems, 128 for small ones (conditioning path, final linear).  Exposed so callers can size split-K.
+#ifdef MAPDIT_GEMM_STAMPS
+extern "C" void mapdit_debug_set_stamps(long long* p) {
+    hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p);
+    (void)hipDeviceSynchronize();
+}
+#endif
+
 extern "C" int mapdit_gemm_tile_size(int M, int N) {
     const char* env = getenv("MAPDIT_GEMM_TILE");         // A/B switch for benchmarking (read per call, cheap)
     const int force = env ? atoi(env) : 0;

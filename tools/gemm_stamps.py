@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Timeline of the 256x256 GEMM's K-tile loop from in-kernel shader-clock stamps (guide: 'In-kernel stamps').
+
+Builds gemm.hip with -DMAPDIT_GEMM_STAMPS into tools/_stamps/libgemm_stamps.so (a separate library; the product library has
+no instrumentation), runs one NN GEMM [65536,3072] x [3072,768] and one TN GEMM, and prints, for a wave of each of the two
+wave groups, the cycles spent per K-tile in: LOAD A (fragment reads + DMA issue | DMA wait | barrier), MFMA A, LOAD B, MFMA B.
+
+    python tools/gemm_stamps.py --build      # here (hipcc cross-compiles)
+    python tools/gemm_stamps.py              # on the GPU box
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "_stamps")
+SO = os.path.join(OUT, "libgemm_stamps.so")
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(ROOT, "map-dit_amd", "csrc", "gemm.hip")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+                           "-DMAPDIT_GEMM_STAMPS", "-Wno-unused-function", src, "-o", SO])
+    print("built", SO)
+
+
+def main():
+    import torch
+    sys.path.insert(0, ROOT)
+    import mapdit_amd
+    L = mapdit_amd._lib
+    lib = C.CDLL(SO)
+    lib.mapdit_gemm_bf16.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(L.Epilogue), C.c_void_p]
+    lib.mapdit_gemm_bf16.restype = C.c_int
+    lib.mapdit_last_error.restype = C.c_char_p
+    TILES, PTS = 12, 11
+    stamps = torch.zeros(2 * TILES * PTS, dtype=torch.int64, device="cuda")
+    # set the device-side pointer through the tiny setter kernel
+    mod_launch = getattr(lib, "mapdit_debug_set_stamps", None)
+    assert mod_launch is not None, "stamp build lacks mapdit_debug_set_stamps"
+    mod_launch.argtypes = [C.c_void_p]
+    mod_launch(stamps.data_ptr())
+    torch.cuda.synchronize()
+    D, M = 768, 65536
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).bfloat16()
+    dh, w4, x = rnd(M, 4 * D), rnd(4 * D, D), rnd(M, D)
+    out = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    slabs = torch.empty(8, 4 * D * D, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    names = ["A:issue", "A:dma-wait", "A:barrier", "A:mfma", "A:barrier2", "B:issue", "B:dma-wait", "B:barrier", "B:mfma", "B:barrier2"]
+    for label in ("NN fc1 dX (K=3072)", "TN fc1 dW (K=65536, split 7)"):
+        e = L.Epilogue()
+        for _ in range(3):
+            if label.startswith("NN"):
+                e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, out.data_ptr(), D, 1.0
+                rc = lib.mapdit_gemm_bf16(1, M, D, 4 * D, dh.data_ptr(), 4 * D, w4.data_ptr(), D, C.byref(e), st)
+            else:
+                e.kind, e.out, e.ldo, e.alpha, e.split_k, e.slab_stride = L.EPI_STORE_F32, slabs.data_ptr(), D, 1.0, 7, 4 * D * D
+                rc = lib.mapdit_gemm_bf16(2, 4 * D, D, M, dh.data_ptr(), 4 * D, x.data_ptr(), D, C.byref(e), st)
+            assert rc == 0, lib.mapdit_last_error()
+        torch.cuda.synchronize()
+        s = stamps.cpu().view(2, TILES, PTS)
+        print(f"== {label}: cycles per K-tile section (median over K-tiles 2..{TILES - 1}), wave group 0 | 1")
+        for i, nm in enumerate(names):
+            d = (s[:, 2:, i + 1] - s[:, 2:, i]).float()
+            print(f"   {nm:12s} {d[0].median().item():7.0f} | {d[1].median().item():7.0f}")
+        per = (s[:, 3:, 0] - s[:, 2:-1, 0]).float()
+        print(f"   K-tile total {per[0].median().item():7.0f} | {per[1].median().item():7.0f}   (MFMA issue alone: 2 x 512)")
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+    else:
+        main()
