@@ -93,3 +93,49 @@ def calculate_posthoc_ema(out_std: float, ema_dir: str, verbose: bool = True) ->
     if verbose:
         print()
     return acc
+
+
+class EMA:
+    """Counterpart of the reference's ``EMA`` helper (src/ema.py:117-155) for training loops that keep ``torch.optim.Adam``:
+    one power-function EMA copy of the model per relative width, updated after every optimiser step and snapshotted as
+    fp16 state dicts.  (``mapdit_amd.optim.FusedAdamEMA`` folds the same update into the optimiser kernel.)
+
+    The copies are flat clones of the model's parameter buffer, so an update is ONE ``lerp_`` per width instead of one per
+    parameter tensor."""
+
+    @torch.no_grad()
+    def __init__(self, net, results_dir, stds=(0.05, 0.1)):
+        self.net = net
+        self.stds = tuple(stds)
+        self.flat = {s: net._pflat.detach().clone() for s in self.stds}
+        self.ema_dir = os.path.join(results_dir, "ema")
+        os.makedirs(self.ema_dir, exist_ok=True)
+
+    @torch.no_grad()
+    def update(self, t, model=None):
+        """ema <- lerp(ema, model, (1 - 1/t)^(gamma+1))   (reference src/ema.py:126-140)."""
+        model = model or self.net
+        for s, flat in self.flat.items():
+            flat.lerp_(model._pflat, float(calc_beta(s, t)))
+
+    def state_dict(self, std):
+        """The EMA weights of width ``std`` under the model's state-dict keys (buffers are the model's own)."""
+        flat = self.flat[std]
+        sd = {}
+        params = dict(self.net.named_parameters())
+        offs = {id(p): o for p, o in zip(self.net.parameters(), self.net._poffs)}
+        for k, v in self.net.state_dict().items():
+            if k in params:
+                p = params[k]
+                o = offs[id(p)]
+                sd[k] = flat[o:o + p.numel()].view(p.shape).clone()
+            else:
+                sd[k] = v.clone()
+        return sd
+
+    @torch.no_grad()
+    def save_snapshot(self, t):
+        """``ema/{std:.3f}_{t:07d}.pt`` = {"std", "t", "state_dict" (fp16, CPU)}   (reference src/ema.py:143-155)."""
+        for s in self.stds:
+            sd = {k: v.cpu().half() for k, v in self.state_dict(s).items()}
+            torch.save({"std": s, "t": t, "state_dict": sd}, os.path.join(self.ema_dir, f"{s:.3f}_{t:07d}.pt"))
