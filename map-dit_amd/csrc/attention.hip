@@ -78,6 +78,22 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int d0, int kbase,
 }
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
+// The same B-operand fragment taken from a ROW-MAJOR [k][64] tile (the layout of frag_rows) by two transposing LDS loads
+// (ds_read_b64_tr_b16: 16 lanes fetch a 4-row x 16-column block and each gets one column of it), so a product whose reduction
+// index is the tile's row index needs no transposed image: element j of lane (r, h) is [k = kbase + 8 (j >> 2) + 4 h + (j & 3)]
+// [d = d0 + r].
+__device__ __forceinline__ bf16x8_t frag_tr_rows(const char* tile, int d0, int kbase, int lane) {
+    const int i = lane & 15, grp = lane >> 4;                 // 16-lane group: d half = grp & 1, h = grp >> 1
+    const int col = d0 + 16 * (grp & 1) + 4 * (i & 3);
+    const int row0 = kbase + 4 * (grp >> 1) + (i >> 2), row1 = row0 + 8;
+    const int off0 = row0 * 128 + ((((col >> 3) ^ (row0 & 7)) << 4) | ((col & 7) << 1));
+    const int off1 = row1 * 128 + ((((col >> 3) ^ (row1 & 7)) << 4) | ((col & 7) << 1));
+    typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off0));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // A wave's 32 x 64 result tile, held as two accumulator tiles (columns r and 32 + r of rows acc_row(i)), leaves through a
 // private 32 x 136-byte LDS buffer so that each lane stores four 16-byte row chunks (8 lanes = one 128-byte row) instead of
 // thirty-two 2-byte column elements.  gdst = address of the tile's [0][0], row stride ld elements.
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
                                                               const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                               float* __restrict__ lse, int H, float scale) {
     using G = Geo<T>;
-    __shared__ __attribute__((aligned(16))) char smem[T * 128 + 64 * G::VLD];
+    __shared__ __attribute__((aligned(16))) char smem[2 * T * 128];
     char* ks_ = smem;
     char* vs_ = smem + T * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
     sk_.store(ks_, nullptr, tid);
-    sv_.store(nullptr, vs_, tid);
+    sv_.store(vs_, nullptr, tid);
     __syncthreads();
 
     // one pass over the keys: cosine logits are bounded (|q^.k^| / 8 <= 8), so exp() needs no running maximum and every
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
             const bf16x8_t pa = pack8(a, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
+                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_rows(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -223,10 +239,10 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
                                                                  int H, float scale, const float* __restrict__ sq,
                                                                  bf16_t* __restrict__ dqkv) {
     using G = Geo<T>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 64 * G::VLD];
+    constexpr int SM = 2 * T * 128 > G::NW * WF_BYTES ? 2 * T * 128 : G::NW * WF_BYTES;   // operands | store buffers
+    __shared__ __attribute__((aligned(16))) char smem[SM];
     char* ks_ = smem;
     char* vs_ = smem + T * 128;
-    char* kts_ = smem + 2 * T * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const size_t bh = blockIdx.y;
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
         for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
     }
     const float lse_q = lse[bh * T + q0 + r];
-    sk_.store(ks_, kts_, tid);
+    sk_.store(ks_, nullptr, tid);
     sv_.store(vs_, nullptr, tid);
     const float del_q = del_p + __shfl_xor(del_p, 32, 64);
     if (h2 == 0) delta[bh * T + q0 + r] = del_q;       // consumed by the dK/dV pass (launched after this kernel)
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
             const bf16x8_t a = pack8(st, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr_rows(ks_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
         }
     }
     __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
@@ -299,6 +315,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
                                                                   float scale, const float* __restrict__ sk,
                                                                   bf16_t* __restrict__ dqkv) {
     using G = Geo<T>;
+    // (this pass keeps the transposed images: with four transposing reads per MFMA pair, their 2-way bank conflict on the
+    // 128-byte-row layout costs more than the images' staging - measured 252 vs 228 us)
     __shared__ __attribute__((aligned(16))) char smem[2 * T * 128 + 2 * 64 * G::VLD + 2 * T * 4];
     char* qs_ = smem;
     char* dos_ = smem + T * 128;
