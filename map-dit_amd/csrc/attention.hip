@@ -1,6 +1,6 @@
 // Cosine attention forward/backward on v_mfma_f32_32x32x16_bf16.
 // Replaces F.scaled_dot_product_attention(q^, k^, v, scale=1/sqrt(hd)) of reference src/layers/attention.py:47
-// and its autograd.  q^, k^ are already cosine-normalised (qkv_split_kernel), so logits lie in [-sqrt(hd), sqrt(hd)]
+// and its autograd.  q^, k^ are already cosine-normalised (QKV GEMM epilogue / qkv_split), so logits lie in [-sqrt(hd), sqrt(hd)]
 // and the softmax needs no running maximum: the whole key range of a head (T <= 256 tokens) is processed in one
 // sweep with S kept in registers.
 //
@@ -11,8 +11,9 @@
 //   backward dQ  S^T, dP^T = V dO^T -> dS^T -> dQ = (dS^T)^T K                              needs K^T  [d][key]
 //   backward dKV S = Q K^T (query on rows, key on lanes), dP = dO V^T -> dV = P^T dO, dK = dS^T Q
 //                                                                                  needs dO^T, Q^T [d][query]
-// Every operand is therefore read K-contiguous.  Transposed images are built in LDS while staging the row-major data
-// (16-byte global loads, 2-byte transposed LDS stores), so HBM holds each head tensor once, row-major.
+// Every operand is therefore read K-contiguous, while HBM holds each head tensor once, row-major: the forward and the dQ pass
+// take the transposed operand from the row-major LDS tile with transposing loads (ds_read_b64_tr_b16, frag_tr_rows); the
+// dK/dV pass builds transposed images in LDS while staging (16-byte global loads, 2-byte transposed LDS stores).
 // The backward is two passes (7 products instead of 5) so no cross-wave reduction and no atomics are needed:
 // attention is ~5 % of the block's FLOPs.
 #include <stdlib.h>

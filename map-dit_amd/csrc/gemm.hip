@@ -6,7 +6,9 @@
 //   NN  dx = dy W        A rows [M][K], B K-major [K][N]
 //   TN  dW = dy^T x      A K-major [K][M], B K-major [K][N]
 //
-// Structure: 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// Two kernels share the staging, fragment and epilogue code: gemm_mfma256_kernel (256x256x64 tile, 8 waves, used for every
+// token-sized problem; described at its definition) and gemm_mfma_kernel for small shapes, described here:
+// 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of
 // v_mfma_f32_16x16x32_bf16.  Operand tiles are staged HBM -> LDS with 16-byte global_load_lds
 // (LDS-DMA, no VGPR round trip) into two buffers, one barrier per K-tile, the next tile's DMA in flight
 // under the current tile's MFMAs.  The LDS image is lane-linear (a DMA constraint), so the bank-conflict
@@ -312,7 +314,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
 }
 
 // ---- the large-tile kernel: 256x256x64, 8 waves (2 M x 4 N, 128x64 per wave), one workgroup per CU ---------------
-// Staggered 8-phase schedule (guide §5 "The 256^2 8-phase template"), written against explicit hazard rules:
+// Staggered schedule after the guide's "256^2 8-phase template", written against explicit hazard rules.  The DEFAULT loop
+// runs TWO phases per K-tile (one 64-row half of the wave's output, 32 MFMAs, per phase; see the comment at the loop): with
+// ~130 cycles of barrier overhead per interval, 16-MFMA intervals capped the structure at 66 %.  The original four-phase loop
+// is kept behind MAPDIT_GEMM_PHASES=4 for A/B runs; the rules below are stated for it and carry over with "phase" read as
+// "half":
 //
 //  * LDS = 2 K-tile buffers x 4 half-tile slots {A0, A1, B0, B1} of 16 KiB (128 idx x 64 k, the same swizzled images
 //    as the 128^2 kernel).  Half h of the M side holds, for both wave rows, the wave's rows [64h, 64h+64); half h of
