@@ -234,9 +234,10 @@ typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
     int max_batch;
-    int precision;  /* MAPDIT_PREC_BF16: bf16 MFMA operands (training + inference).  MAPDIT_PREC_BF16X3: fp32-accurate
-                     * forward - fp32 activations, every GEMM on the same MFMA kernel with operands split into hi+lo bf16
-                     * terms (3x the GEMM work, inference engines only); logits agree with the fp32 reference to <1e-3. */
+    int precision;  /* MAPDIT_PREC_BF16: bf16 MFMA operands (the fast path).  MAPDIT_PREC_BF16X3: fp32-accurate forward AND
+                     * backward - fp32 activations and gradients, every product on the same MFMA kernel with both operands
+                     * split into hi+lo bf16 terms along the reduction index (3x the GEMM work, unfused fp32 pointwise and
+                     * attention kernels); logits, losses and parameter gradients agree with the fp32 reference to ~1e-5. */
 } mapdit_config_t;
 enum { MAPDIT_PREC_BF16 = 0, MAPDIT_PREC_BF16X3 = 1 };
 

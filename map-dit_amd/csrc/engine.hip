@@ -85,6 +85,16 @@ struct mapdit_engine {
         float *four, *h1, *t0, *qkv, *qn, *kn, *v, *o, *y, *h, *wtmp;
         bf16_t* As;                       // [rows][3K] split A operand of the next GEMM
     } px;
+    // bf16x3 training engines: per-block fp32 activations, K-major ([hi; lo; hi] stacked) weight images for the dX products,
+    // fp32 gradient scratch, stacked operand staging for the dW products
+    struct PBlock { float *xm, *qn, *kn, *v, *qks, *o, *y, *xm2, *h, *y2; };
+    std::vector<PBlock> pblk;
+    std::vector<bf16_t*> imgT;
+    struct {
+        float *xmodf, *patches, *dy, *dh, *dhact, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *P, *dS, *dlin, *da, *drefpart, *dtemb, *dh1,
+            *dh1act, *gpart;
+        bf16_t *AsT, *BsT;
+    } pg;
     long G_cap = 0;                       // floats available in G (split-K slabs)
     // optional HIP-event timing of one kernel family (bench.py roofline)
     int prof_which = -1;
@@ -180,7 +190,34 @@ size_t carve(mapdit_engine* e, void* base) {
         e->px.h = cv.take<float>(M * Hm);
         size_t amax = M * 3 * (size_t)(Hm > D ? Hm : D);
         if ((size_t)N * 3 * FOURIER > amax) amax = (size_t)N * 3 * FOURIER;
+        if (e->train && amax < M * 9 * (size_t)D) amax = M * 9 * (size_t)D;      // dqkv [M, 3D] split: [M, 9D]
         e->px.As = cv.take<bf16_t>(amax);
+        if (e->train) {
+            e->pblk.assign(L, mapdit_engine::PBlock());
+            for (int i = 0; i < L; ++i) {
+                auto& b = e->pblk[i];
+                b.xm = cv.take<float>(M * D); b.qn = cv.take<float>(M * D); b.kn = cv.take<float>(M * D); b.v = cv.take<float>(M * D);
+                b.qks = cv.take<float>((size_t)2 * N * c.num_heads * T);
+                b.o = cv.take<float>(M * D); b.y = cv.take<float>(M * D); b.xm2 = cv.take<float>(M * D);
+                b.h = cv.take<float>(M * Hm); b.y2 = cv.take<float>(M * D);
+            }
+            e->imgT.assign(np, nullptr);
+            for (int i = 0; i < np; ++i)
+                if (e->wimg[i].rows > 0) e->imgT[i] = cv.take<bf16_t>((size_t)3 * e->wimg[i].rows * e->wimg[i].cols);
+            auto& g = e->pg;
+            const size_t wide = (size_t)(Hm > 3 * D ? Hm : 3 * D);
+            g.xmodf = cv.take<float>(M * D); g.patches = cv.take<float>(M * e->ldp);
+            g.dy = cv.take<float>(M * D); g.dh = cv.take<float>(M * Hm); g.dhact = cv.take<float>(M * Hm); g.dxm = cv.take<float>(M * D);
+            g.dO = cv.take<float>(M * D); g.dqn = cv.take<float>(M * D); g.dkn = cv.take<float>(M * D); g.dv = cv.take<float>(M * D);
+            g.dqkv = cv.take<float>(M * 3 * D);
+            g.P = cv.take<float>((size_t)N * c.num_heads * T * T); g.dS = cv.take<float>((size_t)N * c.num_heads * T * T);
+            g.dlin = cv.take<float>(M * 2 * e->P); g.da = cv.take<float>((size_t)2 * N * NSCALE);
+            g.drefpart = cv.take<float>((size_t)N * 2 * NSCALE);
+            g.dtemb = cv.take<float>((size_t)N * D); g.dh1 = cv.take<float>((size_t)N * D); g.dh1act = cv.take<float>((size_t)N * D);
+            g.gpart = cv.take<float>((size_t)N * D);
+            g.AsT = cv.take<bf16_t>(3 * M * wide);
+            g.BsT = cv.take<bf16_t>(3 * M * (size_t)(Hm > e->ldp ? Hm : e->ldp));
+        }
     }
     if (e->train) {
         size_t gmax = (size_t)6 * D * D;
@@ -321,10 +358,6 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
 
 extern "C" size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int train) {
     if (check_cfg(cfg) != MAPDIT_OK) return 0;
-    if (train && cfg->precision != MAPDIT_PREC_BF16) {
-        mapdit_set_error("engine: precision bf16x3 is forward-only (inference engines)");
-        return 0;
-    }
     mapdit_engine tmp;
     tmp.cfg = *cfg;
     tmp.train = train;
@@ -336,7 +369,6 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
                                     mapdit_engine_t** out) {
     TRY(check_cfg(cfg));
     MD_CHECK(workspace && out, "engine_create: null argument");
-    MD_CHECK(!train || cfg->precision == MAPDIT_PREC_BF16, "engine: precision bf16x3 is forward-only (inference engines)");
     MD_CHECK(((uintptr_t)workspace & 255) == 0, "engine_create: workspace must be 256-byte aligned");
     mapdit_engine* e = new mapdit_engine();
     e->cfg = *cfg;
@@ -456,6 +488,8 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
         if (c.precision == MAPDIT_PREC_BF16X3) {   // fp32 effective weight -> [hi | lo | hi] image, K' = 3K
             TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, nullptr, e->px.wtmp, nullptr, st));
             TRY(mapdit_split3(e->px.wtmp, w.cols, w.img, w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
+            if (e->train)
+                TRY(mapdit_split3_stack(e->px.wtmp, w.cols, e->imgT[i], w.cols, w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
             continue;
         }
         TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, w.img, nullptr, nullptr, st));
@@ -468,7 +502,8 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
 
 // The fp32-accurate forward (see precise.hip): same sequence as mapdit_engine_forward, nothing fused, every linear as
 //   split(A) -> bf16 MFMA GEMM over K' = 3K -> fp32.
-static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, const int64_t* y_eff, int N, float* out, void* st) {
+static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, const int64_t* y_eff, int N, int save, float* out,
+                           void* st) {
     const mapdit_config_t& c = e->cfg;
     const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, ldm = e->ldm;
     const int M = N * T;
@@ -484,38 +519,178 @@ static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, c
     TRY(linear(px.four, N, FOURIER, NONE, MAPDIT_P_T0, D, px.h1, D));
     TRY(linear(px.h1, N, D, SILU, MAPDIT_P_T2, D, e->temb, D));
     TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));   // fp32 c; bf16 copies unused
+    if (save) {
+        hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
+        MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
+        TRY(mapdit_patchify32(x, e->pg.patches, e->ldp, N, c.in_channels, c.input_size, c.patch, st));
+    }
     TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], nullptr, e->ldp, N, c.in_channels, c.input_size,
                                c.patch, D, st));
     TRY(mapdit_split3(e->c, D, px.As, N, D, MAPDIT_SPLIT_A, SILU, st));
     TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, px.As, 3 * D, e->wimg[pidx_block(0, MAPDIT_B_MOD)].img, 3 * D, epi_f32(e->mod_all, ldm), st));
     TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_F_MOD].img, 3 * D, epi_f32(e->fmod, 2 * D), st));
-    float* xin = e->X[0];
-    float* xmid = e->X[1];
     for (int i = 0; i < L; ++i) {
         const float* mod = e->mod_all + (size_t)i * 6 * D;
+        // inference: two residual buffers ping-pong and one set of activations; training (save): everything the backward reads
+        // stays, in fp32 (X[2i] -> X[2i+1] -> X[2i+2] like the bf16 engine)
+        float* xin = save ? e->X[2 * i] : e->X[0];
+        float* xmid = save ? e->X[2 * i + 1] : e->X[1];
+        float* xout = save ? e->X[2 * i + 2] : e->X[0];
+        mapdit_engine::PBlock b;
+        if (save) b = e->pblk[i];
+        else { b.xm = px.t0; b.qn = px.qn; b.kn = px.kn; b.v = px.v; b.qks = nullptr; b.o = px.o; b.y = px.y; b.xm2 = px.t0; b.h = px.h; b.y2 = px.y; }
         // attention branch (dit_block.py:35)
-        TRY(mapdit_modulate32(xin, mod, mod + D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], px.t0, N, T, D, st));
-        TRY(linear(px.t0, M, D, NONE, pidx_block(i, MAPDIT_B_QKV), 3 * D, px.qkv, 3 * D));
-        TRY(mapdit_qkv_split32(px.qkv, N, T, H, e->hd, px.qn, px.kn, px.v, st));
-        TRY(mapdit_attn32(px.qn, px.kn, px.v, px.o, N, T, H, e->hd, st));
-        TRY(linear(px.o, M, D, NONE, pidx_block(i, MAPDIT_B_PROJ), D, px.y, D));
-        TRY(mapdit_resid32(xin, px.y, mod + 2 * D, ldm, xmid, N, T, D, 0.3f, st));
+        TRY(mapdit_modulate32(xin, mod, mod + D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], b.xm, N, T, D, st));
+        TRY(linear(b.xm, M, D, NONE, pidx_block(i, MAPDIT_B_QKV), 3 * D, px.qkv, 3 * D));
+        TRY(mapdit_qkv_split32(px.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, b.qks, st));
+        TRY(mapdit_attn32(b.qn, b.kn, b.v, b.o, N, T, H, e->hd, st));
+        TRY(linear(b.o, M, D, NONE, pidx_block(i, MAPDIT_B_PROJ), D, b.y, D));
+        TRY(mapdit_resid32(xin, b.y, mod + 2 * D, ldm, xmid, N, T, D, 0.3f, st));
         // MLP branch (dit_block.py:36)
-        TRY(mapdit_modulate32(xmid, mod + 3 * D, mod + 4 * D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], px.t0, N, T, D, st));
-        TRY(linear(px.t0, M, D, NONE, pidx_block(i, MAPDIT_B_FC1), Hm, px.h, Hm));
-        TRY(linear(px.h, M, Hm, SILU, pidx_block(i, MAPDIT_B_FC2), D, px.y, D));
-        TRY(mapdit_resid32(xmid, px.y, mod + 5 * D, ldm, xin, N, T, D, 0.3f, st));
+        TRY(mapdit_modulate32(xmid, mod + 3 * D, mod + 4 * D, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], b.xm2, N, T, D, st));
+        TRY(linear(b.xm2, M, D, NONE, pidx_block(i, MAPDIT_B_FC1), Hm, b.h, Hm));
+        TRY(linear(b.h, M, Hm, SILU, pidx_block(i, MAPDIT_B_FC2), D, b.y2, D));
+        TRY(mapdit_resid32(xmid, b.y2, mod + 5 * D, ldm, xout, N, T, D, 0.3f, st));
     }
     // final layer (final_layer.py:53-59)
-    TRY(mapdit_modulate32(xin, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], px.t0, N, T, D, st));
-    TRY(linear(px.t0, M, D, NONE, MAPDIT_P_F_LIN, 2 * e->P, e->lin, 2 * e->P));
+    float* xL = save ? e->X[2 * L] : e->X[0];
+    float* xmodf = save ? e->pg.xmodf : px.t0;
+    TRY(mapdit_modulate32(xL, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], xmodf, N, T, D, st));
+    TRY(linear(xmodf, M, D, NONE, MAPDIT_P_F_LIN, 2 * e->P, e->lin, 2 * e->P));
     TRY(mapdit_split3(e->c, D, px.As, N, D, MAPDIT_SPLIT_A, NONE, st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_MS_LIN].img, 3 * D, epi_f32(e->a_mean, NSCALE), st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_SS_LIN].img, 3 * D, epi_f32(e->a_sigma, NSCALE), st));
     TRY(mapdit_final_out_fwd(e->lin, 2 * e->P, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], out, N,
                              c.in_channels, c.input_size, c.patch, st));
     e->last_N = N;
+    e->next_stage = 0;
+    e->have_saved = save != 0;
+    return MAPDIT_OK;
+}
+
+// Backward of forward_precise, same stages as mapdit_engine_backward_stages.  Every product runs on the MFMA GEMM with both
+// operands split into two bf16 terms along the reduction index (dX = dY W: NN, dY split side by side, the weight image stacked;
+// dW = dY^T X: TN over the tokens, both operands stacked), everything else is the fp32 kernels of precise.hip.
+static int backward_precise(mapdit_engine* e, const float* dout, int stage_from, int stage_to, void* st) {
+    const mapdit_config_t& c = e->cfg;
+    const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, N = e->last_N, ldm = e->ldm;
+    const int M = N * T, P2 = 2 * e->P;
+    hipStream_t hs = (hipStream_t)st;
+    auto& px = e->px;
+    auto& pg = e->pg;
+    auto G = [&](int idx) { return e->grads[idx]; };
+    const int NONE = MAPDIT_SPLIT_OP_NONE, SILU = MAPDIT_SPLIT_OP_MPSILU;
+    // dx[rows, w.cols] (+)= dy[rows, w.rows] W
+    auto lin_dx = [&](const float* dy, int ld_dy, int rows, int widx, float* dx, int ldx, int acc) -> int {
+        const WeightImg& w = e->wimg[widx];
+        TRY(mapdit_split3(dy, ld_dy, px.As, rows, w.rows, MAPDIT_SPLIT_A, NONE, st));
+        return gemm(MAPDIT_NN, rows, w.cols, 3 * w.rows, px.As, 3 * w.rows, e->imgT[widx], w.cols, epi_f32(dx, ldx, 1.f, acc), st);
+    };
+    // grad W_idx = weight-norm Jacobian of dy^T op(x), reduction over `rows` tokens / samples
+    auto lin_dw = [&](int widx, const float* dy, int ld_dy, const float* x, int ld_x, int opx, int rows) -> int {
+        const WeightImg& w = e->wimg[widx];
+        TRY(mapdit_split3_stack(dy, ld_dy, pg.AsT, w.rows, rows, w.rows, MAPDIT_SPLIT_A, NONE, st));
+        TRY(mapdit_split3_stack(x, ld_x, pg.BsT, w.cols, rows, w.cols, MAPDIT_SPLIT_B, opx, st));
+        const long slab = (long)w.rows * w.cols;
+        mapdit_epilogue_t ep = epi_f32(e->G, w.cols, 1.f);
+        ep.split_k = pick_split_k(w.rows, w.cols, 3 * rows, e->G_cap / slab);
+        ep.slab_stride = slab;
+        TRY(gemm(MAPDIT_TN, w.rows, w.cols, 3 * rows, pg.AsT, w.rows, pg.BsT, w.cols, ep, st));
+        if (G(widx)) TRY(mapdit_weightnorm_bwd(e->params[widx], e->G, w.cols, ep.split_k, slab, G(widx), w.rows, w.cols, 1.f, 0, st));
+        return MAPDIT_OK;
+    };
+    auto rmb = [&](const float* dxo, const float* x, const float* shift, const float* scale, int ldmod, int gain_idx, float* dshift,
+                   float* dscale, int ldd, const float* y_up, const float* g_up, float* dg_up, float* dx) -> int {
+        mapdit_rmb32_t a; memset(&a, 0, sizeof(a));
+        a.dxo = dxo; a.dxm = pg.dxm; a.x = x; a.shift = shift; a.scale = scale; a.gain = e->params[gain_idx]; a.ldmod = ldmod;
+        a.dshift = dshift; a.dscale = dscale; a.ldd = ldd; a.gpart = pg.gpart;
+        a.y_up = y_up; a.g_up = g_up; a.ldg_up = ldm; a.dy_up = pg.dy; a.dg_up = dg_up; a.ldd_up = ldm;
+        a.dx = dx; a.N = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+        TRY(mapdit_rmb32(&a, st));
+        return mapdit_reduce_partials(pg.gpart, N * D, G(gain_idx), 0, st);
+    };
+
+    if (stage_from == 0) {
+        hipError_t he = hipMemsetAsync(e->dcs, 0, (size_t)N * D * 4, hs);
+        if (he == hipSuccess) he = hipMemsetAsync(e->dcd, 0, (size_t)N * D * 4, hs);
+        if (he == hipSuccess) he = hipMemsetAsync(e->dtable, 0, (size_t)c.table_rows * D * 4, hs);
+        MD_CHECK(he == hipSuccess, "engine_backward: memset failed: %s", hipGetErrorString(he));
+        MD_CHECK(G(MAPDIT_P_MS_REF) && G(MAPDIT_P_SS_REF), "engine_backward: gradient buffers not bound");
+        // final layer (final_layer.py:53-59, dit.py:96-101)
+        TRY(mapdit_final_out_bwd32(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF],
+                                   pg.dlin, P2, pg.da, pg.drefpart, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels,
+                                   c.input_size, c.patch, st));
+        for (int w = 0; w < 2; ++w) {
+            const int pi = w == 0 ? MAPDIT_P_MS_LIN : MAPDIT_P_SS_LIN;
+            const float* da = pg.da + (size_t)w * N * NSCALE;
+            TRY(lin_dx(da, NSCALE, N, pi, e->dcd, D, 1));
+            TRY(lin_dw(pi, da, NSCALE, e->c, D, NONE, N));
+        }
+        TRY(lin_dx(pg.dlin, P2, M, MAPDIT_P_F_LIN, pg.dxm, D, 0));
+        TRY(lin_dw(MAPDIT_P_F_LIN, pg.dlin, P2, pg.xmodf, D, NONE, M));
+        float* dmod_last = e->dmod + (size_t)(L - 1) * 6 * D;
+        TRY(rmb(nullptr, e->X[2 * L], e->fmod, e->fmod + D, 2 * D, MAPDIT_P_F_GAIN, e->dfmod, e->dfmod + D, 2 * D, e->pblk[L - 1].y2,
+                e->mod_all + (size_t)(L - 1) * 6 * D + 5 * D, dmod_last + 5 * D, e->DXa));
+        TRY(lin_dx(e->dfmod, 2 * D, N, MAPDIT_P_F_MOD, e->dcs, D, 1));
+        TRY(lin_dw(MAPDIT_P_F_MOD, e->dfmod, 2 * D, e->c, D, SILU, N));
+    }
+    // blocks, last to first.  Invariant: DXa = d/d X[2i+2]; pg.dy = grad of the MLP branch output y2_i
+    for (int i = L - 1; i >= 0; --i) {
+        const int stage = L - i;
+        if (stage < stage_from || stage > stage_to) continue;
+        const mapdit_engine::PBlock& b = e->pblk[i];
+        float* dmod = e->dmod + (size_t)i * 6 * D;
+        const float* mod = e->mod_all + (size_t)i * 6 * D;
+        const int iqkv = pidx_block(i, MAPDIT_B_QKV), iproj = pidx_block(i, MAPDIT_B_PROJ), ifc1 = pidx_block(i, MAPDIT_B_FC1),
+                  ifc2 = pidx_block(i, MAPDIT_B_FC2), imod = pidx_block(i, MAPDIT_B_MOD);
+        // MLP branch
+        TRY(lin_dx(pg.dy, D, M, ifc2, pg.dhact, Hm, 0));
+        TRY(mapdit_dsilu32(pg.dhact, b.h, pg.dh, (long)M * Hm, st));
+        TRY(lin_dw(ifc2, pg.dy, D, b.h, Hm, SILU, M));
+        TRY(lin_dx(pg.dh, Hm, M, ifc1, pg.dxm, D, 0));
+        TRY(lin_dw(ifc1, pg.dh, Hm, b.xm2, D, NONE, M));
+        TRY(rmb(e->DXa, e->X[2 * i + 1], mod + 3 * D, mod + 4 * D, ldm, pidx_block(i, MAPDIT_B_GAIN_MLP), dmod + 3 * D, dmod + 4 * D, ldm,
+                b.y, mod + 2 * D, dmod + 2 * D, e->DXb));
+        // attention branch: pg.dy now holds the grad of the attention branch output y_i
+        TRY(lin_dx(pg.dy, D, M, iproj, pg.dO, D, 0));
+        TRY(lin_dw(iproj, pg.dy, D, b.o, D, NONE, M));
+        TRY(mapdit_attn32_bwd(b.qn, b.kn, b.v, pg.dO, b.o, pg.P, pg.dS, pg.dqn, pg.dkn, pg.dv, N, T, H, e->hd, st));
+        TRY(mapdit_qkv_merge_bwd32(b.qn, b.kn, b.qks, pg.dqn, pg.dkn, pg.dv, pg.dqkv, N, T, H, e->hd, st));
+        TRY(lin_dx(pg.dqkv, 3 * D, M, iqkv, pg.dxm, D, 0));
+        TRY(lin_dw(iqkv, pg.dqkv, 3 * D, b.xm, D, NONE, M));
+        if (i > 0)
+            TRY(rmb(e->DXb, e->X[2 * i], mod, mod + D, ldm, pidx_block(i, MAPDIT_B_GAIN_MSA), dmod, dmod + D, ldm, e->pblk[i - 1].y2,
+                    mod - D, dmod - D, e->DXa));
+        else
+            TRY(rmb(e->DXb, e->X[0], mod, mod + D, ldm, pidx_block(i, MAPDIT_B_GAIN_MSA), dmod, dmod + D, ldm, nullptr, nullptr, nullptr,
+                    e->DXa));
+        // modulation linear of this block: its six gradient chunks are complete now
+        TRY(lin_dw(imod, dmod, ldm, e->c, D, SILU, N));
+        TRY(lin_dx(dmod, ldm, N, imod, e->dcs, D, 1));
+    }
+    e->next_stage = stage_to + 1;
+    if (stage_to < L + 1) return MAPDIT_OK;
+    // patch embedding: x0 = (x_embedder(patches) + pos) * C5; DXa = d/d X[0]
+    {
+        const float c5 = 0.70710678118654752f;
+        const long slab = (long)D * e->ldp;
+        TRY(mapdit_split3_stack(e->DXa, D, pg.AsT, D, M, D, MAPDIT_SPLIT_A, NONE, st));
+        TRY(mapdit_split3_stack(pg.patches, e->ldp, pg.BsT, e->ldp, M, e->ldp, MAPDIT_SPLIT_B, NONE, st));
+        mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5);
+        ep.split_k = pick_split_k(D, e->ldp, 3 * M, e->G_cap / slab);
+        ep.slab_stride = slab;
+        TRY(gemm(MAPDIT_TN, D, e->ldp, 3 * M, pg.AsT, D, pg.BsT, e->ldp, ep, st));
+        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
+    }
+    // conditioning path
+    TRY(mapdit_cond_combine_bwd32(e->c, e->dcs, e->dcd, e->y_copy, pg.dtemb, e->dtable, N, D, st));
+    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
+    TRY(lin_dx(pg.dtemb, D, N, MAPDIT_P_T2, pg.dh1act, D, 0));
+    TRY(mapdit_dsilu32(pg.dh1act, px.h1, pg.dh1, (long)N * D, st));
+    TRY(lin_dw(MAPDIT_P_T2, pg.dtemb, D, px.h1, D, SILU, N));
+    TRY(lin_dw(MAPDIT_P_T0, pg.dh1, D, px.four, FOURIER, NONE, N));
     e->have_saved = false;
+    e->next_stage = 0;
     return MAPDIT_OK;
 }
 
@@ -525,7 +700,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     MD_CHECK(N > 0 && N <= e->cfg.max_batch, "engine_forward: batch %d outside 1..%d", N, e->cfg.max_batch);
     MD_CHECK(!save || e->train, "engine_forward: save requested on an inference-only engine");
     const mapdit_config_t& c = e->cfg;
-    if (c.precision == MAPDIT_PREC_BF16X3) return forward_precise(e, x, t, y_eff, N, out, st);
+    if (c.precision == MAPDIT_PREC_BF16X3) return forward_precise(e, x, t, y_eff, N, save, out, st);
     const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads;
     const int M = N * T;
     auto W = [&](int idx) { return e->wimg[idx].img; };
@@ -605,6 +780,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
 extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long* elems, int* ld, int* dtype) {
     MD_CHECK(e && ptr && elems && ld && dtype, "engine_peek: null argument");
     MD_CHECK(e->have_saved && e->last_N > 0, "engine_peek: needs a forward with save=1 first");
+    MD_CHECK(e->cfg.precision == MAPDIT_PREC_BF16, "engine_peek: the intermediates listed are those of the bf16 engine");
     MD_CHECK(what >= 0 && what < MAPDIT_PEEK_COUNT, "engine_peek: unknown id %d", what);
     const bool per_block = what >= MAPDIT_PEEK_B_XM;
     MD_CHECK(!per_block || (block >= 0 && block < e->cfg.depth), "engine_peek: block %d outside 0..%d", block, e->cfg.depth - 1);
@@ -652,6 +828,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
              stage_from, stage_to);
     MD_CHECK(stage_from == e->next_stage, "engine_backward: stages must run in order (expected %d, got %d)", e->next_stage, stage_from);
     const mapdit_config_t& c = e->cfg;
+    if (c.precision == MAPDIT_PREC_BF16X3) return backward_precise(e, dout, stage_from, stage_to, st);
     const int D = e->D, T = e->T, Hm = e->Hm, L = c.depth, H = e->heads, N = e->last_N;
     const int M = N * T, P2 = 2 * e->P;
     hipStream_t hs = (hipStream_t)st;

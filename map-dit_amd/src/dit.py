@@ -282,8 +282,8 @@ class DiT(nn.Module):
         self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
 
-        self._rt = {}                 # {train (bool) | "bf16x3": _Runtime}
-        self.gemm_precision = "bf16"  # "bf16x3": fp32-accurate forward (inference only, ~3x slower), see mapdit.h
+        self._rt = {}                 # {train (bool) | ("bf16x3", train): _Runtime}
+        self.gemm_precision = "bf16"  # "bf16x3": fp32-accurate forward and backward (several times slower), see mapdit.h
         self._pflat = None            # flat fp32 storage behind every parameter (views)
         self._gflat = None            # flat gradient buffer, p.grad are views of it
         self._gviews = None
@@ -370,9 +370,7 @@ class DiT(nn.Module):
         precision = getattr(self, "gemm_precision", "bf16")
         if precision not in L.PRECISIONS:
             raise L.MapditError(f"gemm_precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
-        if precision != "bf16" and train:
-            raise L.MapditError(f"gemm_precision={precision!r} is forward-only: run it under torch.no_grad()")
-        slot = train if precision == "bf16" else precision
+        slot = train if precision == "bf16" else (precision, train)
         rt = self._rt.get(slot)
         if rt is None or rt.max_batch < batch or rt.device != self._pflat.device:
             if rt is not None:

@@ -84,6 +84,9 @@ def build_parser():
     p.add_argument("--num-lin-warmup", type=int, default=None)
     p.add_argument("--start-decay", type=int, default=None)
     p.add_argument("--ema-snapshot-every", type=int, default=None)
+    p.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
+                   help="GEMM operand precision: bf16 (fast path) or bf16x3 (fp32-accurate forward and backward, the reference's "
+                        "numerics to ~1e-5, several times slower)")
     for f in MP_FLAGS:
         p.add_argument(f"--use-{f}", dest="use_" + f.replace("-", "_"), action=argparse.BooleanOptionalAction, default=True)
     return p
@@ -132,6 +135,7 @@ def main(argv=None):
 
     diffusion = create_diffusion(timestep_respacing="")
     model = get_model(args).to(dev).train()
+    model.gemm_precision = args.precision
     log(f"model parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad):,}")
     if args.ema_snapshot_every is None:
         args.ema_snapshot_every = args.num_steps // 250
