@@ -194,13 +194,15 @@ int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift,
                        void* stream);
 int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
                             uint16_t* c_bf, int n, int D, void* stream);
+/* dtable [rows][D] += the label-embedding gradient (rows hit by several samples are summed in sample order: no atomics). */
 int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
                             float* dtable, int n, int D, void* stream);
 int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
                          const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream);
 int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
                          const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
-                         float* dref_mean, float* dref_sigma, int N, int C, int S, int p, void* stream);
+                         float* dref_part /* scratch [N][2][8] */, float* dref_mean /* [8], += */, float* dref_sigma,
+                         int N, int C, int S, int p, void* stream);
 /* DiT.forward_with_cfg tail (src/dit.py:113-118). */
 int mapdit_cfg_combine(const float* model_out, float* out, int n_total, int C, int HW, float cfg_scale, void* stream);
 

@@ -85,7 +85,7 @@ _SIGS = {
     "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
     "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
     "mapdit_final_out_fwd": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_cfg_combine": [vp, vp, ci, ci, ci, cf, vp],
     "mapdit_q_sample": [vp, vp, vp, vp, ci, vp, ci, ci, vp],
     "mapdit_loss_fwd": [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp],

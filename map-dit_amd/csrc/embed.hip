@@ -82,15 +82,26 @@ __global__ void cond_combine_kernel(const float* __restrict__ temb, const float*
 }
 
 // Backward of the above: dc = dcs * dmpsilu(c) + dc_direct;  dtemb = C5*dc (bf16 operand);  dtable[y] += C5*dc.
+// No atomics (bit-reproducible steps): the FIRST sample that carries a label owns that table row and adds the contributions
+// of every sample with the same label in sample order.  Grid: (D / 256, n).
 __global__ void cond_combine_bwd_kernel(const float* __restrict__ c, const float* __restrict__ dcs, const float* __restrict__ dcd,
                                         const long* __restrict__ y, bf16_t* __restrict__ dtemb, float* __restrict__ dtable,
                                         int n, int D) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * D) return;
-    const int b = i / D, d = i % D;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (d >= D) return;
+    const int i = b * D + d;
     const float dc = (dcs[i] * dmpsilu_f(c[i]) + dcd[i]) * C5;
     dtemb[i] = f2bf(dc);
-    atomicAdd(dtable + (size_t)y[b] * D + d, dc);
+    const long label = y[b];
+    for (int o = 0; o < b; ++o)
+        if (y[o] == label) return;                       // an earlier sample owns this row (uniform over the block)
+    float sum = dc;
+    for (int o = b + 1; o < n; ++o)
+        if (y[o] == label) {
+            const int k = o * D + d;
+            sum += (dcs[k] * dmpsilu_f(c[k]) + dcd[k]) * C5;
+        }
+    dtable[(size_t)label * D + d] += sum;
 }
 
 // ---- final layer tail: MPScale gates + unpatchify + concat (final_layer.py:20-22,57-59; dit.py:96-101) ---------------
@@ -118,13 +129,13 @@ __global__ void final_out_kernel(const float* __restrict__ lin, int ldl, const f
 }
 
 // Backward: one block per sample.  dlin [M][ldd] bf16 = dout*gate (patchified; columns >= 2P stay zero),
-// da_*[n][8] (bf16 operand + fp32), dref_* accumulated atomically over samples.
+// da_*[n][8] (bf16 operand); the per-sample terms of dref_* go to dref_part [N][2][8] and are added in sample order by
+// sum_dref_kernel (no atomics: bit-reproducible steps).
 __global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ lin, int ldl,
                                                           const float* __restrict__ a_mean, const float* __restrict__ a_sigma,
                                                           const float* __restrict__ ref_mean, const float* __restrict__ ref_sigma,
                                                           bf16_t* __restrict__ dlin, int ldd, bf16_t* __restrict__ da_bf,
-                                                          float* __restrict__ dref_mean, float* __restrict__ dref_sigma,
-                                                          int C, int S, int p) {
+                                                          float* __restrict__ dref_part, int C, int S, int p) {
     __shared__ float red[2][4];
     const int n = blockIdx.x;
     const int grid = S / p, P = p * p * C, T = grid * grid;
@@ -152,8 +163,15 @@ __global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restr
         const float* ref = which == 0 ? ref_mean : ref_sigma;
         const float* a = (which == 0 ? a_mean : a_sigma) + n * 8;
         da_bf[((size_t)which * gridDim.x + n) * 8 + j] = f2bf(dang * ref[j]);
-        atomicAdd((which == 0 ? dref_mean : dref_sigma) + j, dang * a[j]);
+        dref_part[((size_t)n * 2 + which) * 8 + j] = dang * a[j];
     }
+}
+__global__ void sum_dref_kernel(const float* __restrict__ part, int N, float* __restrict__ dref_mean, float* __restrict__ dref_sigma) {
+    const int which = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (threadIdx.x >= 16) return;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += part[((size_t)n * 2 + which) * 8 + j];
+    (which == 0 ? dref_mean : dref_sigma)[j] += a;
 }
 
 // forward_with_cfg tail (reference src/dit.py:113-118): eps = u + s (c - u) on the first C channels, both halves.
@@ -214,7 +232,7 @@ extern "C" int mapdit_cond_combine_fwd(const float* temb, const float* table, co
 extern "C" int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
                                        float* dtable, int n, int D, void* stream) {
     MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0, "cond_combine_bwd: null/empty argument");
-    hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3(cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd,
+    hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd,
                        (const long*)y, dtemb, dtable, n, D);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
@@ -232,11 +250,14 @@ extern "C" int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_me
 
 extern "C" int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
                                     const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
-                                    float* dref_mean, float* dref_sigma, int N, int C, int S, int p, void* stream) {
-    MD_CHECK(dout && lin && a_mean && a_sigma && ref_mean && ref_sigma && dlin && da_bf && dref_mean && dref_sigma,
+                                    float* dref_part, float* dref_mean, float* dref_sigma, int N, int C, int S, int p,
+                                    void* stream) {
+    MD_CHECK(dout && lin && a_mean && a_sigma && ref_mean && ref_sigma && dlin && da_bf && dref_part && dref_mean && dref_sigma,
              "final_out_bwd: null argument");
     hipLaunchKernelGGL(final_out_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dout, lin, ldl, a_mean, a_sigma,
-                       ref_mean, ref_sigma, dlin, ldd, da_bf, dref_mean, dref_sigma, C, S, p);
+                       ref_mean, ref_sigma, dlin, ldd, da_bf, dref_part, C, S, p);
+    MD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_dref_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dref_part, N, dref_mean, dref_sigma);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

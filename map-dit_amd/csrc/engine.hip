@@ -72,7 +72,7 @@ struct mapdit_engine {
     int ldm;                              // = L*6D
     bf16_t* xmodf;
     // backward scratch
-    float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part;
+    float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part, *dref_part;
     bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
     // one-launch weight pass: job table (host copy + device copy in the workspace), rebuilt by engine_bind
@@ -247,6 +247,7 @@ size_t carve(mapdit_engine* e, void* base) {
         e->dlin = cv.take<bf16_t>(M * e->ldl);
         e->zero_bytes_dlin = M * e->ldl * sizeof(bf16_t);
         e->da_bf = cv.take<bf16_t>((size_t)2 * N * NSCALE);
+        e->dref_part = cv.take<float>((size_t)2 * N * NSCALE);
         e->dmod_bf = cv.take<bf16_t>((size_t)N * L * 6 * D);
         e->dx0_bf = cv.take<bf16_t>(M * D);
         e->dtemb_bf = cv.take<bf16_t>((size_t)N * D);
@@ -847,7 +848,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
 
     // ---- final layer ---------------------------------------------------------------------------------------
     TRY(mapdit_final_out_bwd(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], e->dlin,
-                             e->ldl, e->da_bf, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size, c.patch, st));
+                             e->ldl, e->da_bf, e->dref_part, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size,
+                             c.patch, st));
     for (int w = 0; w < 2; ++w) {
         const int pi = w == 0 ? MAPDIT_P_MS_LIN : MAPDIT_P_SS_LIN;
         const bf16_t* da = e->da_bf + (size_t)w * N * NSCALE;

@@ -348,18 +348,26 @@ __global__ void sum_dref_kernel(const float* __restrict__ part, int N, float* __
     for (int n = 0; n < N; ++n) a += part[((size_t)n * 2 + which) * 8 + j];
     (which == 0 ? dref_mean : dref_sigma)[j] = a;
 }
-// dc = (dcs dmpsilu(c) + dcd) C5 ; dtemb = dc (fp32) ; dtable[y[b]] += dc, rows visited in sample order by one thread per column
+// dc = (dcs dmpsilu(c) + dcd) C5 ; dtemb = dc (fp32) ; dtable[y[b]] += dc: the first sample that carries a label owns the row and
+// adds every sample with that label in sample order (as cond_combine_bwd_kernel in embed.hip).  Grid: (D / 256, n).
 __global__ void cond_combine_bwd32_kernel(const float* __restrict__ c, const float* __restrict__ dcs, const float* __restrict__ dcd,
                                           const long* __restrict__ y, float* __restrict__ dtemb, float* __restrict__ dtable, int n,
                                           int D) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (d >= D) return;
-    for (int b = 0; b < n; ++b) {
-        const int i = b * D + d;
-        const float dc = (dcs[i] * dmpsilu_exact(c[i]) + dcd[i]) * 0.70710678118654752f;
-        dtemb[i] = dc;
-        dtable[(size_t)y[b] * D + d] += dc;
-    }
+    const int i = b * D + d;
+    const float dc = (dcs[i] * dmpsilu_exact(c[i]) + dcd[i]) * 0.70710678118654752f;
+    dtemb[i] = dc;
+    const long label = y[b];
+    for (int o = 0; o < b; ++o)
+        if (y[o] == label) return;
+    float sum = dc;
+    for (int o = b + 1; o < n; ++o)
+        if (y[o] == label) {
+            const int k = o * D + d;
+            sum += (dcs[k] * dmpsilu_exact(c[k]) + dcd[k]) * 0.70710678118654752f;
+        }
+    dtable[(size_t)label * D + d] += sum;
 }
 // patchify + ones column as fp32 [M][ldp] (zero padded): the x operand of the x_embedder weight gradient
 __global__ void patchify32_kernel(const float* __restrict__ x, float* __restrict__ patches, int ldp, int C, int S, int p, long M) {
@@ -437,7 +445,10 @@ int mapdit_final_out_bwd32(const float* dout, const float* lin, int ldl, const f
 int mapdit_cond_combine_bwd32(const float* c, const float* dcs, const float* dcd, const int64_t* y, float* dtemb, float* dtable, int n,
                               int D, void* stream) {
     MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0, "cond_combine_bwd32: bad argument");
-    P32_LAUNCH(cond_combine_bwd32_kernel, D, c, dcs, dcd, (const long*)y, dtemb, dtable, n, D);
+    hipLaunchKernelGGL(cond_combine_bwd32_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd, (const long*)y,
+                       dtemb, dtable, n, D);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
 }
 int mapdit_patchify32(const float* x, float* patches, int ldp, int N, int C, int S, int p, void* stream) {
     MD_CHECK(x && patches && N > 0, "patchify32: bad argument");

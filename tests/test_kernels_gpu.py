@@ -622,9 +622,10 @@ def test_final_out(L, p_, S):
     dlin = torch.zeros(N * T, ldd, device=DEV, dtype=torch.bfloat16)
     da = torch.zeros(2, N, 8, device=DEV, dtype=torch.bfloat16)
     drm, drs = torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
+    part = torch.zeros(N, 2, 8, device=DEV)
     dd = dout.to(DEV).contiguous()
-    L.lib().final_out_bwd(p(dd), p(d[0]), 2 * P, p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(dlin), ldd, p(da), p(drm), p(drs),
-                          N, C_, S, p_, st())
+    L.lib().final_out_bwd(p(dd), p(d[0]), 2 * P, p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(dlin), ldd, p(da), p(part), p(drm),
+                          p(drs), N, C_, S, p_, st())
     torch.cuda.synchronize()
     assert rel_err(dlin[:, :2 * P].float().cpu().numpy(), l_.grad.numpy()) < 3e-3
     assert rel_err(da[0].float().cpu().numpy(), a1.grad.numpy()) < 4e-3
