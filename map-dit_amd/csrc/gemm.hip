@@ -109,6 +109,13 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, 
 
 // ---- epilogues ----------------------------------------------------------------------------------------
 // operator()(m, n, v): v[0..7] are C[m][n..n+7]; n is a multiple of 8 and the chunk is fully in range.
+// The 256^2 kernel calls the three-step form so that what an epilogue READS does not sit on its critical path (measured: with
+// the reads inside the per-chunk call, 16 dependent memory round trips per tile made the DSILU / RESID epilogues 2x longer than
+// their traffic):  tile_begin(m_first, m_last, n) once per thread and tile - per-column operands that are the same for every row
+// of the tile;  load(m, n) - the per-chunk stream operand, issued for a whole pass of 8 chunks before any of them is used;
+// apply(m, n, v, z, aux, tile) - arithmetic and stores.
+struct EpiNoAux {};
+struct EpiNoTile {};
 // Epilogue outputs are streams far larger than the L2 that nothing re-reads soon: non-temporal stores (`nt`) so that the
 // output stream is first in line for eviction and does not push out the operand panels the XCD's other workgroups still read.
 // (An `sc1` write-through store, which does not keep the line in L2 at all, was 5 % faster still but let a following kernel
@@ -128,8 +135,15 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // 
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+#define EPI_TRIVIAL_STEPS                                                                                      \
+    typedef EpiNoAux Aux;                                                                                      \
+    typedef EpiNoTile Tile;                                                                                    \
+    __device__ __forceinline__ Tile tile_begin(int, int, int) const { return Tile(); }                         \
+    __device__ __forceinline__ Aux load(int, int) const { return Aux(); }                                      \
+    __device__ __forceinline__ void apply(int m, int n, const float* v, int z, const Aux&, const Tile&) const { (*this)(m, n, v, z); }
 struct EpiStoreBf16 {
     bf16_t* out; int ldo; float alpha;
+    EPI_TRIVIAL_STEPS
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float w[8];
 #pragma unroll
@@ -139,6 +153,7 @@ struct EpiStoreBf16 {
 };
 struct EpiStoreF32 {
     float* out; int ldo; float alpha; int accumulate; long slab_stride;
+    EPI_TRIVIAL_STEPS
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int z = 0) const {
         float4* p = (float4*)(out + (size_t)z * slab_stride + (size_t)m * ldo + n);
         float4 a = make_float4(alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]);
@@ -155,6 +170,7 @@ struct EpiStoreF32 {
 // profiles of the dominant fc1 GEMM are not diluted by the [batch x D] launch.
 template <int TAG> struct EpiSilu2 {
     bf16_t* pre; bf16_t* act; int ldo;
+    EPI_TRIVIAL_STEPS
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float a[8];
 #pragma unroll
@@ -167,6 +183,57 @@ struct EpiResid {
     bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
     // optional fused modulate of the NEXT branch (src/utils.py:11-16): xm = bf16(((1-g) xout scale + g shift) / den)
     bf16_t* xm; const float* nshift; const float* nscale; const float* ngain; int ldn;
+    struct Aux { float4 x0, x1; };
+    struct Tile { float4 g0, g1, c0, c1, h0, h1; float ka, kb; int smp; };     // smp < 0: rows of several samples in the tile
+    __device__ __forceinline__ void per_sample(int smp, int n, Tile& t) const {
+        const float4* g = (const float4*)(gate + (size_t)smp * ldg + n);
+        t.g0 = g[0]; t.g1 = g[1];
+        if (xm) {
+            const float4* sc = (const float4*)(nscale + (size_t)smp * ldn + n);
+            const float4* sh = (const float4*)(nshift + (size_t)smp * ldn + n);
+            t.c0 = sc[0]; t.c1 = sc[1]; t.h0 = sh[0]; t.h1 = sh[1];
+        }
+    }
+    __device__ __forceinline__ Tile tile_begin(int m_first, int m_last, int n) const {
+        Tile t;
+        t.smp = m_first / rows == m_last / rows ? m_first / rows : -1;
+        t.ka = t.kb = 0.f;
+        if (xm) {
+            const float gg = *ngain, den = sqrtf((1.f - gg) * (1.f - gg) + gg * gg);
+            t.ka = (1.f - gg) / den; t.kb = gg / den;
+        }
+        if (t.smp >= 0) per_sample(t.smp, n, t);
+        return t;
+    }
+    __device__ __forceinline__ Aux load(int m, int n) const {
+        const float4* xi = (const float4*)(xin + (size_t)m * ldo + n);
+        Aux a; a.x0 = xi[0]; a.x1 = xi[1];
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile& tc) const {
+        Tile t = tc;
+        if (tc.smp < 0) per_sample(m / rows, n, t);
+        const float4 g0 = t.g0, g1 = t.g1, x0 = a.x0, x1 = a.x1;
+        float o[8];
+        o[0] = ca * x0.x + cb * g0.x * v[0]; o[1] = ca * x0.y + cb * g0.y * v[1];
+        o[2] = ca * x0.z + cb * g0.z * v[2]; o[3] = ca * x0.w + cb * g0.w * v[3];
+        o[4] = ca * x1.x + cb * g1.x * v[4]; o[5] = ca * x1.y + cb * g1.y * v[5];
+        o[6] = ca * x1.z + cb * g1.z * v[6]; o[7] = ca * x1.w + cb * g1.w * v[7];
+        float4* xo = (float4*)(xout + (size_t)m * ldo + n);
+        xo[0] = make_float4(o[0], o[1], o[2], o[3]);
+        xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+        if (y) store8_bf16(y + (size_t)m * ldo + n, v);
+        if (xm) {
+            const float ka = t.ka, kb = t.kb;
+            const float4 c0 = t.c0, c1 = t.c1, h0 = t.h0, h1 = t.h1;
+            float w[8];
+            w[0] = ka * o[0] * c0.x + kb * h0.x; w[1] = ka * o[1] * c0.y + kb * h0.y;
+            w[2] = ka * o[2] * c0.z + kb * h0.z; w[3] = ka * o[3] * c0.w + kb * h0.w;
+            w[4] = ka * o[4] * c1.x + kb * h1.x; w[5] = ka * o[5] * c1.y + kb * h1.y;
+            w[6] = ka * o[6] * c1.z + kb * h1.z; w[7] = ka * o[7] * c1.w + kb * h1.w;
+            store8_bf16(xm + (size_t)m * ldo + n, w);
+        }
+    }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         const int smp = m / rows;
         const float4* g = (const float4*)(gate + (size_t)smp * ldg + n);
@@ -198,6 +265,24 @@ struct EpiResid {
 };
 struct EpiDSilu {
     bf16_t* out; const bf16_t* pre; int ldo;
+    struct Aux { u32x4_t h; };
+    typedef EpiNoTile Tile;
+    __device__ __forceinline__ Tile tile_begin(int, int, int) const { return Tile(); }
+    __device__ __forceinline__ Aux load(int m, int n) const {
+        Aux a; a.h = __builtin_nontemporal_load((const u32x4_t*)(pre + (size_t)m * ldo + n));
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile&) const {
+        const u32x4_t u = a.h;
+        float h[8], w[8];
+        h[0] = __uint_as_float(u.x << 16); h[1] = __uint_as_float(u.x & 0xffff0000u);
+        h[2] = __uint_as_float(u.y << 16); h[3] = __uint_as_float(u.y & 0xffff0000u);
+        h[4] = __uint_as_float(u.z << 16); h[5] = __uint_as_float(u.z & 0xffff0000u);
+        h[6] = __uint_as_float(u.w << 16); h[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = v[i] * dmpsilu_f(h[i]);
+        store8_bf16(out + (size_t)m * ldo + n, w);
+    }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float h[8], w[8];
         load8_bf16(pre + (size_t)m * ldo + n, h);
@@ -212,6 +297,7 @@ struct EpiDSilu {
 // xor-shuffles.  (which, head) are uniform over those 8 lanes; the row's predicate too.
 struct EpiQkvHeads {
     bf16_t *qn, *kn, *v; float* s; int T, H;          // D = 64 H
+    EPI_TRIVIAL_STEPS
     __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
         const int D = 64 * H;
         const int which = n / D, c = n - which * D, h = c >> 6, d = c & 63;
@@ -580,6 +666,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
 
     // epilogue: two passes of 128 rows through LDS, then whole 8-column row chunks per thread
     float* cs = (float*)smem;
+    const int ecol = (tid & 31) * 8, gn = n0 + ecol;
+    const bool col_ok = gn < p.N;
+    typename Epi::Tile tctx;
+    if (col_ok) tctx = epi.tile_begin(m0, (m0 + BM2 <= p.M ? m0 + BM2 : p.M) - 1, gn);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -590,16 +680,23 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
                 const int col = wn * 64 + j * 16 + 4 * (lane >> 4);
                 *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
             }
+        typename Epi::Aux aux[8];                          // (after the accumulators of this pass are dead: register budget)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                   // the pass's stream operands: all in flight before the first use
+            const int row = (tid >> 5) + 16 * it;
+            const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
+            if (gm < p.M && col_ok) aux[it] = epi.load(gm, gn);
+        }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int row = (tid >> 5) + 16 * it, col = (tid & 31) * 8;
-            const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63), gn = n0 + col;
-            if (gm < p.M && gn < p.N) {
+            const int row = (tid >> 5) + 16 * it;
+            const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
+            if (gm < p.M && col_ok) {
                 float v[8];
-                *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + col);
-                *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + col + 4);
-                epi(gm, gn, v, z);
+                *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + ecol);
+                *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
+                epi.apply(gm, gn, v, z, aux[it], tctx);
             }
         }
         __syncthreads();
