@@ -432,15 +432,24 @@ constexpr int SMEM2_BYTES = 128 * CS2_LD * 4;             // 133,120 B >= 2 x 64
 // stamps out when the tile is done.
 constexpr int STAMP_TILES = 12, STAMP_POINTS = 11;
 __device__ long long* g_stamps = nullptr;
-extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p) { g_stamps = p; }
+__device__ int g_stamp_block = -1;
+extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int block) { g_stamps = p; g_stamp_block = block; }
 #define G256_STAMP(PT)                                                                              \
     if (stamp_on && t < STAMP_TILES) {                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         stamp_lds[(wm * STAMP_TILES + t) * STAMP_POINTS + (PT)] = (long long)__builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
+// whole-tile stamps (wave 0): 0 = workgroup entry, 1 = K loop starts, 2 = K loop done, 3 = epilogue pass 0 done, 4 = epilogue done
+#define G256_TSTAMP(IDX)                                                                            \
+    if (stamp_on && wave == 0) {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
 #else
 #define G256_STAMP(PT)
+#define G256_TSTAMP(IDX)
 #endif
 
 template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
@@ -486,7 +495,7 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
 template <int AK, int BK, class Epi, bool KTAIL = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
 #ifdef MAPDIT_GEMM_STAMPS
-    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES + 2 * STAMP_TILES * STAMP_POINTS * 8];
+    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES + (2 * STAMP_TILES * STAMP_POINTS + 8) * 8];
     long long* stamp_lds = (long long*)(smem + SMEM2_BYTES);
 #else
     __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
@@ -495,8 +504,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;               // wm doubles as the stagger group (waves 4-7 run behind)
 #ifdef MAPDIT_GEMM_STAMPS
-    const bool stamp_on = g_stamps && blockIdx.x == 8 && (wave == 0 || wave == 4) && lane == 0;
+    const bool stamp_on = g_stamps && blockIdx.x == (g_stamp_block >= 0 ? g_stamp_block : 8) && (wave == 0 || wave == 4) && lane == 0;
 #endif
+    G256_TSTAMP(0);
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -569,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     // DMA issue order per wave: ... A1[t+1] (phase 1 of tile t), A0[t+2] (2), B0[t+2] (3), B1[t+2] (4), A1[t+2] ...
     // Every wait leaves the five youngest half-tiles in flight (vmcnt(10)) and retires what the NEXT phase reads:
     //   phase 1 -> B1[t] (read in 2)   phase 2 -> A1[t] (read in 3)   phase 4 -> A0[t+1], B0[t+1] (read in 1 of t+1)
+    G256_TSTAMP(1);
     if (p.phases == 2) {
         // Two phases per K-tile: 32 MFMAs (512 cycles) per MFMA interval, half as many barriers.  Phase A reads A0, B0, B1
         // of tile t and computes the upper half (quadrants (0,0), (0,1)); phase B reads A1 and computes the lower half from
@@ -663,6 +674,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    G256_TSTAMP(2);
 
     // epilogue: two passes of 128 rows through LDS, then whole 8-column row chunks per thread
     float* cs = (float*)smem;
@@ -700,7 +712,12 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             }
         }
         __syncthreads();
+        G256_TSTAMP(3 + pass);
     }
+#ifdef MAPDIT_GEMM_STAMPS
+    if (stamp_on && wave == 0)
+        for (int i = 0; i < 8; ++i) g_stamps[2 * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[2 * STAMP_TILES * STAMP_POINTS + i];
+#endif
 }
 
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
@@ -727,7 +744,11 @@ __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long 
 // token-sized problems, 128 for small ones (conditioning path, final linear).  Exposed so callers can size split-K.
 #ifdef MAPDIT_GEMM_STAMPS
 extern "C" void mapdit_debug_set_stamps(long long* p) {
-    hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p);
+    hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p, -1);
+    (void)hipDeviceSynchronize();
+}
+extern "C" void mapdit_debug_set_stamps_block(long long* p, int block) {      // stamp workgroup `block` instead of 8
+    hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p, block);
     (void)hipDeviceSynchronize();
 }
 #endif

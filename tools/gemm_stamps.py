@@ -37,7 +37,7 @@ def main():
     lib.mapdit_gemm_bf16.restype = C.c_int
     lib.mapdit_last_error.restype = C.c_char_p
     TILES, PTS = 12, 11
-    stamps = torch.zeros(2 * TILES * PTS, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(2 * TILES * PTS + 8, dtype=torch.int64, device="cuda")
     # set the device-side pointer through the tiny setter kernel
     mod_launch = getattr(lib, "mapdit_debug_set_stamps", None)
     assert mod_launch is not None, "stamp build lacks mapdit_debug_set_stamps"
@@ -63,13 +63,36 @@ def main():
                 rc = lib.mapdit_gemm_bf16(2, 4 * D, D, M, dh.data_ptr(), 4 * D, x.data_ptr(), D, C.byref(e), st)
             assert rc == 0, lib.mapdit_last_error()
         torch.cuda.synchronize()
-        s = stamps.cpu().view(2, TILES, PTS)
+        s = stamps.cpu()[:2 * TILES * PTS].view(2, TILES, PTS)
         print(f"== {label}: cycles per K-tile section (median over K-tiles 2..{TILES - 1}), wave group 0 | 1")
         for i, nm in enumerate(names):
             d = (s[:, 2:, i + 1] - s[:, 2:, i]).float()
             print(f"   {nm:12s} {d[0].median().item():7.0f} | {d[1].median().item():7.0f}")
         per = (s[:, 3:, 0] - s[:, 2:-1, 0]).float()
         print(f"   K-tile total {per[0].median().item():7.0f} | {per[1].median().item():7.0f}   (MFMA issue alone: 2 x 512)")
+    # whole-tile timeline of the forward shape (NT [65536,768] x [3072,768]^T, 12 K-tiles per output tile, 12 rounds of tiles):
+    # where the time of one tile goes outside the K loop, for a first-round workgroup and for later ones
+    setb = lib.mapdit_debug_set_stamps_block
+    setb.argtypes = [C.c_void_p, C.c_int]
+    xa, wb = rnd(M, D), rnd(4 * D, D)
+    o2 = torch.empty(M, 4 * D, device="cuda", dtype=torch.bfloat16)
+    o3 = torch.empty(M, 4 * D, device="cuda", dtype=torch.bfloat16)
+    for kind in ("bf16 store", "SiLU dual store"):
+        for blk in (8, 1032, 2056):
+            setb(stamps.data_ptr(), blk)
+            e = L.Epilogue()
+            if kind == "bf16 store":
+                e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, o2.data_ptr(), 4 * D, 1.0
+            else:
+                e.kind, e.out, e.out2, e.ldo = L.EPI_SILU2, o2.data_ptr(), o3.data_ptr(), 4 * D
+            for _ in range(3):
+                rc = lib.mapdit_gemm_bf16(0, M, 4 * D, D, xa.data_ptr(), D, wb.data_ptr(), D, C.byref(e), st)
+                assert rc == 0, lib.mapdit_last_error()
+            torch.cuda.synchronize()
+            tt = stamps.cpu()[2 * TILES * PTS:]
+            d = [int(tt[i + 1] - tt[i]) for i in range(4)]
+            print(f"== NT fc1 shape, {kind}, workgroup {blk}: cycles  fill (entry -> K loop) {d[0]}  K loop (12 tiles) {d[1]}  "
+                  f"epilogue pass 0 {d[2]}  pass 1 {d[3]}  | total {int(tt[4] - tt[0])}")
 
 
 if __name__ == "__main__":
