@@ -147,7 +147,8 @@ size_t carve(mapdit_engine* e, void* base) {
     const int nx = e->train ? 2 * L + 1 : 3;
     e->X.assign(nx, nullptr);
     for (int i = 0; i < nx; ++i) e->X[i] = cv.take<float>(M * D);
-    const int nb = e->train ? L : 1;
+    // bf16 activations of the fast path (a bf16x3 engine keeps fp32 ones instead: px / pblk below)
+    const int nb = precise ? 0 : (e->train ? L : 1);
     e->blk.assign(nb, BlockBufs());
     for (int i = 0; i < nb; ++i) {
         BlockBufs& b = e->blk[i];
@@ -165,14 +166,14 @@ size_t carve(mapdit_engine* e, void* base) {
         b.y2 = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.lse = cv.take<float>((size_t)N * c.num_heads * T);
     }
-    e->patches = e->train ? cv.take<bf16_t>(M * e->ldp) : nullptr;
+    e->patches = e->train && !precise ? cv.take<bf16_t>(M * e->ldp) : nullptr;
     e->fmod = cv.take<float>((size_t)N * 2 * D);
     e->mod_all = cv.take<float>((size_t)N * L * 6 * D);
     e->ldm = L * 6 * D;
     e->lin = cv.take<float>(M * 2 * e->P);
     e->a_mean = cv.take<float>((size_t)N * NSCALE);
     e->a_sigma = cv.take<float>((size_t)N * NSCALE);
-    e->xmodf = cv.take<bf16_t>(M * D);
+    e->xmodf = precise ? nullptr : cv.take<bf16_t>(M * D);
     if (precise) {
         size_t wmax = (size_t)6 * D * D;
         if ((size_t)Hm * D > wmax) wmax = (size_t)Hm * D;
@@ -234,6 +235,10 @@ size_t carve(mapdit_engine* e, void* base) {
         e->dcs = cv.take<float>((size_t)N * D);
         e->dcd = cv.take<float>((size_t)N * D);
         e->dtable = cv.take<float>((size_t)c.table_rows * D);
+        e->zero_bytes_dlin = 0;
+        e->dlin = nullptr;
+    }
+    if (e->train && !precise) {                            // bf16 gradient operands of the fast path
         e->delta = cv.take<float>((size_t)N * c.num_heads * T);
         e->gain_part = cv.take<float>((size_t)N * (D / 128));
         e->dy = cv.take<bf16_t>(M * D);
@@ -388,7 +393,7 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     const WeightImg& fl = e->wimg[MAPDIT_P_F_LIN];
     hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t) * (cfg->precision == MAPDIT_PREC_BF16X3 ? 3 : 1),
                                    (hipStream_t)stream);
-    if (he == hipSuccess && train) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
+    if (he == hipSuccess && train && e->dlin) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
     if (he != hipSuccess) {
         delete e;
         mapdit_set_error("engine_create: memset failed: %s", hipGetErrorString(he));
