@@ -430,3 +430,50 @@ def test_ddim_matches_reference():
     z = torch.from_numpy(g["loop_noise"]).to(DEV)
     out = d5.ddim_sample_loop(stub5, tuple(z.shape), noise=z, clip_denoised=False, device=DEV, eta=0.0)
     assert rel_err(out.cpu().numpy(), g["loop_final"]) < 1e-5
+
+
+@pytest.mark.parametrize("name,precision", [("tiny_a", "bf16"), ("tiny_b", "bf16"), ("tiny_p8", "bf16"), ("xl_d1", "bf16"),
+                                            ("tiny_a", "bf16x3")])
+def test_ragged_batches_and_single_samples(name, precision):
+    """Batches of 1, 3, 5 and 7 samples (token-row counts that are not multiples of any tile size, engines re-created as the
+    batch grows): every sample's logits are the same bits whatever batch it sits in, and the gradient of a 7-sample batch
+    equals the sum of the gradients of its 3 + 4 split (fp32 summation order only: 2e-5 of the tensor)."""
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden(name)
+    m, cfg, _ = build(g)
+    m.gemm_precision = precision
+    gen = torch.Generator().manual_seed(21)
+    n = 7
+    x = torch.randn(n, cfg.in_channels, cfg.input_size, cfg.input_size, generator=gen).to(DEV)
+    t = torch.randint(0, 1000, (n,), generator=gen).to(DEV)
+    y = torch.randint(0, cfg.num_classes, (n,), generator=gen).to(DEV)
+    noise = torch.randn(x.shape, generator=gen).to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for b in (1, 3, 5, 7):                       # growing batch: the runtime re-creates its engine each time
+            outs[b] = m(x[:b].contiguous(), t[:b].contiguous(), y[:b].contiguous())
+            assert torch.isfinite(outs[b]).all()
+        single_last = m(x[6:7].contiguous(), t[6:7].contiguous(), y[6:7].contiguous())
+    for b in (1, 3, 5):
+        assert torch.equal(outs[b], outs[7][:b]), b
+    assert torch.equal(single_last, outs[7][6:7])
+    diff = create_diffusion("")
+
+    def grads(lo, hi):
+        for p in m.parameters():
+            p.grad = None
+        sl = slice(lo, hi)
+        loss = diff.training_losses(m, x[sl].contiguous(), t[sl].contiguous(), dict(y=y[sl].contiguous()), noise=noise[sl].contiguous())["loss"]
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), m._gflat.clone()
+
+    l7, g7 = grads(0, 7)
+    la, ga = grads(0, 3)
+    lb, gb = grads(3, 7)
+    assert torch.equal(torch.cat([la, lb]), l7)
+    for (k, p), o in zip(m.named_parameters(), m._poffs):
+        whole = g7[o:o + p.numel()].double()
+        parts = ga[o:o + p.numel()].double() + gb[o:o + p.numel()].double()
+        if float(whole.norm()) > 1e-9:
+            assert float((whole - parts).norm() / whole.norm()) < 2e-5, k
