@@ -177,7 +177,7 @@ def main():
                    "global_batch": world * B, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
                    "seeds": {"model": 0, "data": "1+rank"}, "final_loss": final_loss},
         "step_mfma_frac": value * 3 * f_fwd / (world * PEAK_BF16_DENSE_TFLOPS * 1e12),
-        "roofline": {"bound": "mfma", "kernel": "gemm_mfma256_kernel<0, 0, EpiSilu2<0>> (NT, block-MLP fc1: "
+        "roofline": {"bound": "mfma", "kernel": "gemm_mfma256_kernel<0, 0, EpiSilu2Grad> (NT, block-MLP fc1: "
                                                   f"[{B * T},{D}]x[{Hm},{D}]^T)",
                      "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, **pmc_traffic(args.model, B),

@@ -45,6 +45,9 @@ enum {
                                   optionally out3 = bf16(modulate(out2, ...)) for the next branch (utils.py:11-16)      */
     MAPDIT_EPI_DSILU = 4,      /* out = bf16(acc * d/dh[silu(h)/0.596]), h = aux (bf16)      (backward of SILU2)      */
     MAPDIT_EPI_SILU2_COND = 5, /* SILU2 under its own kernel symbol (timestep MLP, timestep_embedder.py:43)           */
+    MAPDIT_EPI_SILU2_GRAD = 7, /* out = bf16(d/dh[silu(h)/0.596]) at h = acc [optional]; out2 = bf16(silu(acc)/0.596): the backward
+                                * needs the pre-activation only through this factor, and here it comes out of the same exp / rcp */
+    MAPDIT_EPI_MUL_AUX = 8,    /* out = bf16(acc * aux), aux bf16 [M, ldo]   (backward of SILU2_GRAD: aux = its first output)   */
     MAPDIT_EPI_QKV_HEADS = 6   /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
                                 * is (which, head, d) = (n / D, n % D / 64, n % 64); q and k rows are cosine-normalised per
                                 * head, x * s with s = 8 / (|x| + 1e-4) from the fp32 accumulators, and everything is written

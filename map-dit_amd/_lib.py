@@ -11,7 +11,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmapdit_hip.so")
+LIB_PATH = os.environ.get("MAPDIT_LIB") or os.path.join(_HERE, "libmapdit_hip.so")      # MAPDIT_LIB: A/B runs against another build
 CSRC = os.path.join(_HERE, "csrc")
 
 vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_long
@@ -47,7 +47,7 @@ PRECISIONS = {"bf16": 0, "bf16x3": 1}
 
 
 NT, NN, TN = 0, 1, 2
-EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS = range(7)
+EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS, EPI_SILU2_GRAD, EPI_MUL_AUX = range(9)
 PROF_FC1_FWD = 0
 PEEK_IDS = {name: i for i, name in enumerate(
     ["four", "temb", "c", "mod_all", "x0", "xmodf", "lin", "xm", "qkv", "qn", "kn", "v", "o", "xm2", "hact", "xmid", "xout"])}

@@ -32,7 +32,7 @@ struct Carver {
 
 struct BlockBufs {
     // saved for backward (train) / scratch (eval)
-    bf16_t *xm, *qkv, *qn, *kn, *v, *o, *y, *xm2, *hpre, *hact, *y2;
+    bf16_t *xm, *qkv, *qn, *kn, *v, *o, *y, *xm2, *hdact, *hact, *y2;   // hdact = d/dh[silu(h)/0.596] at the fc1 output h
     float* lse;       // [N*H][T]
     float* qks;       // [2][N*H][T] cosine-normalisation scales of q, k (fused QKV epilogue; MFMA attention path only)
 };
@@ -161,7 +161,7 @@ size_t carve(mapdit_engine* e, void* base) {
         b.o = cv.take<bf16_t>(M * D);
         b.y = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.xm2 = cv.take<bf16_t>(M * D);
-        b.hpre = e->train ? cv.take<bf16_t>(M * Hm) : nullptr;
+        b.hdact = e->train ? cv.take<bf16_t>(M * Hm) : nullptr;
         b.hact = cv.take<bf16_t>(M * Hm);
         b.y2 = e->train ? cv.take<bf16_t>(M * D) : nullptr;
         b.lse = cv.take<float>((size_t)N * c.num_heads * T);
@@ -315,6 +315,14 @@ mapdit_epilogue_t epi_f32(float* out, int ldo, float alpha = 1.f, int acc = 0) {
 mapdit_epilogue_t epi_silu2(bf16_t* pre, bf16_t* act, int ldo) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
     e.kind = MAPDIT_EPI_SILU2; e.out = pre; e.out2 = act; e.ldo = ldo; return e;
+}
+mapdit_epilogue_t epi_silu2_grad(bf16_t* dact, bf16_t* act, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_SILU2_GRAD; e.out = dact; e.out2 = act; e.ldo = ldo; return e;
+}
+mapdit_epilogue_t epi_mul_aux(bf16_t* out, const bf16_t* aux, int ldo) {
+    mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.kind = MAPDIT_EPI_MUL_AUX; e.out = out; e.aux = aux; e.ldo = ldo; return e;
 }
 mapdit_epilogue_t epi_dsilu(bf16_t* out, const bf16_t* pre, int ldo) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
@@ -761,7 +769,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
-        TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2(save ? b.hpre : nullptr, b.hact, Hm), st));
+        TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
                  i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->blk[save ? i + 1 : 0].xm, mod + 6 * D,
@@ -888,7 +896,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         const float* mod = e->mod_all + (size_t)i * 6 * D;
         const int ldm = e->ldm;
         // MLP branch
-        TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_dsilu(e->dh, b.hpre, Hm), st));
+        TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
         TRY(gemm(MAPDIT_NN, M, D, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));

@@ -179,6 +179,48 @@ template <int TAG> struct EpiSilu2 {
         store8_bf16(act + (size_t)m * ldo + n, a);
     }
 };
+// SILU2 with the derivative factor instead of the pre-activation as its first output (one exp and one rcp serve both), and
+// the backward epilogue that goes with it: a plain product, no transcendental in the dX GEMM's epilogue.
+struct EpiSilu2Grad {
+    bf16_t* dact; bf16_t* act; int ldo;
+    EPI_TRIVIAL_STEPS
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
+        float a[8], d[8];
+        if (dact) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float s = __builtin_amdgcn_rcpf(1.f + __expf(-v[i]));
+                a[i] = v[i] * s * (1.f / MP_SILU_DIV);
+                d[i] = s * (1.f + v[i] * (1.f - s)) * (1.f / MP_SILU_DIV);
+            }
+            store8_bf16(dact + (size_t)m * ldo + n, d);
+        } else {                                           // inference: no backward, no factor
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = silu_f(v[i]) * (1.f / MP_SILU_DIV);
+        }
+        store8_bf16(act + (size_t)m * ldo + n, a);
+    }
+};
+struct EpiMulAux {
+    bf16_t* out; const bf16_t* aux; int ldo;
+    struct Aux { u32x4_t h; };
+    typedef EpiNoTile Tile;
+    __device__ __forceinline__ Tile tile_begin(int, int, int) const { return Tile(); }
+    __device__ __forceinline__ Aux load(int m, int n) const {
+        Aux a; a.h = __builtin_nontemporal_load((const u32x4_t*)(aux + (size_t)m * ldo + n));
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile&) const {
+        const u32x4_t u = a.h;
+        float w[8];
+        w[0] = v[0] * __uint_as_float(u.x << 16); w[1] = v[1] * __uint_as_float(u.x & 0xffff0000u);
+        w[2] = v[2] * __uint_as_float(u.y << 16); w[3] = v[3] * __uint_as_float(u.y & 0xffff0000u);
+        w[4] = v[4] * __uint_as_float(u.z << 16); w[5] = v[5] * __uint_as_float(u.z & 0xffff0000u);
+        w[6] = v[6] * __uint_as_float(u.w << 16); w[7] = v[7] * __uint_as_float(u.w & 0xffff0000u);
+        store8_bf16(out + (size_t)m * ldo + n, w);
+    }
+    __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const { apply(m, n, v, 0, load(m, n), Tile()); }
+};
 struct EpiResid {
     bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
     // optional fused modulate of the NEXT branch (src/utils.py:11-16): xm = bf16(((1-g) xout scale + g shift) / den)
@@ -851,7 +893,8 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {
     MD_CHECK(layout >= MAPDIT_NT && layout <= MAPDIT_TN, "gemm: bad layout %d", layout);
     MD_CHECK(M > 0 && N > 0 && K > 0 && A && B && e, "gemm: null/empty argument (M=%d N=%d K=%d)", M, N, K);
-    MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_SILU2_COND || e->kind == MAPDIT_EPI_RESID,
+    MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_SILU2_COND || e->kind == MAPDIT_EPI_RESID ||
+                 e->kind == MAPDIT_EPI_SILU2_GRAD,
              "gemm: null output");
     MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
     MD_CHECK(e->ldo % 8 == 0 || e->kind == MAPDIT_EPI_QKV_HEADS, "gemm: ldo=%d must be a multiple of 8", e->ldo);
@@ -879,6 +922,12 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
                           EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
                                    e->rows_per_sample, e->alpha, e->beta, (bf16_t*)e->out3, e->shift2, e->scale2, e->gain2,
                                    e->ld2}, st);
+        case MAPDIT_EPI_SILU2_GRAD:
+            MD_CHECK(e->out2, "gemm: SILU2_GRAD needs out2");
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2Grad{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+        case MAPDIT_EPI_MUL_AUX:
+            MD_CHECK(e->aux, "gemm: MUL_AUX needs aux");
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiMulAux{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
         case MAPDIT_EPI_DSILU:
             MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);

@@ -143,6 +143,20 @@ def test_gemm_epilogues(L):
     run_gemm(L, 0, a, b, L.EPI_SILU2, M, N, K, out=p(pre), out2=p(act), ldo=N)
     assert rel_err(pre.float().cpu().numpy(), acc.numpy()) < 3e-3
     assert rel_err(act.float().cpu().numpy(), (torch.nn.functional.silu(acc) / 0.596).numpy()) < 3e-3
+    # silu2 with the derivative factor instead of the pre-activation, and the product epilogue that consumes it
+    dfac = torch.zeros_like(pre)
+    act2 = torch.zeros_like(pre)
+    run_gemm(L, 0, a, b, L.EPI_SILU2_GRAD, M, N, K, out=p(dfac), out2=p(act2), ldo=N)
+    leaf = acc.clone().requires_grad_(True)
+    (torch.nn.functional.silu(leaf) / 0.596).sum().backward()
+    assert rel_err(dfac.float().cpu().numpy(), leaf.grad.numpy()) < 3e-3
+    assert rel_err(act2.float().cpu().numpy(), (torch.nn.functional.silu(acc) / 0.596).numpy()) < 3e-3
+    act3 = torch.zeros_like(pre)
+    run_gemm(L, 0, a, b, L.EPI_SILU2_GRAD, M, N, K, out=None, out2=p(act3), ldo=N)          # inference form: no factor
+    assert rel_err(act3.float().cpu().numpy(), act2.float().cpu().numpy()) < 1e-6
+    prod = torch.zeros_like(pre)
+    run_gemm(L, 0, a, b, L.EPI_MUL_AUX, M, N, K, out=p(prod), aux=p(dfac), ldo=N)
+    assert rel_err(prod.float().cpu().numpy(), (acc * dfac.float().cpu()).numpy()) < 3e-3
     # residual: xout = ca*x + cb*gate[m/T]*acc
     x = torch.randn(M, N)
     gate = torch.randn(M // T, 3 * N)

@@ -472,8 +472,12 @@ def test_ragged_batches_and_single_samples(name, precision):
     la, ga = grads(0, 3)
     lb, gb = grads(3, 7)
     assert torch.equal(torch.cat([la, lb]), l7)
+    # scalar gains are sums of ~1e5 cancelling terms: judged on the scale of the largest gain gradient (as everywhere above)
+    gain_scale = max(float(g7[o].abs()) for (k, p), o in zip(m.named_parameters(), m._poffs) if p.dim() == 0)
     for (k, p), o in zip(m.named_parameters(), m._poffs):
         whole = g7[o:o + p.numel()].double()
         parts = ga[o:o + p.numel()].double() + gb[o:o + p.numel()].double()
-        if float(whole.norm()) > 1e-9:
+        if p.dim() == 0:
+            assert abs(float(whole) - float(parts)) < 1e-3 * gain_scale + 1e-9, k
+        elif float(whole.norm()) > 1e-9:
             assert float((whole - parts).norm() / whole.norm()) < 2e-5, k

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE GEMM case repeatedly (for rocprofv3 --pmc): python tools/gemm_one.py {nt|nn|tn|fc1} [tile]
-(fc1 = the bench's roofline kernel: NT [65536,768]x[3072,768]^T with the SILU2 dual-store epilogue)"""
+(fc1 = the bench's roofline kernel: NT [65536,768]x[3072,768]^T with the SILU2_GRAD dual-store epilogue)"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mapdit_amd
@@ -21,7 +21,7 @@ for _ in range(5):
         e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, out.data_ptr(), 4 * D, 1.0
         L.lib().gemm_bf16(0, M, 4 * D, D, x.data_ptr(), D, w.data_ptr(), D, C.byref(e), st)
     elif kind == "fc1":
-        e.kind, e.out, e.out2, e.ldo = L.EPI_SILU2, out.data_ptr(), out2.data_ptr(), 4 * D
+        e.kind, e.out, e.out2, e.ldo = L.EPI_SILU2_GRAD, out.data_ptr(), out2.data_ptr(), 4 * D
         L.lib().gemm_bf16(0, M, 4 * D, D, x.data_ptr(), D, w.data_ptr(), D, C.byref(e), st)
     elif kind == "nn":
         e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, out.data_ptr(), D, 1.0
