@@ -116,11 +116,31 @@ _lock = threading.Lock()
 _handle = None
 
 
+def _source_digest() -> str:
+    """SHA-256 over everything the library is built from (sources, headers, Makefile)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include", "mapdit.h")
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile") + [inc]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU).  Staleness is decided by a digest of the sources
+    kept next to the library, not by file times: a repo snapshot copied to another machine does not keep them."""
+    stamp = LIB_PATH + ".src-sha256"
+    digest = _source_digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return LIB_PATH
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"])
     subprocess.check_call(["make", "-C", CSRC, "-j8"])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return LIB_PATH
 
 
@@ -155,6 +175,11 @@ def lib() -> _Lib:
             if not os.path.exists(LIB_PATH):
                 raise MapditError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                   f"or `make -C {CSRC}`; there is no CPU fallback")
+            # torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so, loaded into the global scope), and
+            # the library's HIP calls must bind to THAT one.  Loaded before torch, they bind to the ROCm installation's
+            # libamdhip64.so.7 instead - a second runtime in the process, which does not see the device torch holds (every
+            # launch then fails with hipErrorNoDevice).
+            import torch  # noqa: F401
             _handle = _Lib(C.CDLL(LIB_PATH))
         return _handle
 
