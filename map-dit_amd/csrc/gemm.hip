@@ -116,6 +116,11 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, 
 // apply(m, n, v, z, aux, tile) - arithmetic and stores.
 struct EpiNoAux {};
 struct EpiNoTile {};
+// Epilogues whose outputs are bf16 and a function of the accumulator alone can also run in the accumulator layout of the
+// 256^2 kernel (kDirectOuts<Epi> outputs): pw() turns four accumulators (columns n..n+3 of a row) into four bf16 per output,
+// and only those go through LDS - half the bytes of the fp32 image, for the store-only epilogue in one pass instead of two.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+template <class Epi> constexpr int kDirectOuts = 0;
 // Epilogue outputs are streams far larger than the L2 that nothing re-reads soon: non-temporal stores (`nt`) so that the
 // output stream is first in line for eviction and does not push out the operand panels the XCD's other workgroups still read.
 // (An `sc1` write-through store, which does not keep the line in L2 at all, was 5 % faster still but let a following kernel
@@ -144,6 +149,11 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // 
 struct EpiStoreBf16 {
     bf16_t* out; int ldo; float alpha;
     EPI_TRIVIAL_STEPS
+    __device__ __forceinline__ int n_direct() const { return 1; }
+    __device__ __forceinline__ bf16_t* dst(int) const { return out; }
+    __device__ __forceinline__ void pw(const f32x4_t& v, u32x2_t* o, int) const {
+        o[0] = u32x2_t{pack2bf(alpha * v[0], alpha * v[1]), pack2bf(alpha * v[2], alpha * v[3])};
+    }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float w[8];
 #pragma unroll
@@ -184,6 +194,19 @@ template <int TAG> struct EpiSilu2 {
 struct EpiSilu2Grad {
     bf16_t* dact; bf16_t* act; int ldo;
     EPI_TRIVIAL_STEPS
+    __device__ __forceinline__ int n_direct() const { return dact ? 2 : 1; }
+    __device__ __forceinline__ bf16_t* dst(int w) const { return w == 0 ? act : dact; }
+    __device__ __forceinline__ void pw(const f32x4_t& v, u32x2_t* o, int nout) const {
+        float a[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = __builtin_amdgcn_rcpf(1.f + __expf(-v[i]));
+            a[i] = v[i] * s * (1.f / MP_SILU_DIV);
+            d[i] = s * (1.f + v[i] * (1.f - s)) * (1.f / MP_SILU_DIV);
+        }
+        o[0] = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+        if (nout > 1) o[1] = u32x2_t{pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+    }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float a[8], d[8];
         if (dact) {
@@ -201,6 +224,8 @@ struct EpiSilu2Grad {
         store8_bf16(act + (size_t)m * ldo + n, a);
     }
 };
+template <> constexpr int kDirectOuts<EpiStoreBf16> = 1;
+// (EpiSilu2Grad has the pointwise form too, but measured slower this way: fc1 853 -> 809 TFLOP/s; it stays on the fp32 image)
 struct EpiMulAux {
     bf16_t* out; const bf16_t* aux; int ldo;
     struct Aux { u32x4_t h; };
@@ -489,9 +514,13 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
         stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
+#define G256_STAMPS_OUT()                                                                           \
+    if (stamp_on && wave == 0)                                                                      \
+        for (int i = 0; i < 8; ++i) g_stamps[2 * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[2 * STAMP_TILES * STAMP_POINTS + i]
 #else
 #define G256_STAMP(PT)
 #define G256_TSTAMP(IDX)
+#define G256_STAMPS_OUT()
 #endif
 
 template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
@@ -719,6 +748,54 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     G256_TSTAMP(2);
 
     // epilogue: two passes of 128 rows through LDS, then whole 8-column row chunks per thread
+    if constexpr (kDirectOuts<Epi> > 0) {
+        // bf16 images [rows][DLD bytes]: 520 = 512 + 8 keeps both the 8-byte column writes of the accumulator layout and the
+        // 8-byte row reads of the store loop spread over the banks; 256 rows of one image = the whole LDS window exactly.
+        constexpr int NO = kDirectOuts<Epi>, DLD = 520;
+        constexpr int ROWS = NO == 1 ? 256 : 128, NPASS = 256 / ROWS;
+        const int nout = epi.n_direct();
+        const int dcol = tid & 31, dgn = n0 + dcol * 8;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (NO > 1 && half != pass) continue;       // two outputs: one 128-row half of the tile per pass
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int R = (NO == 1 ? half * 128 : 0) + wm * 64 + i * 16 + (lane & 15);
+                        const int cb = (wn * 64 + j * 16 + 4 * (lane >> 4)) * 2;
+                        u32x2_t o[NO];
+                        epi.pw(acc[half * 4 + i][j], o, nout);
+#pragma unroll
+                        for (int w = 0; w < NO; ++w)
+                            if (w < nout) *(u32x2_t*)(smem + w * (ROWS * DLD) + R * DLD + cb) = o[w];
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ROWS / 16; ++it) {
+                const int R = (tid >> 5) + 16 * it;
+                const int half = NO == 1 ? (R >> 7) : pass, row = R & 127;
+                const int gm = m0 + (row >> 6) * 128 + half * 64 + (row & 63);
+                if (gm < p.M && dgn < p.N) {
+#pragma unroll
+                    for (int w = 0; w < NO; ++w)
+                        if (w < nout) {
+                            const char* src = smem + w * (ROWS * DLD) + R * DLD + dcol * 16;
+                            const u32x2_t lo = *(const u32x2_t*)src, hi = *(const u32x2_t*)(src + 8);
+                            store16_stream(epi.dst(w) + (size_t)gm * epi.ldo + dgn, u32x4_t{lo.x, lo.y, hi.x, hi.y});
+                        }
+                }
+            }
+            if (pass + 1 < NPASS) __syncthreads();
+        }
+        G256_TSTAMP(3);
+        G256_TSTAMP(4);
+        G256_STAMPS_OUT();
+        return;
+    }
     float* cs = (float*)smem;
     const int ecol = (tid & 31) * 8, gn = n0 + ecol;
     const bool col_ok = gn < p.N;
@@ -756,10 +833,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         __syncthreads();
         G256_TSTAMP(3 + pass);
     }
-#ifdef MAPDIT_GEMM_STAMPS
-    if (stamp_on && wave == 0)
-        for (int i = 0; i < 8; ++i) g_stamps[2 * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[2 * STAMP_TILES * STAMP_POINTS + i];
-#endif
+    G256_STAMPS_OUT();
 }
 
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
