@@ -507,11 +507,19 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
         stamp_lds[(wm * STAMP_TILES + t) * STAMP_POINTS + (PT)] = (long long)__builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
-// whole-tile stamps (wave 0): 0 = workgroup entry, 1 = K loop starts, 2 = K loop done, 3 = epilogue pass 0 done, 4 = epilogue done
+// whole-tile stamps (wave 0): 0 = workgroup entry, 1 = K loop starts, 2 = K loop done, 3 = epilogue pass 0 done, 4 = epilogue done;
+// slots 5 / 6 = the 100 MHz s_memrealtime at K loop start / end: (stamp 2 - stamp 1) / (slot 6 - slot 5) x 100 MHz is the clock the
+// K loop ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
 #define G256_TSTAMP(IDX)                                                                            \
     if (stamp_on && wave == 0) {                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+#define G256_RSTAMP(IDX)                                                                            \
+    if (stamp_on && wave == 0) {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
 #define G256_STAMPS_OUT()                                                                           \
@@ -520,6 +528,7 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 #else
 #define G256_STAMP(PT)
 #define G256_TSTAMP(IDX)
+#define G256_RSTAMP(IDX)
 #define G256_STAMPS_OUT()
 #endif
 
@@ -651,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     // Every wait leaves the five youngest half-tiles in flight (vmcnt(10)) and retires what the NEXT phase reads:
     //   phase 1 -> B1[t] (read in 2)   phase 2 -> A1[t] (read in 3)   phase 4 -> A0[t+1], B0[t+1] (read in 1 of t+1)
     G256_TSTAMP(1);
+    G256_RSTAMP(5);
     if (p.phases == 2) {
         // Two phases per K-tile: 32 MFMAs (512 cycles) per MFMA interval, half as many barriers.  Phase A reads A0, B0, B1
         // of tile t and computes the upper half (quadrants (0,0), (0,1)); phase B reads A1 and computes the lower half from
@@ -746,6 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }
     __syncthreads();
     G256_TSTAMP(2);
+    G256_RSTAMP(6);
 
     // epilogue: two passes of 128 rows through LDS, then whole 8-column row chunks per thread
     if constexpr (kDirectOuts<Epi> > 0) {
