@@ -106,19 +106,23 @@ class OverlappedGradReducer:
     """All-reduce each backward stage's gradient slice as soon as that stage is enqueued (see module docstring).
     Usage: r = OverlappedGradReducer(model); ...; loss.backward(); r.finish(); opt.step()."""
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, force_collective: bool = False):
         self.model, self.group = model, group
         self.world = _world(group)
         self.slices = stage_slices(model)
         self.works = []
-        model._stage_hook = self._on_stage if self.world > 1 or os.environ.get("MAPDIT_FORCE_STAGED_BACKWARD") else None
+        # force_collective: issue the all-reduces in a one-rank group too (an identity through RCCL: rehearses the stream hand-over
+        # between the engine's kernels and the collective on a one-GPU box)
+        self.force_collective = force_collective
+        staged = self.world > 1 or force_collective or os.environ.get("MAPDIT_FORCE_STAGED_BACKWARD")
+        model._stage_hook = self._on_stage if staged else None
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
     def _on_stage(self, stage: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         lo, hi = self.slices[stage]
         self.works.append(dist.all_reduce(self.model._gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -249,3 +249,44 @@ def test_ema_class_matches_fused_optimizer(tmp_path):
     assert snap["std"] == 0.05 and snap["t"] == 3 and snap["state_dict"]["x_embedder.weight"].dtype == torch.float16
     back = calculate_posthoc_ema(0.05, os.path.join(str(tmp_path), "ema"), verbose=False)
     assert torch.equal(back["x_embedder.weight"], snap["state_dict"]["x_embedder.weight"])
+
+
+def test_overlapped_reducer_through_rccl_single_rank():
+    """The data-parallel step with a REAL RCCL process group (one rank: every all-reduce is an identity, but it runs RCCL's
+    kernels on RCCL's stream against the engine's raw-stream kernels): staged backward -> per-stage async all-reduce of the
+    gradient slice -> finish() -> fused optimiser.  Gradients and updated weights must be the bits of the plain single-GPU
+    step."""
+    import torch.distributed as dist
+    from oracle import dit_oracle as O
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.optim import FusedAdamEMA
+    from mapdit_amd.parallel import OverlappedGradReducer
+    from mapdit_amd.src.dit import DiT
+    g = load_golden("tiny_b")
+    cfg = golden_cfg(g)
+    sd = O.init_state_dict(cfg, seed=3, gains=0.3, perturb_reference=0.5)
+    x, t, y, noise = (torch.from_numpy(g[n]).to(DEV) for n in ("x", "t", "y_eff", "noise"))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+    try:
+        outs = []
+        for through_rccl in (False, True):
+            m = DiT(**cfg.to_dict())
+            m.load_state_dict(sd)
+            m = m.to(DEV).train()
+            m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+            r = OverlappedGradReducer(m, force_collective=through_rccl)
+            opt = FusedAdamEMA(m, lr=1e-2, grad_scale=r.grad_scale)
+            for _ in range(2):
+                loss = create_diffusion("").training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean()
+                opt.zero_grad()
+                loss.backward()
+                r.finish()
+                opt.step()
+            torch.cuda.synchronize()
+            outs.append((m._gflat.clone(), m._pflat.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
