@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="DiT-B/2")
     ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
+                    help="bf16x3: the fp32-accurate parity engine (informational; the headline metric is bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -116,6 +118,7 @@ def main():
 
     torch.manual_seed(0)                                   # model seed 0
     model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000).to(dev).train()
+    model.gemm_precision = args.precision
     diffusion = create_diffusion(timestep_respacing="")
     num_steps = 400_000                                    # train.py defaults -> warm-up / decay points
     reducer = OverlappedGradReducer(model)                 # all-reduce of block i overlaps backward of blocks i-1..0
@@ -143,7 +146,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    rt = model._rt[True]
+    rt = model._rt[True if args.precision == "bf16" else (args.precision, True)]
     L.lib().engine_profile_begin(rt.handle, L.PROF_FC1_FWD, model.depth * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -167,10 +170,10 @@ def main():
     fc1_ms = tot_ms.value / max(cnt.value, 1)
     achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if cnt.value else None
     out = {
-        "metric": f"latent-images/sec training step, {args.model} bf16 @256",
+        "metric": f"latent-images/sec training step, {args.model} {args.precision} @256",
         "value": value, "unit": "latent-img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (two-term split bf16 operands, fp32 accumulate and storage)", "data": "synthetic",
         "config": {"workload": f"{args.model} full training step on 32x32x4 latents (fwd+loss+bwd+allreduce+Adam+2xEMA), "
                                "all magnitude-preserving features on, bf16 GEMM operands / fp32 accumulate, master and "
                                "residual fp32",

@@ -105,37 +105,65 @@ __global__ void rmb32_kernel(Rmb32P p) {
 }
 
 // Attention backward with the probability matrices spelled out (scratch P, dS: [B*H][T][T] fp32 each).
-// probs: one thread per (head, query): P[i][j] = softmax_j(q^_i . k^_j * scale), dS[i][j] = P (dO_i . v_j - dO_i . O_i) scale
-__global__ void attn32_probs_kernel(const float* __restrict__ qn, const float* __restrict__ kn, const float* __restrict__ v,
-                                    const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ P,
-                                    float* __restrict__ dS, int T, int H, int hd, float scale, long total) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const long bh = id / T;
-    const int i = (int)(id % T), b = (int)(bh / H), hh = (int)(bh % H), D = H * hd;
-    const float* q = qn + (bh * T + i) * hd;
-    const float* go = dO + ((size_t)b * T + i) * D + hh * hd;
-    const float* oo = O + ((size_t)b * T + i) * D + hh * hd;
-    float* Pi = P + (bh * T + i) * T;
-    float* dSi = dS + (bh * T + i) * T;
-    float l = 0.f, delta = 0.f;
-    for (int d = 0; d < hd; ++d) delta += go[d] * oo[d];
-    for (int j = 0; j < T; ++j) {
-        const float* k = kn + (bh * T + j) * hd;
-        float s = 0.f;
-        for (int d = 0; d < hd; ++d) s += q[d] * k[d];
-        const float e = expf(s * scale);
-        Pi[j] = e;
-        l += e;
+// probs: one workgroup per head, thread j = key j with k^_j and v_j in registers; the queries pass through LDS 16 rows at a time
+// (every thread reads the same q^_i / dO_i element: a broadcast) and every P / dS row is written as one contiguous run over j:
+//   P[i][j] = exp(q^_i . k^_j scale) / sum_j(...),   dS[i][j] = P[i][j] (dO_i . v_j - dO_i . O_i) scale
+constexpr int PB_QT = 16;
+template <int PB_HD>                                       // register / LDS row size: the smallest of 32, 64, 96 that holds head_dim
+__global__ __launch_bounds__(256) void attn32_probs_kernel(const float* __restrict__ qn, const float* __restrict__ kn,
+                                                         const float* __restrict__ v, const float* __restrict__ dO,
+                                                         const float* __restrict__ O, float* __restrict__ P, float* __restrict__ dS,
+                                                         int T, int H, int hd, float scale) {
+    __shared__ float qs[PB_QT][PB_HD], gs[PB_QT][PB_HD], part[PB_QT][4], dl[PB_QT];
+    const size_t bh = blockIdx.x;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * hd;
+    const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const bool act = j < T;
+    float kr[PB_HD], vr[PB_HD];
+#pragma unroll
+    for (int d = 0; d < PB_HD; ++d) {
+        const bool in = act && d < hd;
+        kr[d] = in ? kn[(bh * T + j) * hd + d] : 0.f;
+        vr[d] = in ? v[(bh * T + j) * hd + d] : 0.f;
     }
-    const float il = 1.f / l;
-    for (int j = 0; j < T; ++j) {
-        const float* vj = v + (bh * T + j) * hd;
-        float dp = 0.f;
-        for (int d = 0; d < hd; ++d) dp += go[d] * vj[d];
-        const float pj = Pi[j] * il;
-        Pi[j] = pj;
-        dSi[j] = pj * (dp - delta) * scale;
+    for (int i0 = 0; i0 < T; i0 += PB_QT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < PB_QT * hd; e += 256) {
+            const int r = e / hd, d = e - r * hd, i = i0 + r;
+            qs[r][d] = i < T ? qn[(bh * T + i) * hd + d] : 0.f;
+            gs[r][d] = i < T ? dO[((size_t)b * T + i) * D + hh * hd + d] : 0.f;
+        }
+        if (threadIdx.x < PB_QT) {
+            const int i = i0 + threadIdx.x;
+            float a = 0.f;
+            if (i < T)
+                for (int d = 0; d < hd; ++d) a += dO[((size_t)b * T + i) * D + hh * hd + d] * O[((size_t)b * T + i) * D + hh * hd + d];
+            dl[threadIdx.x] = a;
+        }
+        __syncthreads();
+        float ex[PB_QT], dp[PB_QT];
+#pragma unroll
+        for (int r = 0; r < PB_QT; ++r) {
+            float sdot = 0.f, g = 0.f;
+#pragma unroll
+            for (int d = 0; d < PB_HD; ++d)
+                if (d < hd) { sdot += qs[r][d] * kr[d]; g += gs[r][d] * vr[d]; }
+            ex[r] = act ? expf(sdot * scale) : 0.f;
+            dp[r] = g;
+            const float ws = wave_sum(ex[r]);
+            if (lane == 0) part[r][wave] = ws;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PB_QT; ++r) {
+            const int i = i0 + r;
+            if (i < T && act) {
+                const float l = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);
+                const float pj = ex[r] / l;
+                P[(bh * T + i) * T + j] = pj;
+                dS[(bh * T + i) * T + j] = pj * (dp[r] - dl[r]) * scale;
+            }
+        }
     }
 }
 // dq^_i = sum_j dS[i][j] k^_j : one thread per (head, query, d)
@@ -256,7 +284,8 @@ __global__ void qkv_split32_kernel(const float* __restrict__ qkv, int B, int T, 
 
 // fp32 attention: one thread per query row, K/V streamed through LDS 64 keys at a time.  softmax with running maximum
 // is unnecessary (|logit| <= sqrt(hd)); expf, not the fast intrinsic.
-constexpr int PA_HD = 96, PA_CHUNK = 64;
+constexpr int PA_CHUNK = 64;
+template <int PA_HD>                                       // as above
 __global__ __launch_bounds__(256) void attn32_kernel(const float* __restrict__ qn, const float* __restrict__ kn,
                                                    const float* __restrict__ v, float* __restrict__ o, int T, int H, int hd,
                                                    float scale) {
@@ -416,8 +445,16 @@ int mapdit_attn32_bwd(const float* qn, const float* kn, const float* v, const fl
                       float* dqn, float* dkn, float* dv, int B, int T, int H, int hd, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && P && dS && dqn && dkn && dv && B > 0, "attn32_bwd: bad argument");
     const long rows = (long)B * H * T;
-    hipLaunchKernelGGL(attn32_probs_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, qn, kn, v, dO, O, P, dS, T, H, hd,
-                       1.f / sqrtf((float)hd), rows);
+    MD_CHECK(T <= 256 && hd <= 96, "attn32_bwd: T=%d, head_dim=%d unsupported (<= 256, <= 96)", T, hd);
+    if (hd <= 32)
+        hipLaunchKernelGGL(attn32_probs_kernel<32>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, dO, O, P, dS, T, H, hd,
+                           1.f / sqrtf((float)hd));
+    else if (hd <= 64)
+        hipLaunchKernelGGL(attn32_probs_kernel<64>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, dO, O, P, dS, T, H, hd,
+                           1.f / sqrtf((float)hd));
+    else
+        hipLaunchKernelGGL(attn32_probs_kernel<96>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, dO, O, P, dS, T, H, hd,
+                           1.f / sqrtf((float)hd));
     MD_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn32_dq_kernel, dim3(cdiv(rows * hd, 256)), dim3(256), 0, (hipStream_t)stream, dS, kn, dqn, T, hd, rows * hd);
     MD_LAUNCH_CHECK();
@@ -507,8 +544,10 @@ int mapdit_qkv_split32(const float* qkv, int B, int T, int H, int hd, float* qn,
 
 int mapdit_attn32(const float* qn, const float* kn, const float* v, float* o, int B, int T, int H, int hd, void* stream) {
     MD_CHECK(qn && kn && v && o && B > 0, "attn32: bad argument");
-    MD_CHECK(T <= 256 && hd <= PA_HD, "attn32: T=%d, head_dim=%d unsupported (<= 256, <= %d)", T, hd, PA_HD);
-    hipLaunchKernelGGL(attn32_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, o, T, H, hd, 1.f / sqrtf((float)hd));
+    MD_CHECK(T <= 256 && hd <= 96, "attn32: T=%d, head_dim=%d unsupported (<= 256, <= 96)", T, hd);
+    if (hd <= 32) hipLaunchKernelGGL(attn32_kernel<32>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, o, T, H, hd, 1.f / sqrtf((float)hd));
+    else if (hd <= 64) hipLaunchKernelGGL(attn32_kernel<64>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, o, T, H, hd, 1.f / sqrtf((float)hd));
+    else hipLaunchKernelGGL(attn32_kernel<96>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qn, kn, v, o, T, H, hd, 1.f / sqrtf((float)hd));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
