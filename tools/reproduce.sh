@@ -21,6 +21,8 @@ for m in "DiT-S/2 256" "DiT-L/2 128" "DiT-XL/2 64" "DiT-XL/2 128" "DiT-B/2 32" "
     set -- $m
     python bench.py --model "$1" --batch-per-gpu "$2" --steps 10 --warmup 3 --no-cpu-baseline >> gpurun_out/other_models.jsonl
 done
+python bench.py --precision bf16x3 --batch-per-gpu 64 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_bf16x3.json   # parity engine's speed
+python tools/precision_trajectory.py --model DiT-S/2 --batch 64 --steps 300 > gpurun_out/precision_trajectory.log  # bf16 vs bf16x3, 300 steps
 python -m mapdit_amd.train --synthetic --model DiT-B/2 --num-steps 300 --batch-size 256 --log-every 25 --ckpt-every 1000 \
     --ema-snapshot-every 150 --results-dir /tmp/mapdit_res > gpurun_out/train300.log
 echo "done: see gpurun_out/"
