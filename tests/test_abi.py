@@ -58,3 +58,19 @@ def test_workspace_query_and_config_errors():
     big = L.Config(depth=2, hidden=256, patch=2, input_size=64, in_channels=4, num_heads=4, mlp_hidden=1024,
                    table_rows=11, max_batch=2)
     assert lib.engine_workspace_bytes(ctypes.byref(big), 0) == 0 and b"tokens" in lib.last_error()   # 1024 tokens
+
+
+def test_build_is_decided_by_source_digest_not_file_times(monkeypatch):
+    """build() keeps a SHA-256 of the sources next to the library and skips make while it matches: a repo snapshot copied to the
+    GPU box does not keep file times, and nothing there should recompile a library that is current."""
+    import subprocess
+    import mapdit_amd._lib as L
+    path = L.build()                                   # brings the stamp up to date (a no-op make at most)
+    stamp = path + ".src-sha256"
+    assert os.path.exists(path) and open(stamp).read().strip() == L._source_digest()
+    calls = []
+    monkeypatch.setattr(subprocess, "check_call", lambda *a, **k: calls.append(a))
+    assert L.build() == path and calls == []           # current: make is not even started
+    open(stamp, "w").write("stale\n")
+    L.build()
+    assert len(calls) == 1 and open(stamp).read().strip() == L._source_digest()
