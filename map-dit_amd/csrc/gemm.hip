@@ -522,9 +522,15 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
         stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
+// (copied out at the very end of the kernel: a copy placed after the K loop held the stamping waves back by ~10 k cycles and the
+// workgroup with them, and made the loop look that much longer)
 #define G256_STAMPS_OUT()                                                                           \
-    if (stamp_on && wave == 0)                                                                      \
-        for (int i = 0; i < 8; ++i) g_stamps[2 * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[2 * STAMP_TILES * STAMP_POINTS + i]
+    if (stamp_on) {                                                                                 \
+        for (int i = 0; i < STAMP_TILES * STAMP_POINTS; ++i)                                        \
+            g_stamps[wm * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[wm * STAMP_TILES * STAMP_POINTS + i]; \
+        if (wave == 0)                                                                              \
+            for (int i = 0; i < 8; ++i) g_stamps[2 * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[2 * STAMP_TILES * STAMP_POINTS + i]; \
+    }
 #else
 #define G256_STAMP(PT)
 #define G256_TSTAMP(IDX)
@@ -712,10 +718,6 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             G256_END_MFMA();
             G256_STAMP(10);
         }
-#ifdef MAPDIT_GEMM_STAMPS
-        if (stamp_on)
-            for (int i = 0; i < STAMP_TILES * STAMP_POINTS; ++i) g_stamps[wm * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[wm * STAMP_TILES * STAMP_POINTS + i];
-#endif
     } else
     for (int t = 0; t < nk; ++t) {
         char* cur = smem + (t & 1) * KBUF_BYTES;

@@ -23,7 +23,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "map-dit_amd", "csrc", "gemm.hip")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-                           "-DMAPDIT_GEMM_STAMPS", "-Wno-unused-function", src, "-o", SO])
+                           "-fno-slp-vectorize", "-DMAPDIT_GEMM_STAMPS", "-Wno-unused-function", src, "-o", SO])
     print("built", SO)
 
 
@@ -96,6 +96,12 @@ def main():
                     torch.cuda.synchronize()
             torch.cuda.synchronize()
             tt = stamps.cpu()[2 * TILES * PTS:]
+            kt = stamps.cpu()[:2 * TILES * PTS].view(2, TILES, PTS)
+            per_tile = [int(kt[0, i + 1, 0] - kt[0, i, 0]) for i in range(TILES - 1)]
+            print(f"   K-tile durations of that workgroup (wave group 0), tiles 0..{TILES - 2}: {per_tile}; last tile "
+                  f"{int(kt[0, TILES - 1, PTS - 1] - kt[0, TILES - 1, 0])}; K-loop entry -> first tile {int(kt[0, 0, 0] - tt[1])}; "
+                  f"last tile end -> epilogue start {int(tt[2] - kt[0, TILES - 1, PTS - 1])}; wave group 1 ends its last tile "
+                  f"{int(kt[1, TILES - 1, PTS - 1] - kt[0, TILES - 1, PTS - 1])} after group 0")
             d = [int(tt[i + 1] - tt[i]) for i in range(4)]
             ghz = (int(tt[2]) - int(tt[1])) / max(int(tt[6]) - int(tt[5]), 1) * 0.1
             print(f"== NT fc1 shape, {kind}, workgroup {blk}: cycles  fill (entry -> K loop) {d[0]}  K loop (12 tiles) {d[1]}  "
