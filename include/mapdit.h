@@ -26,7 +26,7 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);
+int mapdit_abi_version(void);   /* 2: cond_combine_* take table_rows; adam_ema_step_scalars; device_error_poll; comm_* */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM on bf16 MFMA with fused epilogues — F.linear and its autograd (src/basic/mp_linear.py:46,75).
@@ -113,6 +113,17 @@ int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long sl
  * fp32 buffers.  hyper (device, 5 floats): lr/(1-b1^t), 1/sqrt(1-b2^t), ema beta a, ema beta b, grad scale. */
 int mapdit_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
                          float* ema_b, long n, const float* hyper, float beta1, float beta2, float eps, void* stream);
+/* The same step with the five per-step values passed by value (host struct -> kernel arguments): no host-to-device copy
+ * in the training loop.  Works on any 4-element-aligned sub-range of the flat buffers (a ZeRO-1 shard). */
+typedef struct {
+    float step_size;     /* lr / (1 - beta1^t) */
+    float inv_sqrt_bc2;  /* 1 / sqrt(1 - beta2^t) */
+    float ema_beta_a, ema_beta_b;
+    float grad_scale;    /* 1 / world_size under data parallelism */
+} mapdit_adam_scalars_t;
+int mapdit_adam_ema_step_scalars(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
+                                 float* ema_b, long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2,
+                                 float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Token-stream kernels of the DiT block (src/utils.py:11-16, src/blocks/dit_block.py:33-36).
@@ -195,11 +206,16 @@ int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const float* pos,
                            int ldp, int N, int C, int S, int p, int D, void* stream);
 int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift, uint16_t* out, int n, int F,
                        void* stream);
+/* Labels outside [0, table_rows) and timesteps outside [0, nsteps) never index memory: the kernels clamp them and record a
+ * code that mapdit_device_error_poll reports (the reference raises IndexError there: F.embedding, numpy indexing). */
 int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
-                            uint16_t* c_bf, int n, int D, void* stream);
+                            uint16_t* c_bf, int n, int D, int table_rows, void* stream);
 /* dtable [rows][D] += the label-embedding gradient (rows hit by several samples are summed in sample order: no atomics). */
 int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
-                            float* dtable, int n, int D, void* stream);
+                            float* dtable, int n, int D, int table_rows, void* stream);
+/* Synchronises `stream`, returns MAPDIT_ERR_ARG (with a message naming the index kind) if any kernel since the last poll saw an
+ * out-of-range label or timestep, and clears the record.  Not capturable: call it outside hipGraph capture. */
+int mapdit_device_error_poll(void* stream);
 int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
                          const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream);
 int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,

@@ -38,6 +38,10 @@ class WnJob(C.Structure):          # mapdit_wn_job_t
     _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp)]
 
 
+class AdamScalars(C.Structure):    # mapdit_adam_scalars_t
+    _fields_ = [("step_size", cf), ("inv_sqrt_bc2", cf), ("ema_beta_a", cf), ("ema_beta_b", cf), ("grad_scale", cf)]
+
+
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
                 ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci)]
@@ -64,6 +68,7 @@ _SIGS = {
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
+    "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
@@ -82,8 +87,9 @@ _SIGS = {
     "mapdit_attn_generic_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
     "mapdit_patch_embed_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "mapdit_fourier_fwd": [vp, vp, vp, vp, ci, ci, vp],
-    "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
-    "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
+    "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
+    "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
+    "mapdit_device_error_poll": [vp],
     "mapdit_final_out_fwd": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_cfg_combine": [vp, vp, ci, ci, ci, cf, vp],

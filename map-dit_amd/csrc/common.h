@@ -37,6 +37,37 @@ __device__ __forceinline__ float dmpsilu_f(float x) {
     return s * (1.f + x * (1.f - s)) * (1.f / MP_SILU_DIV);
 }
 
+// ---- index validation (labels, timesteps) ------------------------------------------------------------------------------
+// The reference raises an IndexError for an out-of-range label / timestep (F.embedding, numpy fancy indexing).  A kernel cannot
+// raise: it clamps the index (no out-of-bounds access, ever) and records a code in a device word that
+// mapdit_device_error_poll() hands to the host.  One word per translation unit (no relocatable device code in this build);
+// the poll entry point ORs them together.
+#define MAPDIT_DEVERR_LABEL 1
+#define MAPDIT_DEVERR_TIMESTEP 2
+#define MAPDIT_DEFINE_DEV_ERROR(TU)                                                                    \
+    __device__ int g_dev_error_##TU = 0;                                                               \
+    int mapdit_dev_error_take_##TU(hipStream_t st, int* out) {                                         \
+        int v = 0, zero = 0;                                                                           \
+        hipError_t e = hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_dev_error_##TU), sizeof(int), 0, hipMemcpyDeviceToHost, st); \
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                                             \
+        if (e == hipSuccess && v) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dev_error_##TU), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st); \
+        if (e == hipSuccess && v) e = hipStreamSynchronize(st);                                        \
+        *out = v;                                                                                      \
+        return e == hipSuccess ? 0 : 1;                                                                \
+    }
+#define MAPDIT_CHECKED_INDEX(TU, v, n, code)                                                           \
+    ([&]() -> long {                                                                                   \
+        long v_ = (v);                                                                                 \
+        if (v_ < 0 || v_ >= (long)(n)) {                                                               \
+            g_dev_error_##TU = (code);                                                                 \
+            v_ = v_ < 0 ? 0 : (long)(n) - 1;                                                           \
+        }                                                                                              \
+        return v_;                                                                                     \
+    }())
+int mapdit_dev_error_take_embed(hipStream_t st, int* out);
+int mapdit_dev_error_take_diffusion(hipStream_t st, int* out);
+int mapdit_dev_error_take_precise(hipStream_t st, int* out);
+
 // Error plumbing shared by the C-ABI entry points (thread-local last-error string).
 void mapdit_set_error(const char* fmt, ...);
 #define MD_CHECK(cond, ...)                                   \

@@ -8,6 +8,8 @@
 //   6 posterior_mean_coef1        7 posterior_mean_coef2
 #include "common.h"
 
+MAPDIT_DEFINE_DEV_ERROR(diffusion)
+
 namespace {
 
 #define INV_LN2 1.44269504088896341f
@@ -17,7 +19,7 @@ __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __res
                                 const float* __restrict__ tab, int nsteps, float* __restrict__ xt, long total, int per) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const long tt = t[i / per];
+    const long tt = MAPDIT_CHECKED_INDEX(diffusion, t[i / per], nsteps, MAPDIT_DEVERR_TIMESTEP);
     xt[i] = tab[tt] * x0[i] + tab[nsteps + tt] * noise[i];
 }
 
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ mo,
                                                  float* __restrict__ G, int per /* C*H*W */) {
     __shared__ float red[2][4];
     const int n = blockIdx.x;
-    const long tt = t[n];
+    const long tt = MAPDIT_CHECKED_INDEX(diffusion, t[n], nsteps, MAPDIT_DEVERR_TIMESTEP);
     const float ra = tab[2 * nsteps + tt], rm1 = tab[3 * nsteps + tt], minlog = tab[4 * nsteps + tt],
                 maxlog = tab[5 * nsteps + tt], c1 = tab[6 * nsteps + tt], c2 = tab[7 * nsteps + tt];
     const float inv_per = 1.f / (float)per;
@@ -116,7 +118,7 @@ __global__ void p_sample_kernel(const float* __restrict__ mo, const float* __res
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const long n = i / per, e = i % per;
-    const long tt = t[n];
+    const long tt = MAPDIT_CHECKED_INDEX(diffusion, t[n], nsteps, MAPDIT_DEVERR_TIMESTEP);
     const float eps = mo[n * 2 * per + e], v = mo[n * 2 * per + per + e], x_t = x[i];
     const float ra = tab[2 * nsteps + tt], rm1 = tab[3 * nsteps + tt], minlog = tab[4 * nsteps + tt],
                 maxlog = tab[5 * nsteps + tt], c1 = tab[6 * nsteps + tt], c2 = tab[7 * nsteps + tt];
@@ -139,7 +141,7 @@ __global__ void ddim_kernel(const float* __restrict__ mo, const float* __restric
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const long n = i / per, e = i % per;
-    const long tt = t[n];
+    const long tt = MAPDIT_CHECKED_INDEX(diffusion, t[n], nsteps, MAPDIT_DEVERR_TIMESTEP);
     const float epsm = mo[n * 2 * per + e], x_t = x[i];
     const float ra = tab[2 * nsteps + tt], rm1 = tab[3 * nsteps + tt];
     float xs = ra * x_t - rm1 * epsm;

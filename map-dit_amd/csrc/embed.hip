@@ -2,6 +2,8 @@
 // All are small or HBM-bound; the FLOP-carrying parts go through mapdit_gemm_bf16.
 #include "common.h"
 
+MAPDIT_DEFINE_DEV_ERROR(embed)
+
 namespace {
 
 #define C5 0.70710678118654752f   // mp_sum(a, b, 0.5) = (a + b) * 0.5 / sqrt(0.5)   (src/utils.py:15-16, dit.py:84,88)
@@ -71,11 +73,13 @@ __global__ void fourier_kernel(const long* __restrict__ t, const float* __restri
 
 // ---- c = mp_sum(t_emb, y_emb, 0.5); also MPSiLU(c) and c as bf16 GEMM operands (dit.py:86-88) ------------------------
 __global__ void cond_combine_kernel(const float* __restrict__ temb, const float* __restrict__ table, const long* __restrict__ y,
-                                    float* __restrict__ c, bf16_t* __restrict__ c_silu, bf16_t* __restrict__ c_bf, int n, int D) {
+                                    float* __restrict__ c, bf16_t* __restrict__ c_silu, bf16_t* __restrict__ c_bf, int n, int D,
+                                    int table_rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * D) return;
     const int b = i / D, d = i % D;
-    const float v = (temb[i] + table[(size_t)y[b] * D + d]) * C5;
+    const long label = MAPDIT_CHECKED_INDEX(embed, y[b], table_rows, MAPDIT_DEVERR_LABEL);
+    const float v = (temb[i] + table[(size_t)label * D + d]) * C5;
     c[i] = v;
     c_silu[i] = f2bf(silu_f(v) * (1.f / MP_SILU_DIV));
     c_bf[i] = f2bf(v);
@@ -86,13 +90,17 @@ __global__ void cond_combine_kernel(const float* __restrict__ temb, const float*
 // of every sample with the same label in sample order.  Grid: (D / 256, n).
 __global__ void cond_combine_bwd_kernel(const float* __restrict__ c, const float* __restrict__ dcs, const float* __restrict__ dcd,
                                         const long* __restrict__ y, bf16_t* __restrict__ dtemb, float* __restrict__ dtable,
-                                        int n, int D) {
+                                        int n, int D, int table_rows) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (d >= D) return;
     const int i = b * D + d;
     const float dc = (dcs[i] * dmpsilu_f(c[i]) + dcd[i]) * C5;
     dtemb[i] = f2bf(dc);
     const long label = y[b];
+    if (label < 0 || label >= table_rows) {              // the forward clamped it and flagged the call; never write out of bounds
+        g_dev_error_embed = MAPDIT_DEVERR_LABEL;
+        return;
+    }
     for (int o = 0; o < b; ++o)
         if (y[o] == label) return;                       // an earlier sample owns this row (uniform over the block)
     float sum = dc;
@@ -221,19 +229,19 @@ extern "C" int mapdit_fourier_fwd(const int64_t* t, const float* scale, const fl
 }
 
 extern "C" int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
-                                       uint16_t* c_bf, int n, int D, void* stream) {
-    MD_CHECK(temb && table && y && c && c_silu && c_bf && n > 0, "cond_combine_fwd: null/empty argument");
+                                       uint16_t* c_bf, int n, int D, int table_rows, void* stream) {
+    MD_CHECK(temb && table && y && c && c_silu && c_bf && n > 0 && table_rows > 0, "cond_combine_fwd: null/empty argument");
     hipLaunchKernelGGL(cond_combine_kernel, dim3(cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, temb, table,
-                       (const long*)y, c, c_silu, c_bf, n, D);
+                       (const long*)y, c, c_silu, c_bf, n, D, table_rows);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
 extern "C" int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
-                                       float* dtable, int n, int D, void* stream) {
-    MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0, "cond_combine_bwd: null/empty argument");
+                                       float* dtable, int n, int D, int table_rows, void* stream) {
+    MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0 && table_rows > 0, "cond_combine_bwd: null/empty argument");
     hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd,
-                       (const long*)y, dtemb, dtable, n, D);
+                       (const long*)y, dtemb, dtable, n, D, table_rows);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

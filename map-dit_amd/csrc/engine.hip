@@ -532,7 +532,7 @@ static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, c
     TRY(mapdit_fourier32(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], px.four, N, FOURIER, st));
     TRY(linear(px.four, N, FOURIER, NONE, MAPDIT_P_T0, D, px.h1, D));
     TRY(linear(px.h1, N, D, SILU, MAPDIT_P_T2, D, e->temb, D));
-    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));   // fp32 c; bf16 copies unused
+    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));   // fp32 c; bf16 copies unused
     if (save) {
         hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
         MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
@@ -697,7 +697,7 @@ static int backward_precise(mapdit_engine* e, const float* dout, int stage_from,
         TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
     }
     // conditioning path
-    TRY(mapdit_cond_combine_bwd32(e->c, e->dcs, e->dcd, e->y_copy, pg.dtemb, e->dtable, N, D, st));
+    TRY(mapdit_cond_combine_bwd32(e->c, e->dcs, e->dcd, e->y_copy, pg.dtemb, e->dtable, N, D, c.table_rows, st));
     TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
     TRY(lin_dx(pg.dtemb, D, N, MAPDIT_P_T2, pg.dh1act, D, 0));
     TRY(mapdit_dsilu32(pg.dh1act, px.h1, pg.dh1, (long)N * D, st));
@@ -727,7 +727,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         TRY(gemm(MAPDIT_NT, N, D, FOURIER, e->four, FOURIER, W(MAPDIT_P_T0), FOURIER, ep, st));
     }
     TRY(gemm(MAPDIT_NT, N, D, D, e->h1_act, D, W(MAPDIT_P_T2), D, epi_f32(e->temb, D), st));
-    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, st));
+    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));
     if (save) {
         hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
         MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
@@ -966,7 +966,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
     }
     // ---- conditioning path ------------------------------------------------------------------------------------------
-    TRY(mapdit_cond_combine_bwd(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, st));
+    TRY(mapdit_cond_combine_bwd(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, c.table_rows, st));
     TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
     TRY(gemm(MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
     TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));

@@ -974,7 +974,29 @@ void mapdit_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mapdit_last_error(void) { return g_err; }
-extern "C" int mapdit_abi_version(void) { return 1; }
+extern "C" int mapdit_abi_version(void) { return 2; }
+
+extern "C" int mapdit_device_error_poll(void* stream) {
+    int a = 0, b = 0, c = 0;
+    const int rc = mapdit_dev_error_take_embed((hipStream_t)stream, &a) | mapdit_dev_error_take_diffusion((hipStream_t)stream, &b) |
+                   mapdit_dev_error_take_precise((hipStream_t)stream, &c);
+    if (rc) {
+        mapdit_set_error("device_error_poll: reading the device error words failed");
+        return MAPDIT_ERR_HIP;
+    }
+    const int code = a | b | c;
+    if (code & MAPDIT_DEVERR_LABEL) {
+        mapdit_set_error("index out of range: a class label outside [0, embedding rows) reached the label embedding (the kernels "
+                         "clamped it; results of that call are invalid)");
+        return MAPDIT_ERR_ARG;
+    }
+    if (code & MAPDIT_DEVERR_TIMESTEP) {
+        mapdit_set_error("index out of range: a timestep outside [0, num_timesteps) reached the diffusion tables (clamped; results "
+                         "of that call are invalid)");
+        return MAPDIT_ERR_ARG;
+    }
+    return MAPDIT_OK;
+}
 
 extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {

@@ -33,6 +33,6 @@ int mapdit_final_out_bwd32(const float* dout, const float* lin, int ldl, const f
                            const float* ref_sigma, float* dlin, int ldd, float* da, float* dref_part, float* dref_mean,
                            float* dref_sigma, int N, int C, int S, int p, void* stream);
 int mapdit_cond_combine_bwd32(const float* c, const float* dcs, const float* dcd, const int64_t* y, float* dtemb, float* dtable, int n,
-                              int D, void* stream);
+                              int D, int table_rows, void* stream);
 int mapdit_patchify32(const float* x, float* patches, int ldp, int N, int C, int S, int p, void* stream);
 int mapdit_axpby32(const float* in, float* out, long n, float alpha, int accumulate, void* stream);

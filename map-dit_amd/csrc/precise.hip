@@ -14,6 +14,8 @@
 #include "common.h"
 #include "precise.h"
 
+MAPDIT_DEFINE_DEV_ERROR(precise)
+
 namespace {
 
 __device__ __forceinline__ float mpsilu_exact(float x) { return x / (1.f + expf(-x)) * (1.f / MP_SILU_DIV); }
@@ -381,13 +383,17 @@ __global__ void sum_dref_kernel(const float* __restrict__ part, int N, float* __
 // adds every sample with that label in sample order (as cond_combine_bwd_kernel in embed.hip).  Grid: (D / 256, n).
 __global__ void cond_combine_bwd32_kernel(const float* __restrict__ c, const float* __restrict__ dcs, const float* __restrict__ dcd,
                                           const long* __restrict__ y, float* __restrict__ dtemb, float* __restrict__ dtable, int n,
-                                          int D) {
+                                          int D, int table_rows) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (d >= D) return;
     const int i = b * D + d;
     const float dc = (dcs[i] * dmpsilu_exact(c[i]) + dcd[i]) * 0.70710678118654752f;
     dtemb[i] = dc;
     const long label = y[b];
+    if (label < 0 || label >= table_rows) {
+        g_dev_error_precise = MAPDIT_DEVERR_LABEL;
+        return;
+    }
     for (int o = 0; o < b; ++o)
         if (y[o] == label) return;
     float sum = dc;
@@ -480,10 +486,10 @@ int mapdit_final_out_bwd32(const float* dout, const float* lin, int ldl, const f
     return MAPDIT_OK;
 }
 int mapdit_cond_combine_bwd32(const float* c, const float* dcs, const float* dcd, const int64_t* y, float* dtemb, float* dtable, int n,
-                              int D, void* stream) {
-    MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0, "cond_combine_bwd32: bad argument");
+                              int D, int table_rows, void* stream) {
+    MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0 && table_rows > 0, "cond_combine_bwd32: bad argument");
     hipLaunchKernelGGL(cond_combine_bwd32_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd, (const long*)y,
-                       dtemb, dtable, n, D);
+                       dtemb, dtable, n, D, table_rows);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -144,8 +144,12 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v,
                                                      float* __restrict__ e1, float* __restrict__ e2, long n,
-                                                     const float* __restrict__ hp, float b1, float b2, float eps) {
-    const float step_size = hp[0], inv_sqrt_bc2 = hp[1], eb1 = hp[2], eb2 = hp[3], gs = hp[4];
+                                                     const float* __restrict__ hp, mapdit_adam_scalars_t hs, float b1,
+                                                     float b2, float eps) {
+    // hyper-parameters of the step: by value (kernel arguments, nothing crosses PCIe) or, for a caller that replays one captured
+    // launch with changing values, from a 5-float device buffer
+    const float step_size = hp ? hp[0] : hs.step_size, inv_sqrt_bc2 = hp ? hp[1] : hs.inv_sqrt_bc2, eb1 = hp ? hp[2] : hs.ema_beta_a,
+                eb2 = hp ? hp[3] : hs.ema_beta_b, gs = hp ? hp[4] : hs.grad_scale;
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
@@ -215,8 +219,21 @@ extern "C" int mapdit_adam_ema_step(float* params, const float* grads, float* ex
     MD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && n > 0, "adam_ema_step: null/empty argument");
     MD_CHECK(n % 4 == 0, "adam_ema_step: n=%ld must be a multiple of 4 (pad the flat buffer)", n);
     const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    mapdit_adam_scalars_t none = {0.f, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, ema_a, ema_b, n, hyper, beta1, beta2, eps);
+                       exp_avg_sq, ema_a, ema_b, n, hyper, none, beta1, beta2, eps);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_adam_ema_step_scalars(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
+                                            float* ema_b, long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2,
+                                            float eps, void* stream) {
+    MD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && n > 0, "adam_ema_step_scalars: null/empty argument");
+    MD_CHECK(n % 4 == 0, "adam_ema_step_scalars: n=%ld must be a multiple of 4 (pad the flat buffer)", n);
+    const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, ema_a, ema_b, n, (const float*)nullptr, *hyper, beta1, beta2, eps);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

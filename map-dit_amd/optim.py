@@ -7,6 +7,7 @@ sum-all-reduce of the flat gradient buffer (see parallel.py).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import numpy as np
@@ -57,6 +58,8 @@ class FusedAdamEMA:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.ema = [flat.clone() for _ in self.ema_stds]
         self._gammas = [std_to_gamma(s) for s in self.ema_stds]
+        self.shard = (0, flat.numel())               # element range of the flat buffers this rank updates
+        self.after_step = None
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
@@ -77,12 +80,19 @@ class FusedAdamEMA:
         t = self.step_count
         b1, b2 = self.betas
         betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
-        hyper = torch.tensor([lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale],
-                             dtype=torch.float32, device=m._pflat.device)
-        with torch.cuda.device(m._pflat.device):
-            L.lib().adam_ema_step(m._pflat.data_ptr(), m._gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                  L.ptr(self.ema[0]) if self.ema else None, L.ptr(self.ema[1]) if self.ema else None,
-                                  m._pflat.numel(), hyper.data_ptr(), b1, b2, self.eps, L.cur_stream())
+        # the per-step values travel as kernel arguments: nothing is uploaded in the training loop
+        hyper = L.AdamScalars(lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale)
+        lo, hi = self.shard                          # the whole flat buffer unless a ZeRO-1 reducer owns a partition
+        if hi > lo:
+            off = lo * 4
+            with torch.cuda.device(m._pflat.device):
+                L.lib().adam_ema_step_scalars(m._pflat.data_ptr() + off, m._gflat.data_ptr() + off, self.exp_avg.data_ptr() + off,
+                                              self.exp_avg_sq.data_ptr() + off,
+                                              self.ema[0].data_ptr() + off if self.ema else None,
+                                              self.ema[1].data_ptr() + off if self.ema else None,
+                                              hi - lo, C.byref(hyper), b1, b2, self.eps, L.cur_stream())
+        if self.after_step is not None:
+            self.after_step()                        # ZeRO-1: all-gather of the updated parameter shards
         m.mark_weights_changed()
 
     # ---- checkpoint interchange with the reference (train.py:125-132 stores torch.optim.Adam.state_dict()) -------

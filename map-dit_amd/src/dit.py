@@ -196,6 +196,7 @@ class _Runtime:
         self.handle = h
         self.bound_key = None
         self.weights_key = None
+        self.generation = 0           # bumped by every forward that saves activations: the engine keeps ONE saved forward
 
     def bind(self, model: "DiT"):
         params = model._param_table()
@@ -228,12 +229,18 @@ class _DiTFunction(torch.autograd.Function):
         out = torch.empty(x.shape[0], 2 * model.in_channels, model.input_size, model.input_size, device=x.device)
         rt.lib.engine_forward(rt.handle, x.data_ptr(), t.data_ptr(), y_eff.data_ptr(), x.shape[0], 1, out.data_ptr(),
                               L.cur_stream())
-        ctx.model, ctx.rt = model, rt
+        rt.generation += 1
+        ctx.model, ctx.rt, ctx.generation = model, rt, rt.generation
         return out
 
     @staticmethod
     def backward(ctx, dout):
         model, rt = ctx.model, ctx.rt
+        # The engine holds the activations of exactly one forward.  forward(A); forward(B); lossA.backward() would silently
+        # differentiate A's loss through B's activations: refuse it (so does a runtime rebuilt for a larger batch in between).
+        if ctx.generation != rt.generation or not any(r is rt for r in model._rt.values()):
+            raise L.MapditError("backward through a stale forward: the engine keeps the saved activations of the most recent "
+                                "training forward only (one outstanding forward per model; run backward before the next forward)")
         dout = dout.contiguous().float()
         accumulate = model._attach_grads()
         keep = model._gflat.clone() if accumulate else None
@@ -250,6 +257,12 @@ class _DiTFunction(torch.autograd.Function):
         if keep is not None:
             model._gflat.add_(keep)
         return None, None, None, None, None, None
+
+
+def _strip_compile_prefix(state_dict, prefix, *args):
+    pre = prefix + "_orig_mod."
+    for k in [k for k in state_dict if k.startswith(pre)]:
+        state_dict[prefix + k[len(pre):]] = state_dict.pop(k)
 
 
 class DiT(nn.Module):
@@ -289,6 +302,9 @@ class DiT(nn.Module):
         self._gviews = None
         self._w_epoch = 0             # bumped by anything that rewrites parameters through raw pointers
         self._flatten_parameters()
+        # checkpoints / EMA snapshots written by the reference come from a torch.compile'd module (train.py:46, src/ema.py:121):
+        # every key carries an "_orig_mod." prefix
+        self._register_load_state_dict_pre_hook(_strip_compile_prefix)
 
     # ---- flat parameter / gradient storage ----------------------------------------------------------------
     def _flatten_parameters(self):
@@ -401,7 +417,17 @@ class DiT(nn.Module):
         """Call after rewriting parameters through raw pointers (the fused optimiser does)."""
         self._w_epoch += 1
 
+    def check_device_errors(self):
+        """Raise MapditError if a kernel since the last call saw a class label outside the embedding table or a timestep outside
+        the schedule (the reference raises IndexError at that point; a kernel can only clamp the index and record it).
+        Synchronises the stream: call it at logging / checkpoint cadence, not per step."""
+        with torch.cuda.device(self._pflat.device):
+            L.lib().device_error_poll(L.cur_stream())
+
     def _check_inputs(self, x, t, y):
+        if x.requires_grad and torch.is_grad_enabled():
+            raise L.MapditError("gradients with respect to the input latents are not produced by the engine (no reference script "
+                                "uses them); detach x, or differentiate through a copy of the model in the reference framework")
         assert x.dim() == 4 and x.shape[1] == self.in_channels and x.shape[2] == x.shape[3] == self.input_size, \
             f"x must be [N,{self.in_channels},{self.input_size},{self.input_size}], got {tuple(x.shape)}"
         assert t.shape == (x.shape[0],) and y.shape == (x.shape[0],)

@@ -196,8 +196,39 @@ def tables():
     out["ema_beta_t100"] = np.array([float(calc_beta(s, 100)) for s in (0.05, 0.1)])
     assert np.allclose(out["ema_gamma"], [O.std_to_gamma(0.05), O.std_to_gamma(0.1)])
     assert np.allclose(out["ema_beta_t100"], [O.ema_beta(0.05, 100), O.ema_beta(0.1, 100)])
+    out.update(constructor_pins())
     np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
     print("== tables.npz written")
+
+
+def constructor_pins():
+    """What the reference's OWN constructor produces (src/dit.py:15-62), nothing loaded over it: the normalised sin-cos
+    position table (src/pos_embed.py:4-60, dit.py:46-48) sampled at 16 fixed places per width, the Fourier buffers' and every
+    parameter's init statistics.  Pins SURVEY A16 and the init distributions (the other fixtures overwrite both with the
+    oracle's state dict)."""
+    out = {}
+    idx = np.array([0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987])
+    for name in ("DiT-S/2", "DiT-S/4", "DiT-B/2", "DiT-XL/2", "DiT-S/8"):
+        cfg = O.model_config(name, in_channels=4, input_size=32, num_classes=1000)
+        torch.manual_seed(0)
+        m = RefDiT(**cfg.to_dict())
+        pe = m.pos_embed.detach().reshape(-1)
+        pos = (idx * 7919) % pe.numel()
+        out[f"ctor/{name}/pos_idx"] = pos
+        out[f"ctor/{name}/pos_val"] = pe[pos].numpy()
+        out[f"ctor/{name}/pos_shape"] = np.array(m.pos_embed.shape)
+        out[f"ctor/{name}/pos_rownorm"] = m.pos_embed.detach()[0].norm(dim=-1)[:4].numpy()
+        stats = {}
+        for k, p in list(m.named_parameters()) + list(m.named_buffers()):
+            if k == "pos_embed":
+                continue
+            f = p.detach().double().reshape(-1)
+            stats[k] = (f.numel(), f.mean().item(), f.std().item() if f.numel() > 1 else 0.0, f.min().item(), f.max().item())
+        if name in ("DiT-S/2", "DiT-XL/2"):
+            out[f"ctor/{name}/param_names"] = np.array(list(stats))
+            out[f"ctor/{name}/param_stats"] = np.array([stats[k] for k in stats])
+        del m
+    return out
 
 
 def optimizer_fixture():
@@ -319,6 +350,16 @@ if __name__ == "__main__":
                                      num_classes=10), n=2, wseed=7, dseed=8, gains=0.3, perturb=0.3, full=False, check_tol=5e-5)
         fixture("tiny_p8", O.DiTConfig(depth=1, hidden_size=128, patch_size=8, input_size=32, in_channels=4, num_heads=2,
                                        num_classes=10), n=3, wseed=9, dseed=10, gains=0.3, perturb=0.3)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tables":
+        tables()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        # BASELINE configs 2 and 4 at full depth: DiT-S/2 at n = 4 and DiT-XL/2 (patch 2, depth 28, head_dim 72) at n = 2
+        fixture("s2_n4", O.model_config("DiT-S/2", in_channels=4, input_size=32, num_classes=1000), n=4, wseed=3, dseed=4,
+                gains=0.2, perturb=0.3, full=False, check_tol=5e-5)
+        fixture("xl2_n2", O.model_config("DiT-XL/2", in_channels=4, input_size=32, num_classes=1000), n=2, wseed=0, dseed=1,
+                gains=0.15, perturb=0.3, full=False, check_tol=5e-5)
         sys.exit(0)
     tiny = dict(in_channels=4, num_heads=2, num_classes=10)
     fixture("tiny_a", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=16, **tiny), n=4, wseed=1, dseed=2)

@@ -591,7 +591,7 @@ def test_conditioning_kernels(L):
     cs = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
     cb = torch.zeros_like(cs)
     tb, tab, yd = temb.to(DEV), table.to(DEV), y.to(DEV)
-    L.lib().cond_combine_fwd(p(tb), p(tab), p(yd), p(c), p(cs), p(cb), N, D, st())
+    L.lib().cond_combine_fwd(p(tb), p(tab), p(yd), p(c), p(cs), p(cb), N, D, tab.shape[0], st())
     torch.cuda.synchronize()
     assert rel_err(c.cpu().numpy(), cref.numpy()) < 1e-6
     assert rel_err(cs.float().cpu().numpy(), (torch.nn.functional.silu(cref) / 0.596).numpy()) < 3e-3
@@ -603,7 +603,7 @@ def test_conditioning_kernels(L):
     dtemb = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
     dtable = torch.zeros(11, D, device=DEV)
     a, b = dcs.to(DEV), dcd.to(DEV)
-    L.lib().cond_combine_bwd(p(c), p(a), p(b), p(yd), p(dtemb), p(dtable), N, D, st())
+    L.lib().cond_combine_bwd(p(c), p(a), p(b), p(yd), p(dtemb), p(dtable), N, D, dtable.shape[0], st())
     torch.cuda.synchronize()
     assert rel_err(dtemb.float().cpu().numpy(), leaf_t.grad.numpy()) < 3e-3
     assert rel_err(dtable.cpu().numpy(), leaf_tab.grad.numpy()) < 1e-5

@@ -79,7 +79,7 @@ def test_eval_forward_matches_bf16_emulating_oracle(name):
 PRECISE_TOL = 1e-3      # BASELINE.json north_star: "forward logits within 1e-3 rel of reference"
 
 
-@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "s4_n8", "s2_n2", "b2_n2", "xl_d1", "tiny_p8"])
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "s4_n8", "s2_n2", "s2_n4", "b2_n2", "xl_d1", "xl2_n2", "tiny_p8"])
 def test_precise_forward_within_1e3_of_reference(name):
     """gemm_precision="bf16x3": fp32 activations and every linear on the MFMA GEMM kernel with hi+lo split operands.
     The logits must be within 1e-3 (norm-wise relative) of the reference's fp32 forward - the fixtures' ``eval_out`` were
@@ -103,7 +103,7 @@ def test_precise_forward_within_1e3_of_reference(name):
     assert e < PRECISE_TOL
 
 
-@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "s4_n8", "s2_n2", "b2_n2", "xl_d1", "tiny_p8"])
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "s4_n8", "s2_n2", "s2_n4", "b2_n2", "xl_d1", "xl2_n2", "tiny_p8"])
 def test_precise_training_gradients_match_reference(name):
     """Full training step in bf16x3 precision (fp32 activations, every product of the forward AND the backward on the MFMA
     GEMM kernel with two-term split operands, fp32 pointwise / attention backward kernels): per-sample losses and EVERY
@@ -302,15 +302,17 @@ def test_sampler_matches_reference(precision, tol):
     assert out.shape == z.shape and torch.isfinite(out).all()
 
 
-@pytest.mark.parametrize("name", ["s4_n8", "s2_n2", "b2_n2"])
+@pytest.mark.parametrize("name", ["s4_n8", "s2_n2", "s2_n4", "b2_n2", "xl2_n2"])
 def test_named_models_match_reference(name):
-    """DiT-S/4 (BASELINE configs[0]), DiT-S/2 (configs[1]) and DiT-B/2 (the metric's model) against reference outputs."""
+    """DiT-S/4 (BASELINE configs[0]), DiT-S/2 (configs[1], full depth at n = 2 and n = 4), DiT-B/2 (the metric's model) and
+    DiT-XL/2 (configs[3] / [4]: patch 2, depth 28, head_dim 72, 256 tokens) against the reference's own outputs: eval logits,
+    training losses and every parameter gradient of one training step."""
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.models import DIT_MODELS
     g = load_golden(name)
     cfg = golden_cfg(g)
     sd = golden_state_dict(g, cfg)
-    fam = {384: "S", 768: "B"}[cfg.hidden_size]
+    fam = {384: "S", 768: "B", 1152: "XL"}[cfg.hidden_size]
     m = DIT_MODELS[f"DiT-{fam}/{cfg.patch_size}"](in_channels=4, input_size=32, num_classes=1000)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
