@@ -5,17 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = label drop + q_sample + DiT-B/2 forward (incl. the forced-weight-norm pass that re-images the bf16
-weights) + MSE/vb loss + full backward + gradient sum over ranks (RCCL) + Adam + LR schedule + 2 EMA copies,
-on a synthetic batch of 32x32x4 latents resident in HBM.  Weak scaling: the per-GPU batch is fixed (256).
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the block-MLP fc1 GEMM), timed with HIP
-events on its launch stream inside the timed region; `cpu_baseline` times the CPU oracle (oracle/) on a bounded
-sample of the same model on the host cores — a reported baseline, not the target.
+One step = fresh synthetic batch (latents, labels, timesteps: drawn on the device) + label drop + q_sample + DiT-B/2 forward
+(incl. the forced-weight-norm pass that re-images the bf16 weights) + MSE/vb loss + full backward + gradient reduction over
+ranks (RCCL) + Adam + LR schedule + 2 EMA copies.
+
+Scaling.  BASELINE.json's configuration is a GLOBAL batch of 256 per node, sharded over the GPUs (per-GPU batch 256/N;
+SURVEY.md §8e): that is the default (`"scaling": "strong"`).  `--scaling weak` keeps 256 samples per GPU instead.
+
+Prints ONE JSON line on rank 0.  `value` = samples of all ranks / wall time of the K timed steps (barrier + synchronize on both
+sides, max over ranks); `ms_per_step_median` is the median over per-step HIP-event intervals of the same K steps.  `roofline` is
+for the dominant kernel (the block-MLP fc1 GEMM), timed with HIP events on its launch stream inside the timed region.  `parity`
+is the error of THIS engine (the timed precision) against the reference's own outputs for the same model (tests/golden fixture).
+`cpu_baseline` times the CPU oracle (oracle/) on a bounded sample of the same model on the host cores — a baseline, not a target.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0          # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FIXTURE_FOR = {"DiT-B/2": "b2_n2", "DiT-S/2": "s2_n4", "DiT-S/4": "s4_n8", "DiT-XL/2": "xl2_n2"}
 
 
 def fwd_flops_per_sample(depth, D, T, P):
@@ -34,8 +43,28 @@ def fwd_flops_per_sample(depth, D, T, P):
         + 2 * (256 * D + D * D) + 4 * D * D + 32 * D
 
 
-def cpu_baseline(model_name: str, batch: int, steps: int):
-    """The CPU oracle (own fp32 PyTorch-eager restatement, pinned to the reference by tests/golden) timed on the host."""
+def physical_cores():
+    """(physical cores, logical CPUs) of the host, from /proc/cpuinfo."""
+    seen = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (len(seen) or None), os.cpu_count()
+
+
+def cpu_steps(model_name: str, batch: int, steps: int):
+    """`steps` full training steps of the CPU oracle (own fp32 PyTorch-eager restatement, pinned to the reference by
+    tests/golden) on the host: the checker, timed as the reference's CPU path.  Returns latent-img/s and seconds per step."""
     from oracle import dit_oracle as O
     from oracle.diffusion_oracle import DiffusionOracle
     cfg = O.model_config(model_name, in_channels=4, input_size=32, num_classes=1000)
@@ -46,10 +75,10 @@ def cpu_baseline(model_name: str, batch: int, steps: int):
     emas = [{k: sd[k].clone() for k in params} for _ in range(2)]
     d = DiffusionOracle("")
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(batch, 4, 32, 32, generator=g)
-    y = torch.randint(0, 1000, (batch,), generator=g)
 
     def step(i):
+        x = torch.randn(batch, 4, 32, 32, generator=g)
+        y = torch.randint(0, 1000, (batch,), generator=g)
         t = torch.randint(0, 1000, (batch,), generator=g)
         drop = torch.rand(batch, generator=g) < 0.1
         leaf = {k: (sd[k].requires_grad_(True) if k in m else sd[k]) for k in sd}
@@ -68,47 +97,141 @@ def cpu_baseline(model_name: str, batch: int, steps: int):
     for i in range(steps):
         step(i + 2)
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "latent-img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{model_name}, batch {batch}, {steps} full steps (fwd+loss+bwd+Adam+2 EMA), fp32 eager oracle, "
-                      f"torch {torch.__version__}, {dt / steps:.2f} s/step"}
+    return batch * steps / dt, dt / steps
+
+
+def cpu_baseline(model_name: str, batch: int, steps: int, c1_steps: int):
+    phys, logical = physical_cores()
+    threads = torch.get_num_threads()
+    val, sps = cpu_steps(model_name, batch, steps)
+    out = {"value": val, "unit": "latent-img/s", "cores": threads, "kind": "port",
+           "host": {"physical_cores": phys, "logical_cpus": logical, "torch_threads": threads, "torch": torch.__version__},
+           "sample": f"{model_name}, batch {batch}, {steps} full steps (fwd+loss+bwd+Adam+2 EMA), fp32 eager oracle, "
+                     f"{sps:.2f} s/step"}
+    if c1_steps > 0:        # BASELINE.json configs[0]: the reference's own CPU-runnable case (SURVEY.md §8d "C1")
+        v1, s1 = cpu_steps("DiT-S/4", 8, c1_steps)
+        out["configs0"] = {"value": v1, "unit": "latent-img/s",
+                           "sample": f"DiT-S/4, batch 8, {c1_steps} full steps, fp32 eager oracle, {s1:.3f} s/step"}
+    return out
 
 
 def pmc_traffic(model, batch):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
-    guide's gfx950 correction + WRITE_SIZE; profiles/r01_fc1_pmc_traffic.json).  The counters cannot be collected from
-    inside this process; they hold for the kernel and shape they were taken on (DiT-B/2, 256 samples) and are null otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fc1_pmc_traffic.json")
-    if model != "DiT-B/2" or batch != 256 or not os.path.exists(path):
-        return {"traffic": None}
-    with open(path) as f:
-        d = json.load(f)
-    return {"traffic": d["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
-            "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": "profiles/r01_fc1_pmc_traffic.json"}
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the guide's
+    gfx950 correction + WRITE_SIZE).  The counters cannot be collected from inside this process; the committed figure holds for
+    the kernel SOURCE it was taken on (sha256 of csrc/gemm.hip recorded next to it), the model and the per-GPU batch: anything
+    else reports null rather than a stale number."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "map-dit_amd", "csrc", "gemm.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+    for name in ("r02_fc1_pmc_traffic.json", "r01_fc1_pmc_traffic.json"):
+        path = os.path.join(here, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("model", "DiT-B/2") != model or d.get("per_gpu_batch", 256) != batch:
+            continue
+        if d.get("gemm_hip_sha256") != sha:
+            return {"traffic": None, "traffic_note": f"profiles/{name} was collected on another build of csrc/gemm.hip"}
+        return {"traffic": d["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                "traffic_algorithmic": d["algorithmic_bytes_per_launch"], "traffic_source": f"profiles/{name}"}
+    return {"traffic": None}
+
+
+def parity_leg(model_name, precision, dev):
+    """Error of the timed engine against the REFERENCE's outputs on the committed fixture of this model (tests/golden/*.npz,
+    generated by running /root/reference in the build container): eval logits, per-sample training loss and parameter gradients
+    (norm-wise relative error over the sub-sampled gradient entries the fixture keeps, all tensors pooled; and the worst tensor).
+    The oracle is used only to regenerate the fixture's seeded weights."""
+    import numpy as np
+    fx = FIXTURE_FOR.get(model_name)
+    path = os.path.join(ROOT, "tests", "golden", f"{fx}.npz") if fx else None
+    if not path or not os.path.exists(path):
+        return None
+    from oracle import dit_oracle as O                     # checker: seeded weights of the fixture
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.models import DIT_MODELS
+    g = dict(np.load(path, allow_pickle=False))
+    cfg = O.DiTConfig(**{k[4:]: g[k].item() for k in g if k.startswith("cfg_")})
+    gains = g["gains"].item()
+    sd = O.init_state_dict(cfg, seed=int(g["wseed"]), gains=None if gains < 0 else gains, perturb_reference=float(g["perturb"]))
+    m = DIT_MODELS[model_name](in_channels=4, input_size=32, num_classes=1000)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.gemm_precision = precision
+    x, t, y, y_eff, noise = (torch.from_numpy(g[k]).to(dev) for k in ("x", "t", "y", "y_eff", "noise"))
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+    with torch.no_grad():
+        out = m(x, t, y)
+    ref = g["eval_out"]
+    got = out.cpu().numpy()
+    if got.shape != ref.shape:
+        got = got.reshape(-1)[::7] if got.size > 20000 else got.reshape(-1)
+    res = {"fixture": f"tests/golden/{fx}.npz", "logits_rel": rel(got, ref)}
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels        # the fixture's labels already carry the drop
+    losses = create_diffusion("").training_losses(m, x, t, dict(y=y_eff), noise=noise)
+    losses["loss"].mean().backward()
+    torch.cuda.synchronize()
+    res["loss_rel"] = rel(losses["loss"].detach().cpu().numpy(), g["train_loss"])
+    num = den = 0.0
+    worst, worst_k = 0.0, ""
+    stride = 7 if "postw/x_embedder.weight" in g else 4099      # tests/golden/make_golden.py: STRIDE / BIG_STRIDE
+    for k, p in m.named_parameters():
+        gref = g["grad/" + k].astype(np.float64)
+        if p.dim() == 0 or gref.size < 64:
+            continue
+        f = p.grad.detach().reshape(-1)
+        mine = (f if f.numel() <= 20000 else f[::stride]).double().cpu().numpy()
+        if mine.shape != gref.shape:
+            continue
+        d2, r2 = float(((mine - gref) ** 2).sum()), float((gref ** 2).sum())
+        num, den = num + d2, den + r2
+        e = (d2 / (r2 + 1e-60)) ** 0.5
+        if e > worst and r2 > 1e-14:
+            worst, worst_k = e, k
+    res["grad_rel"] = (num / (den + 1e-60)) ** 0.5
+    res["grad_rel_worst"] = worst
+    res["grad_rel_worst_tensor"] = worst_k
+    del m
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="DiT-B/2")
-    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: --global-batch per node, sharded over the GPUs (BASELINE.json); weak: --global-batch per GPU")
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the per-GPU batch directly")
     ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
                     help="bf16x3: the fp32-accurate parity engine (informational; the headline metric is bf16)")
+    ap.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
+                    help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-c1-steps", type=int, default=10)
     args = ap.parse_args()
 
     import torch.distributed as dist
     import mapdit_amd
     from mapdit_amd import _lib as L
+    from mapdit_amd import parallel
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.optim import FusedAdamEMA, create_lr_lambda
-    from mapdit_amd.parallel import OverlappedGradReducer, init_from_env
     from mapdit_amd.src.models import DIT_MODELS
 
-    rank, world, local = init_from_env()
+    rank, world, local = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product has no CPU path)"
     if os.environ.get("MAPDIT_FORCE_DEVICE"):              # rehearsal of the N > 1 path on a one-GPU box (gloo backend)
@@ -116,20 +239,34 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    torch.manual_seed(0)                                   # model seed 0
+    if args.batch_per_gpu is not None:
+        B = args.batch_per_gpu
+    elif args.scaling == "strong":
+        lo, hi = parallel.shard_batch(args.global_batch, rank, world)
+        B = hi - lo
+    else:
+        B = args.global_batch
+    global_batch = B * world
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_leg(args.model, args.precision, dev)
+
+    torch.manual_seed(0)                                   # model seed 0 on every rank: identical replicas, no broadcast needed
     model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000).to(dev).train()
     model.gemm_precision = args.precision
+    torch.manual_seed(1000 + rank)                         # from here on every rank draws its OWN timesteps, noise and label drops
     diffusion = create_diffusion(timestep_respacing="")
     num_steps = 400_000                                    # train.py defaults -> warm-up / decay points
-    reducer = OverlappedGradReducer(model)                 # all-reduce of block i overlaps backward of blocks i-1..0
+    reducer = parallel.make_reducer(model, args.grad_comm)
     opt = FusedAdamEMA(model, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
                        lr_lambda=create_lr_lambda(num_steps // 150, num_steps // 10), grad_scale=reducer.grad_scale)
-    B = args.batch_per_gpu
+    reducer.attach(opt)
     g = torch.Generator(device=dev).manual_seed(1 + rank)  # data seed 1 + rank
-    x = torch.randn(B, 4, 32, 32, device=dev, generator=g)
-    y = torch.randint(0, 1000, (B,), device=dev, generator=g)
 
     def step():
+        x = torch.randn(B, 4, 32, 32, device=dev, generator=g)              # a fresh batch every step
+        y = torch.randint(0, 1000, (B,), device=dev, generator=g)
         t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
         loss = diffusion.training_losses(model, x, t, dict(y=y))["loss"].mean()
         opt.zero_grad()
@@ -148,18 +285,23 @@ def main():
     fence()
     rt = model._rt[True if args.precision == "bf16" else (args.precision, True)]
     L.lib().engine_profile_begin(rt.handle, L.PROF_FC1_FWD, model.depth * args.steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()                              # on the compute stream; no host synchronisation inside the region
     fence()
     elapsed = time.perf_counter() - t0
     cnt, tot_ms = C.c_int(0), C.c_double(0.0)
     L.lib().engine_profile_end(rt.handle, C.byref(cnt), C.byref(tot_ms))
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     final_loss = float(loss.item())
+    model.check_device_errors()
 
     T = (model.input_size // model.patch_size) ** 2
     D, Hm = model.hidden_size, model.blocks[0].mlp.hidden_dim
@@ -169,18 +311,23 @@ def main():
     fc1_flops = 2.0 * (B * T) * Hm * D
     fc1_ms = tot_ms.value / max(cnt.value, 1)
     achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if cnt.value else None
+    at = f"@{global_batch}" if args.scaling == "strong" else f"@{B}/GPU"
     out = {
-        "metric": f"latent-images/sec training step, {args.model} {args.precision} @256",
+        "metric": f"latent-images/sec training step, {args.model} {args.precision} {at}",
         "value": value, "unit": "latent-img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": statistics.median(per_step),
+        "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (two-term split bf16 operands, fp32 accumulate and storage)", "data": "synthetic",
-        "config": {"workload": f"{args.model} full training step on 32x32x4 latents (fwd+loss+bwd+allreduce+Adam+2xEMA), "
-                               "all magnitude-preserving features on, bf16 GEMM operands / fp32 accumulate, master and "
+        "config": {"workload": f"{args.model} full training step on 32x32x4 latents (fresh batch+fwd+loss+bwd+grad reduction+Adam+"
+                               "2xEMA), all magnitude-preserving features on, bf16 GEMM operands / fp32 accumulate, master and "
                                "residual fp32",
-                   "global_batch": world * B, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
-                   "seeds": {"model": 0, "data": "1+rank"}, "final_loss": final_loss},
+                   "global_batch": global_batch, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
+                   "grad_comm": reducer.name,
+                   "seeds": {"model": 0, "data": "1+rank", "t/noise/drop": "1000+rank"}, "final_loss": final_loss},
         "step_mfma_frac": value * 3 * f_fwd / (world * PEAK_BF16_DENSE_TFLOPS * 1e12),
-        "roofline": {"bound": "mfma", "kernel": "gemm_mfma256_kernel<0, 0, EpiSilu2Grad> (NT, block-MLP fc1: "
+        "parity": parity,
+        "roofline": {"bound": "mfma", "kernel": "block-MLP fc1 GEMM with the SiLU + derivative epilogue (NT: "
                                                   f"[{B * T},{D}]x[{Hm},{D}]^T)",
                      "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, **pmc_traffic(args.model, B),
@@ -188,7 +335,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps, args.cpu_c1_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

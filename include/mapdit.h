@@ -82,6 +82,10 @@ int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda
                      const mapdit_epilogue_t* epi, void* stream);
 /* Edge (128 or 256) of the output tile the dispatcher picks for an [M, N] result (to size split_k). */
 int mapdit_gemm_tile_size(int M, int N);
+/* Benchmarking hook: force the tile edge (0 = by shape, 128, 256), the K-loop schedule (2 | 4 phases per K-tile) and the
+ * band width of the tile order (0 = derived from K).  The environment (MAPDIT_GEMM_TILE / _PHASES / _BAND) is read once, at the
+ * first launch; this overrides it afterwards. */
+void mapdit_gemm_tuning(int tile, int phases, long band);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight normalisation of MPLinear / MPLinearChunk / MPEmbedding (src/utils.py:19-34, mp_linear.py:38-44,66-74,

@@ -412,8 +412,8 @@ int mapdit_attn72_bwd(const uint16_t*, const uint16_t*, const uint16_t*, const u
                       uint16_t*, uint16_t*, uint16_t*, int, int, int, void*);
 static bool mfma72_shape(int T, int head_dim) {
     if (head_dim != 72 || !(T == 64 || T == 128 || T == 256)) return false;
-    const char* e = getenv("MAPDIT_ATTN72");
-    return !(e && e[0] == '0');
+    static const bool enabled = [] { const char* e = getenv("MAPDIT_ATTN72"); return !(e && e[0] == '0'); }();   // read once
+    return enabled;
 }
 
 extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse,

@@ -882,9 +882,32 @@ extern "C" void mapdit_debug_set_stamps_block(long long* p, int block) {      //
 }
 #endif
 
+// A/B switches for benchmarking, read from the environment ONCE (the first launch): the launch path makes no getenv calls.
+struct GemmEnv {
+    int tile = 0;        // MAPDIT_GEMM_TILE   = 128 | 256: force the tile edge
+    int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule
+    long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
+    GemmEnv() {
+        if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
+    }
+};
+static GemmEnv& gemm_env() {
+    static GemmEnv env;
+    return env;
+}
+// Tuning hook of the benchmarking tools (tools/gemm_bench.py, gemm_band_sweep.py): overrides what the environment said.
+// tile: 0 = by shape | 128 | 256;  phases: 2 | 4;  band: 0 = derived from K.  Not for use while launches are in flight elsewhere.
+extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
+    GemmEnv& e = gemm_env();
+    e.tile = tile;
+    e.phases = phases == 4 ? 4 : 2;
+    e.band = band;
+}
+
 extern "C" int mapdit_gemm_tile_size(int M, int N) {
-    const char* env = getenv("MAPDIT_GEMM_TILE");         // A/B switch for benchmarking (read per call, cheap)
-    const int force = env ? atoi(env) : 0;
+    const int force = gemm_env().tile;
     if (force == 128 || force == 256) return force;
     return (M >= 512 && N >= 256) ? 256 : 128;
 }
@@ -914,11 +937,10 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
-        const char* ph = getenv("MAPDIT_GEMM_PHASES");        // A/B switch for benchmarking: 4 = the quadrant-per-phase schedule
-        if (ph && atoi(ph) == 4) p.phases = 4;
+        p.phases = gemm_env().phases;
         // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
-        const char* be = getenv("MAPDIT_GEMM_BAND");
-        long band = be ? atol(be) : (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);
+        const bool be = gemm_env().band > 0;
+        long band = be ? gemm_env().band : (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);
         // every band re-reads the A panels once more, so banding only pays with wide bands: fewer than 4 column tiles
         // per band (large K) -> one full-width band (measured: band = 1 at K = 3072 costs 25 %)
         if (!be && band < 4) band = p.tiles_n;

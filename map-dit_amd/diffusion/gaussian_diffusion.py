@@ -295,6 +295,8 @@ class GaussianDiffusion:
                                                      denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
                                                      device=device, progress=progress):
             final = sample
+        with torch.cuda.device(final["sample"].device):
+            L.lib().device_error_poll(L.cur_stream())      # out-of-range label / timestep anywhere in the loop -> MapditError
         return final["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,

@@ -58,7 +58,7 @@ class FusedAdamEMA:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.ema = [flat.clone() for _ in self.ema_stds]
         self._gammas = [std_to_gamma(s) for s in self.ema_stds]
-        self.shard = (0, flat.numel())               # element range of the flat buffers this rank updates
+        self.shards = [(0, flat.numel())]            # element ranges of the flat buffers this rank updates
         self.after_step = None
 
     def zero_grad(self, set_to_none: bool = True):
@@ -82,8 +82,9 @@ class FusedAdamEMA:
         betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
         # the per-step values travel as kernel arguments: nothing is uploaded in the training loop
         hyper = L.AdamScalars(lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale)
-        lo, hi = self.shard                          # the whole flat buffer unless a ZeRO-1 reducer owns a partition
-        if hi > lo:
+        for lo, hi in self.shards:                   # the whole flat buffer unless a ZeRO-1 reducer handed over its partition
+            if hi <= lo:
+                continue
             off = lo * 4
             with torch.cuda.device(m._pflat.device):
                 L.lib().adam_ema_step_scalars(m._pflat.data_ptr() + off, m._gflat.data_ptr() + off, self.exp_avg.data_ptr() + off,

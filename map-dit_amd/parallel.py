@@ -137,6 +137,125 @@ class OverlappedGradReducer:
         self.finish()
 
 
+class _ReducerBase:
+    name = "none"
+
+    def attach(self, opt):
+        """Give the reducer the optimiser whose step it partitions (ZeRO-1); a no-op for the replicated reducers."""
+
+    def gather_state(self):
+        """Make optimiser / EMA state complete on every rank before a checkpoint (collective; a no-op when replicated)."""
+
+
+OverlappedGradReducer.name = "allreduce-fp32-per-stage-overlapped"
+OverlappedGradReducer.attach = _ReducerBase.attach
+OverlappedGradReducer.gather_state = _ReducerBase.gather_state
+GradReducer.gather_state = _ReducerBase.gather_state
+GradReducer.name = "allreduce-fp32-after-backward"
+GradReducer.attach = _ReducerBase.attach
+
+
+class Zero1Reducer(_ReducerBase):
+    """Reduce-scatter + sharded optimiser + all-gather (ZeRO stage 1; SURVEY.md §8e "optional").
+
+    Every backward stage's gradient slice [lo, hi) is cut into `world` equal parts; rank r receives the SUM of part r
+    (``reduce_scatter``, issued as soon as the stage is enqueued, so it overlaps the backward of the earlier blocks), runs the
+    fused Adam + EMA kernel on its parts only (1/world of the optimiser's 44 B/parameter HBM traffic and of its state), and the
+    updated parameter parts are all-gathered back into every rank's flat parameter buffer before the next forward.  Bytes on the
+    links equal those of the ring all-reduce it replaces (reduce-scatter + all-gather IS the all-reduce, with the optimiser in the
+    middle).  Replicas stay bit-identical: every parameter element is computed by exactly one rank and copied.
+
+    Adam moments and EMA copies of the parts a rank does not own are never touched: ``FusedAdamEMA.state_dict`` /
+    ``ema_state_dict`` of a sharded optimiser are partial; gather with ``gather_state()`` before checkpointing."""
+
+    name = "zero1: reduce-scatter fp32 per stage + sharded Adam/EMA + all-gather"
+
+    def __init__(self, model, group=None, force_collective: bool = False):
+        self.model, self.group = model, group
+        self.world = _world(group)
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.slices = stage_slices(model)
+        for lo, hi in self.slices:
+            assert (hi - lo) % (4 * self.world) == 0, "stage slices must split into 4-element aligned parts"
+        self.works = []
+        self.force_collective = force_collective
+        self.opt = None
+        staged = self.world > 1 or force_collective
+        model._stage_hook = self._on_stage if staged else None
+        self._native_rs = self.world > 1 and dist.get_backend(group) == "nccl"
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def parts(self):
+        """[(lo, hi)] element ranges of the flat buffers this rank owns, one per backward stage."""
+        out = []
+        for lo, hi in self.slices:
+            n = (hi - lo) // self.world
+            out.append((lo + self.rank * n, lo + (self.rank + 1) * n))
+        return out
+
+    def attach(self, opt):
+        self.opt = opt
+        if self.world > 1 or self.force_collective:
+            opt.shards = self.parts()
+            opt.after_step = self._gather_params
+
+    def _on_stage(self, stage: int):
+        if self.world == 1 and not self.force_collective:
+            return
+        lo, hi = self.slices[stage]
+        g = self.model._gflat
+        n = (hi - lo) // self.world
+        mine = g[lo + self.rank * n: lo + (self.rank + 1) * n]
+        if self._native_rs or (self.world == 1 and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+            # in place: the output is the rank-th part of the input (RCCL's in-place reduce-scatter layout)
+            self.works.append(dist.reduce_scatter_tensor(mine, g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:                                   # gloo has no reduce-scatter: all-reduce the slice, every rank then reads its own part
+            self.works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+
+    reduce = lambda self, flat=None: self.finish()
+
+    def gather_state(self):
+        if self.opt is not None:
+            for buf in [self.opt.exp_avg, self.opt.exp_avg_sq] + list(self.opt.ema):
+                self._gather(buf)
+
+    def _gather_params(self):
+        """All-gather of the parameter parts each rank has just updated (in place in the flat parameter buffer)."""
+        self._gather(self.model._pflat)
+
+    def _gather(self, p):
+        if self.world == 1 and not self.force_collective:
+            return
+        works = []
+        for lo, hi in self.slices:
+            n = (hi - lo) // self.world
+            mine = p[lo + self.rank * n: lo + (self.rank + 1) * n]
+            if self._native_rs or self.world == 1:
+                works.append(dist.all_gather_into_tensor(p[lo:hi], mine, group=self.group, async_op=True))
+            else:
+                works.append(dist.all_gather(list(p[lo:hi].chunk(self.world)), mine.clone(), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+
+def make_reducer(model, mode: str | None = None, group=None):
+    """``allreduce`` (default; per-stage all-reduce overlapped with backward, replicated optimiser) or ``zero1``."""
+    mode = mode or os.environ.get("MAPDIT_GRAD_COMM") or "allreduce"
+    if mode == "allreduce":
+        return OverlappedGradReducer(model, group)
+    if mode == "zero1":
+        return Zero1Reducer(model, group)
+    raise ValueError(f"unknown gradient exchange {mode!r} (allreduce | zero1)")
+
+
 def shard_batch(global_batch: int, rank: int, world: int):
     """[lo, hi) of this rank's samples when a global batch is split evenly (strong scaling); raises on ragged splits."""
     if global_batch % world:

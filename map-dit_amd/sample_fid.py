@@ -22,7 +22,9 @@ def build_parser():
     p.add_argument("--result-dir", type=str, required=True)
     p.add_argument("--use-vae", type=S.str2bool, default=True)
     p.add_argument("--cfg-scale", type=float, default=1.5)
-    p.add_argument("--num-classes", type=int, default=1_000)
+    p.add_argument("--num-classes", type=int, default=None,
+                   help="default: the trained model's num_classes from config.yaml (the reference defaults to 1000 whatever "
+                        "the model was trained with; a mismatch would index past its label table)")
     p.add_argument("--num-samples", type=int, default=10_000)
     p.add_argument("--batch-size", type=int, default=128)
     p.add_argument("--num-sampling-steps", type=int, default=250)
@@ -43,6 +45,11 @@ def main(argv=None):
         torch.manual_seed(args.seed)
     device = torch.device("cuda")
     train_args = S.load_train_args(args.result_dir)
+    if args.num_classes is None:
+        args.num_classes = int(train_args["num_classes"])
+    elif args.num_classes != int(train_args["num_classes"]):
+        raise ValueError(f"--num-classes {args.num_classes} != the trained model's num_classes {train_args['num_classes']} "
+                         "(config.yaml): labels and the null label would fall outside its embedding table")
     model = get_model(train_args).to(device)
     S.load_weights(model, args.result_dir, args.ema_std, args.ckpt, verbose=False)
     model.gemm_precision = args.precision

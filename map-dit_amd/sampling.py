@@ -26,7 +26,8 @@ class GraphedSampler:
         dev = next(model.parameters()).device
         self.dev = dev
         self.img = torch.zeros(*shape, device=dev)
-        self.t = torch.zeros(shape[0], device=dev, dtype=torch.int64)
+        # the warm-up and the capture below each run one real step (t -> t - 1): start high enough to stay inside the schedule
+        self.t = torch.full((shape[0],), max(diffusion.num_timesteps - 1, 0), device=dev, dtype=torch.int64)
         self.y = y.to(dev).clone()
         self.cfg_scale, self.clip = cfg_scale, bool(clip_denoised)
         self.tab = diffusion._tables(dev)
@@ -38,10 +39,12 @@ class GraphedSampler:
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(2):
+                    self.t.fill_(max(diffusion.num_timesteps - 1, 0))
                     self._step()
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
+            self.t.fill_(max(diffusion.num_timesteps - 1, 0))
             with torch.cuda.graph(self.graph):
                 self._step()
 
@@ -80,7 +83,9 @@ class GraphedSampler:
         self.t.fill_(n - 1)
         for _ in range(steps):
             self.graph.replay()
-        return self.img.clone()
+        out = self.img.clone()
+        self.model.check_device_errors()      # a label outside the embedding table (e.g. a null label the model has no row for)
+        return out
 
 
 def p_sample_loop_graphed(diffusion, model, shape, noise=None, clip_denoised=False, model_kwargs=None, device=None):

@@ -437,6 +437,10 @@ class DiT(nn.Module):
         return x, t, y
 
     # ---- reference API ----------------------------------------------------------------------------------------------
+    # The reference wraps the model in torch.compile (train.py:46, sample.py:25).  The whole network is one opaque engine call,
+    # there is nothing for a tracing compiler to fuse: dynamo is told not to trace into forward, so torch.compile(model) is a
+    # thin wrapper around the eager call (and its "_orig_mod."-prefixed state dicts load, see _strip_compile_prefix).
+    @torch.compiler.disable
     def forward(self, x, t, y):
         """x [N,C,H,W], t [N], y [N] -> [N,2C,H,W]   (reference src/dit.py:70-105)."""
         x, t, y = self._check_inputs(x, t, y)
@@ -469,6 +473,7 @@ class DiT(nn.Module):
             self._anchor_t = a
         return a
 
+    @torch.compiler.disable
     def forward_with_cfg(self, x, t, y, cfg_scale):
         """Classifier-free guidance batch (reference src/dit.py:107-118)."""
         half = x[: len(x) // 2]

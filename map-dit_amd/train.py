@@ -87,6 +87,9 @@ def build_parser():
     p.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
                    help="GEMM operand precision: bf16 (fast path) or bf16x3 (fp32-accurate forward and backward, the reference's "
                         "numerics to ~1e-5, several times slower)")
+    p.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
+                   help="data-parallel gradient exchange: per-stage all-reduce overlapped with backward (default), or "
+                        "reduce-scatter + sharded optimiser + all-gather")
     for f in MP_FLAGS:
         p.add_argument(f"--use-{f}", dest="use_" + f.replace("-", "_"), action=argparse.BooleanOptionalAction, default=True)
     return p
@@ -143,9 +146,14 @@ def main(argv=None):
         args.num_lin_warmup = args.num_steps // 150
     if args.start_decay is None:
         args.start_decay = args.num_steps // 10
-    reducer = parallel.OverlappedGradReducer(model)
+    # Identical parameters on every rank come from the shared seed above (no broadcast needed).  From here on each rank must draw
+    # its OWN timesteps, noise and label drops - the reference's single process draws them independently for all 256 samples
+    # (train.py:86; gaussian_diffusion.py:735; label_embedder.py:23) - so the default generators are re-seeded per rank.
+    torch.manual_seed(args.seed + 1000003 * (rank + 1))
+    reducer = parallel.make_reducer(model, args.grad_comm)
     opt = FusedAdamEMA(model, lr=args.lr, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
                        lr_lambda=create_lr_lambda(args.num_lin_warmup, args.start_decay), grad_scale=reducer.grad_scale)
+    reducer.attach(opt)
 
     def batches():
         if loader is None:
@@ -174,6 +182,7 @@ def main(argv=None):
         log_steps += 1
         train_steps += 1
         if train_steps % args.log_every == 0:
+            model.check_device_errors()          # an out-of-range label / timestep raises here (the reference: IndexError)
             avg = running / log_steps
             if world > 1:
                 torch.distributed.all_reduce(avg)
@@ -182,6 +191,8 @@ def main(argv=None):
             log(f"(step={train_steps:07d}) train loss: {avg.item():.4f}, train steps/sec: {sps:.2f}")
             running.zero_()
             log_steps, start = 0, time()
+        if train_steps % args.ckpt_every == 0 or (args.ema_snapshot_every and train_steps % args.ema_snapshot_every == 0):
+            reducer.gather_state()               # ZeRO-1: Adam moments / EMA copies are sharded; complete them (collective)
         if rank == 0 and train_steps % args.ckpt_every == 0:
             torch.save({"model": model.state_dict(), "opt": opt.state_dict()},                 # reference train.py:125-132
                        os.path.join(exp, "checkpoints", f"{train_steps:07d}.pt"))

@@ -1,0 +1,65 @@
+"""Worker of tests/test_train_gpu.py::test_two_rank_data_parallel_*: one data-parallel rank of a short training run.
+
+    python -m torch.distributed.run --nproc-per-node W ... tests/dp_worker.py OUT_DIR MODE PRECISION STEPS
+
+Every rank builds the same seeded model, takes ITS shard of a fixed global batch (same tensors on every rank, generated from a
+seed), runs STEPS optimiser steps through the reducer MODE ("allreduce" | "zero1") and writes its final flat parameter buffer,
+the reduced gradient buffer of the last step and (after gather_state) the Adam / EMA state to OUT_DIR/rank{r}.pt.
+With WORLD_SIZE=1 the same script is the single-process run on the whole batch.  Collectives run on gloo when
+MAPDIT_DIST_BACKEND=gloo (ranks share one GPU on a one-GPU box)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, mode, precision, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    import mapdit_amd  # noqa: F401
+    from mapdit_amd import parallel
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.optim import FusedAdamEMA
+    from mapdit_amd.src.models import DIT_MODELS
+    rank, world, _ = parallel.init_from_env()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(21)
+    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7).to(dev).train()
+    m.gemm_precision = precision
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    with torch.no_grad():                                   # non-trivial gains so that every gradient path is alive
+        for k, p in m.named_parameters():
+            if "gain_" in k:
+                p.fill_(0.2)
+    red = parallel.make_reducer(m, mode)
+    opt = FusedAdamEMA(m, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1), grad_scale=red.grad_scale)
+    red.attach(opt)
+    diff = create_diffusion("")
+    g = torch.Generator().manual_seed(22)
+    n = 16
+    lo, hi = parallel.shard_batch(n, rank, world)
+    for _ in range(steps):
+        x, y = torch.randn(n, 4, 32, 32, generator=g), torch.randint(0, 7, (n,), generator=g)
+        t, noise = torch.randint(0, 1000, (n,), generator=g), torch.randn(n, 4, 32, 32, generator=g)
+        x, y, t, noise = (v[lo:hi].to(dev) for v in (x, y, t, noise))
+        loss = diff.training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean()
+        opt.zero_grad()
+        loss.backward()
+        red.finish()
+        opt.step()
+    red.gather_state()
+    torch.cuda.synchronize()
+    parts = getattr(opt, "shards", None)
+    torch.save({"p": m._pflat.cpu(), "g": m._gflat.cpu() * red.grad_scale, "m": opt.exp_avg.cpu(), "v": opt.exp_avg_sq.cpu(),
+                "e0": opt.ema[0].cpu(), "e1": opt.ema[1].cpu(), "shards": parts, "loss": float(loss)},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

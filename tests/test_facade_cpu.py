@@ -77,3 +77,36 @@ def test_create_diffusion_tables_and_respacing():
     d = create_diffusion("", use_kl=True)
     with pytest.raises(NotImplementedError):
         d.training_losses(None, None, None)
+
+
+def test_compiled_module_checkpoints_load():
+    """The reference saves state dicts of a torch.compile'd module (train.py:46,125-132; src/ema.py:121): every key carries
+    an "_orig_mod." prefix.  Such checkpoints load unchanged, torch.compile(model) wraps the module without tracing into the
+    engine call, and the wrapper's own state dict round-trips."""
+    from mapdit_amd.src.dit import DiT
+    cfg = O.DiTConfig(depth=1, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
+    sd = O.init_state_dict(cfg, seed=3, gains=0.2)
+    m = DiT(**cfg.to_dict())
+    missing = m.load_state_dict({"_orig_mod." + k: v for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    cm = torch.compile(m)                                  # what reference train.py:46 does
+    csd = cm.state_dict()
+    assert all(k.startswith("_orig_mod.") for k in csd) and len(csd) == len(sd)
+    m2 = DiT(**cfg.to_dict())
+    m2.load_state_dict(csd)                                # a checkpoint written from the compiled wrapper
+    assert torch.equal(m2.blocks[0].attn.qkv_proj.weight, sd["blocks.0.attn.qkv_proj.weight"])
+    with pytest.raises(RuntimeError):                      # real mismatches still fail loudly
+        m2.load_state_dict({"_orig_mod." + k: v for k, v in sd.items() if "gain_msa" not in k})
+
+
+def test_flat_buffer_splits_into_stage_parts():
+    """ZeRO-1 layout: every backward stage's slice of the flat buffers splits into 8 four-element-aligned parts."""
+    from mapdit_amd.parallel import stage_slices
+    from mapdit_amd.src.models import DIT_MODELS
+    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=1000)
+    sl = stage_slices(m)
+    assert len(sl) == m.depth + 2
+    for lo, hi in sl:
+        assert (hi - lo) % 32 == 0 and lo % 32 == 0

@@ -483,3 +483,56 @@ def test_ragged_batches_and_single_samples(name, precision):
             assert abs(float(whole) - float(parts)) < 1e-3 * gain_scale + 1e-9, k
         elif float(whole.norm()) > 1e-9:
             assert float((whole - parts).norm() / whole.norm()) < 2e-5, k
+
+
+def test_out_of_range_label_and_stale_forward_are_refused():
+    """What the reference answers with an IndexError / what its autograd tracks per graph: a label outside the embedding
+    table never indexes memory (clamped + reported by check_device_errors), a backward through anything but the most recent
+    training forward raises, and so does asking for input gradients."""
+    from mapdit_amd import _lib as L
+    from mapdit_amd.diffusion import create_diffusion
+    g = load_golden("tiny_a")
+    m, cfg, _ = build(g, train=True)
+    x, t, y = dev(g, "x", "t", "y")
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    m.check_device_errors()                                   # clean
+    bad = y.clone()
+    bad[1] = cfg.num_classes + 5                              # one past the null row and beyond
+    out = m(x, t, bad)
+    out.sum().backward()                                      # backward must not write outside the table gradient either
+    with pytest.raises(L.MapditError, match="label"):
+        m.check_device_errors()
+    m.check_device_errors()                                   # the record was cleared
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    tbad = t.clone()
+    tbad[0] = 1000
+    with torch.no_grad():
+        create_diffusion("").q_sample(x, tbad, torch.zeros_like(x))
+    with pytest.raises(L.MapditError, match="timestep"):
+        m.check_device_errors()
+    # one outstanding forward per model
+    for p in m.parameters():
+        p.grad = None
+    la = m(x, t, y).sum()
+    lb = m(x, t, y).sum()
+    with pytest.raises(L.MapditError, match="stale"):
+        la.backward()
+    lb.backward()
+    with pytest.raises(L.MapditError, match="input latents"):
+        m(x.clone().requires_grad_(True), t, y)
+
+
+def test_torch_compile_wrapper_runs():
+    """torch.compile(model) (reference train.py:46, sample.py:25) must run: same bits as the bare module, training included."""
+    g = load_golden("tiny_a")
+    m, cfg, _ = build(g)
+    x, t, y = dev(g, "x", "t", "y")
+    cm = torch.compile(m)
+    with torch.no_grad():
+        a, b = m(x, t, y), cm(x, t, y)
+        c = torch.compile(m.forward_with_cfg)(x, t, y, 1.5)
+    assert torch.equal(a, b) and c.shape == a.shape
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    cm(x, t, y).sum().backward()
+    assert m.blocks[0].mlp.net[0].weight.grad is not None

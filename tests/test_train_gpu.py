@@ -190,15 +190,70 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, MAPDIT_DIST_BACKEND="gloo", MAPDIT_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch-per-gpu", "16", "--model", "DiT-S/2"]
+           "--global-batch", "32", "--model", "DiT-S/2"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                 # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["per_gpu_batch"] == 16 and d["metric"].endswith("@32") and d["ms_per_step_median"] > 0
+    assert d["parity"] is not None and d["parity"]["logits_rel"] < 3e-2
     assert d["value"] > 0 and d["steps"] == 2 and "cpu_baseline" not in d
     assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
+
+
+def _run_dp(tmp_path, tag, world, mode, precision, steps=3):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / tag
+    out.mkdir()
+    env = dict(os.environ, MAPDIT_DIST_BACKEND="gloo")
+    worker = os.path.join(root, "tests", "dp_worker.py")
+    if world == 1:
+        cmd = [sys.executable, worker, str(out), mode, precision, str(steps)]
+        env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), worker, str(out), mode, precision, str(steps)]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [torch.load(out / f"rank{i}.pt", weights_only=False) for i in range(world)]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
+    """Two data-parallel ranks (different halves of a fixed global batch each; gloo collectives, both ranks on this box's one
+    GPU) against ONE process on the whole batch, three optimiser steps, for both gradient exchanges:
+
+    * the overlapped per-stage all-reduce relies on every stage's gradient slice being FINAL when its all-reduce is issued and
+      on no later stage writing into it: a write-after-reduce or a wrong slice shows up here as a gradient / weight mismatch
+      (a one-rank group cannot see it: its all-reduce is an identity);
+    * replicas must hold the same bits after the run (forced weight normalisation is a function of the weights alone);
+    * ZeRO-1 (reduce-scatter, sharded Adam + EMA, all-gather) must produce the bits of the replicated optimiser.
+
+    Reduced gradients / weights vs the single process: summation order differs (mean of two half-batch means), so 2e-5 on the
+    fp32-accurate engine; the bf16 engine computes each sample independently of its batch, same bound on gradients of 1e-4."""
+    single = _run_dp(tmp_path, "w1", 1, "allreduce", precision)[0]
+    ar = _run_dp(tmp_path, "ar", 2, "allreduce", precision)
+    z1 = _run_dp(tmp_path, "z1", 2, "zero1", precision)
+    for k in ("p", "g", "m", "v", "e0", "e1"):
+        assert torch.equal(ar[0][k], ar[1][k]), f"allreduce replicas differ in {k}"
+        assert torch.equal(z1[0][k], z1[1][k]), f"zero1 replicas differ in {k}"
+    tol = 2e-5 if precision == "bf16x3" else 1e-4
+    for k in ("g", "p", "m", "e0"):
+        e = rel_err(ar[0][k].numpy(), single[k].numpy())
+        print(f"{precision}: 2-rank all-reduce vs single process, {k}: {e:.2e}")
+        assert e < tol, (k, e)
+    # the sharded optimiser is the replicated one, bit for bit (same reduced gradients: gloo's all-reduce on both paths)
+    for k in ("p", "m", "v", "e0", "e1"):
+        assert torch.equal(z1[0][k], ar[0][k]), f"zero1 != replicated optimiser in {k}"
+    assert z1[0]["shards"] != z1[1]["shards"] and len(z1[0]["shards"]) == 6 + 2        # DiT-XS: 6 blocks + final + embedders
 
 
 def test_ema_class_matches_fused_optimizer(tmp_path):

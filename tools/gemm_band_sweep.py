@@ -35,14 +35,10 @@ cases = [("NT M x3D x D ", 0, M, 3 * D, D, x, D, w3, D, 3 * D),
          ("NN M x D x4D (fc1 dX)", 1, M, D, 4 * D, dh, 4 * D, w4, D, D),
          ("NN M x4D x D (fc2 dX)", 1, M, 4 * D, D, dy, D, w4t, 4 * D, 4 * D),
          ("NN M x D x3D (qkv dX)", 1, M, D, 3 * D, dh, 4 * D, w3, D, D)]
-os.environ["MAPDIT_GEMM_TILE"] = "256"
 for name, layout, m, n, k, a, lda, b, ldb, ldo in cases:
     row = []
     for band in ("auto", 1, 2, 3, 4, 6, 12):
-        if band == "auto":
-            os.environ.pop("MAPDIT_GEMM_BAND", None)
-        else:
-            os.environ["MAPDIT_GEMM_BAND"] = str(band)
+        L.lib().gemm_tuning(256, 2, 0 if band == "auto" else band)
         ms = sorted(run(layout, m, n, k, a, lda, b, ldb, ep(ldo), 10) for _ in range(3))[1]
         row.append(f"{band}:{2.0 * m * n * k / ms / 1e9:6.0f}")
     print(f"{name:24s} " + "  ".join(row))

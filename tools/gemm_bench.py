@@ -81,8 +81,7 @@ def main():
         res = {v[0]: [] for v in variants}
         for _ in range(args.rounds):
             for vname, tile, phases in variants:
-                os.environ["MAPDIT_GEMM_TILE"] = str(tile)
-                os.environ["MAPDIT_GEMM_PHASES"] = str(phases)
+                L.lib().gemm_tuning(tile, phases, 0)
                 ee = e
                 if ee is None:
                     tiles = ((m + tile - 1) // tile) * ((n + tile - 1) // tile)
@@ -94,8 +93,7 @@ def main():
         for vname, _, _ in variants:
             ms = sorted(res[vname])[len(res[vname]) // 2]
             print(f"{name:20s} {vname:>8s} {ms:8.3f} {flops / ms / 1e9:9.1f}")
-    os.environ.pop("MAPDIT_GEMM_PHASES", None)
-    os.environ.pop("MAPDIT_GEMM_TILE", None)
+    L.lib().gemm_tuning(0, 2, 0)
 
 
 if __name__ == "__main__":
