@@ -48,6 +48,13 @@ enum {
     MAPDIT_EPI_SILU2_GRAD = 7, /* out = bf16(d/dh[silu(h)/0.596]) at h = acc [optional]; out2 = bf16(silu(acc)/0.596): the backward
                                 * needs the pre-activation only through this factor, and here it comes out of the same exp / rcp */
     MAPDIT_EPI_MUL_AUX = 8,    /* out = bf16(acc * aux), aux bf16 [M, ldo]   (backward of SILU2_GRAD: aux = its first output)   */
+    MAPDIT_EPI_RMB = 9,        /* the dX GEMM of a branch fused with what follows it in the backward pass: acc is the gradient wrt
+                                * u = modulate(x', shift, scale, gain), and the epilogue does what mapdit_resid_mod_bwd does with
+                                * it (utils.py:11-16 backward): dx' = ca*dxo + k*scale*acc, the per-sample column sums dshift /
+                                * dscale / dgate and the gain partials (one per output tile), and dy_up = cb*gate_up*dx'.  `rmb`
+                                * holds the operands (its dxm field is ignored: the accumulator takes its place).  Needs
+                                * T = rmb->T with T % 64 == 0, M >= 512, N = D >= 256 (256x256 tiles: a tile holds whole 64-row
+                                * blocks of one sample each).  dgain_part receives ceil(M/256) * ceil(D/256) partials.          */
     MAPDIT_EPI_QKV_HEADS = 6   /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
                                 * is (which, head, d) = (n / D, n % D / 64, n % 64); q and k rows are cosine-normalised per
                                 * head, x * s with s = 8 / (|x| + 1e-4) from the fp32 accumulators, and everything is written
@@ -76,6 +83,7 @@ typedef struct {
     int split_k;       /* STORE_F32 only: K is cut into split_k ranges, partial sum z is stored at out + z*slab_stride */
     long slab_stride;  /* elements between slabs (the consumer adds the slabs: mapdit_weightnorm_bwd) */
     void* out4;        /* QKV_HEADS only: the per-(token, head) normalisation scales */
+    const void* rmb;   /* RMB only: const mapdit_resid_mod_bwd_t* (declared below) */
 } mapdit_epilogue_t;
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,

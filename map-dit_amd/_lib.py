@@ -24,7 +24,7 @@ class MapditError(RuntimeError):
 class Epilogue(C.Structure):
     _fields_ = [("kind", ci), ("out", vp), ("ldo", ci), ("out2", vp), ("aux", vp), ("gate", vp), ("ldg", ci),
                 ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci), ("out3", vp), ("shift2", vp), ("scale2", vp),
-                ("gain2", vp), ("ld2", ci), ("split_k", ci), ("slab_stride", cl), ("out4", vp)]
+                ("gain2", vp), ("ld2", ci), ("split_k", ci), ("slab_stride", cl), ("out4", vp), ("rmb", vp)]
 
 
 class ResidModBwd(C.Structure):
@@ -51,7 +51,7 @@ PRECISIONS = {"bf16": 0, "bf16x3": 1}
 
 
 NT, NN, TN = 0, 1, 2
-EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS, EPI_SILU2_GRAD, EPI_MUL_AUX = range(9)
+EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS, EPI_SILU2_GRAD, EPI_MUL_AUX, EPI_RMB = range(10)
 PROF_FC1_FWD = 0
 PEEK_IDS = {name: i for i, name in enumerate(
     ["four", "temb", "c", "mod_all", "x0", "xmodf", "lin", "xm", "qkv", "qn", "kn", "v", "o", "xm2", "hact", "xmid", "xout"])}

@@ -352,6 +352,30 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
     return want < 1 ? 1 : (int)want;
 }
 
+// dX GEMM of a branch, dxm = dy W, followed by the backward of modulate() and of the residual mp_sum above it.  Where the shape
+// allows (whole 64-row blocks per sample, 256x256 tiles) both run as ONE launch: the GEMM's epilogue consumes the fp32 accumulators
+// (MAPDIT_EPI_RMB) - the bf16 dxm tensor is neither written nor re-read and the pointwise pass disappears; otherwise the GEMM stores
+// dxm and mapdit_resid_mod_bwd follows.  `a` arrives filled except for dxm.  Ends with the deterministic sum of the gain partials.
+int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy, const bf16_t* wimg, mapdit_resid_mod_bwd_t& a,
+                     float* dgain, void* st) {
+    static const bool no_fuse = [] { const char* v = getenv("MAPDIT_NO_FUSED_RMB"); return v && v[0] == '1'; }();
+    const int D = e->D;
+    int npart;
+    if (!no_fuse && e->T % 64 == 0 && M >= 512 && D >= 256 && K % 64 == 0) {
+        mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
+        ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
+        a.dxm = nullptr;
+        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, ep, st));
+        npart = cdiv(M, 256) * cdiv(D, 256);
+    } else {
+        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
+        a.dxm = e->dxm;
+        TRY(mapdit_resid_mod_bwd(&a, st));
+        npart = a.n_samples * (D / 128);
+    }
+    return mapdit_reduce_partials(e->gain_part, npart, dgain, 0, st);
+}
+
 // dW for one linear: G = dy^T x (TN GEMM into scratch), then the weight-norm Jacobian into the bound grad.
 int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf16_t* x, int ld_x, int K, float alpha, void* st) {
     const WeightImg& w = e->wimg[pidx];
@@ -369,6 +393,28 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
 }
 
 }  // namespace
+
+extern "C" int mapdit_device_error_poll(void* stream) {
+    int a = 0, b = 0, c = 0;
+    const int rc = mapdit_dev_error_take_embed((hipStream_t)stream, &a) | mapdit_dev_error_take_diffusion((hipStream_t)stream, &b) |
+                   mapdit_dev_error_take_precise((hipStream_t)stream, &c);
+    if (rc) {
+        mapdit_set_error("device_error_poll: reading the device error words failed");
+        return MAPDIT_ERR_HIP;
+    }
+    const int code = a | b | c;
+    if (code & MAPDIT_DEVERR_LABEL) {
+        mapdit_set_error("index out of range: a class label outside [0, embedding rows) reached the label embedding (the kernels "
+                         "clamped it; results of that call are invalid)");
+        return MAPDIT_ERR_ARG;
+    }
+    if (code & MAPDIT_DEVERR_TIMESTEP) {
+        mapdit_set_error("index out of range: a timestep outside [0, num_timesteps) reached the diffusion tables (clamped; results "
+                         "of that call are invalid)");
+        return MAPDIT_ERR_ARG;
+    }
+    return MAPDIT_OK;
+}
 
 extern "C" size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int train) {
     if (check_cfg(cfg) != MAPDIT_OK) return 0;
@@ -848,8 +894,6 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     hipStream_t hs = (hipStream_t)st;
     auto W = [&](int idx) { return e->wimg[idx].img; };
     auto G = [&](int idx) { return e->grads[idx]; };
-    const int npart = N * (D / 128);
-
     if (stage_from == 0) {
     hipError_t he = hipMemsetAsync(e->dcs, 0, (size_t)N * D * 4, hs);
     if (he == hipSuccess) he = hipMemsetAsync(e->dcd, 0, (size_t)N * D * 4, hs);
@@ -869,18 +913,16 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(gemm(MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
         TRY(linear_dw(e, pi, da, NSCALE, e->c_bf, D, N, 1.f, st));
     }
-    TRY(gemm(MAPDIT_NN, M, D, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), D, epi_bf16(e->dxm, D), st));
     TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, e->ldl, e->xmodf, D, M, 1.f, st));
     {
         const BlockBufs& bl = e->blk[L - 1];
         mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-        a.dxm = e->dxm; a.x = e->X[2 * L]; a.shift = e->fmod; a.scale = e->fmod + D; a.gain = e->params[MAPDIT_P_F_GAIN];
+        a.x = e->X[2 * L]; a.shift = e->fmod; a.scale = e->fmod + D; a.gain = e->params[MAPDIT_P_F_GAIN];
         a.ldmod = 2 * D; a.dshift = e->dfmod; a.dscale = e->dfmod + D; a.ldd = 2 * D; a.dgain_part = e->gain_part;
         a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * 6 * D + 5 * D; a.ldg_up = e->ldm; a.dy_up = e->dy;
         a.dg_up = e->dmod + (size_t)(L - 1) * 6 * D + 5 * D; a.ldd_up = e->ldm;
         a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-        TRY(mapdit_resid_mod_bwd(&a, st));
-        TRY(mapdit_reduce_partials(e->gain_part, npart, G(MAPDIT_P_F_GAIN), 0, st));
+        TRY(dx_resid_mod_bwd(e, M, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), a, G(MAPDIT_P_F_GAIN), st));
     }
     TRY(mapdit_f32_to_bf16(e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
     TRY(gemm(MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
@@ -898,17 +940,15 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // MLP branch
         TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
-        TRY(gemm(MAPDIT_NN, M, D, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXa; a.dxm = e->dxm; a.x = e->X[2 * i + 1]; a.shift = mod + 3 * D; a.scale = mod + 4 * D;
+            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = mod + 3 * D; a.scale = mod + 4 * D;
             a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldm;
             a.dshift = dmod + 3 * D; a.dscale = dmod + 4 * D; a.ldd = ldm; a.dgain_part = e->gain_part;
             a.y_up = b.y; a.g_up = mod + 2 * D; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + 2 * D; a.ldd_up = ldm;
             a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            TRY(mapdit_resid_mod_bwd(&a, st));
-            TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), 0, st));
+            TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st));
         }
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
@@ -919,11 +959,10 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         } else {   // normalisation Jacobian + head merge inside the attention backward passes
             TRY(mapdit_attn_cos_bwd_fused(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, b.qks, e->dqkv, N, T, H, e->hd, st));
         }
-        TRY(gemm(MAPDIT_NN, M, D, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(e->dxm, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXb; a.dxm = e->dxm; a.x = e->X[2 * i]; a.shift = mod; a.scale = mod + D;
+            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = mod; a.scale = mod + D;
             a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldm;
             a.dshift = dmod; a.dscale = dmod + D; a.ldd = ldm; a.dgain_part = e->gain_part;
             if (i > 0) {
@@ -935,8 +974,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
             }
             a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            TRY(mapdit_resid_mod_bwd(&a, st));
-            TRY(mapdit_reduce_partials(e->gain_part, npart, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), 0, st));
+            TRY(dx_resid_mod_bwd(e, M, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), a, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), st));
         }
         // modulation linear of this block (its six gradient chunks are complete now): dW here, so the block's gradient
         // slice is final when its stage ends (the DP reducer relies on that); d c_silu for all blocks in one GEMM below

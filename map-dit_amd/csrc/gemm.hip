@@ -20,6 +20,7 @@
 // buffers) so the epilogue runs on whole 8-column row chunks with fully coalesced 16/32-byte accesses.
 // Block ids are remapped so each XCD (private L2) works on a contiguous band of output tiles.
 #include <stdarg.h>
+#include <type_traits>
 #include <stdio.h>
 
 #include "common.h"
@@ -359,6 +360,96 @@ struct EpiDSilu {
     }
 };
 
+// The dX GEMM of a branch fused with the backward of modulate() and of the residual mp_sum above it (what
+// resid_mod_bwd_kernel in pointwise.hip does as a separate pass; reference src/utils.py:11-16 through autograd).  v = the gradient
+// wrt u = modulate(x', shift, scale, gain) straight from the accumulators:
+//   dx' = ca dxo + k scale v                       k = (1-g)/den, kb = g/den, kd = 1/den, den = sqrt((1-g)^2 + g^2)
+//   dscale[s] = sum_t k x' v    dshift[s] = sum_t kb v    dgain += sum v (shift - x' scale) kd
+//   dy_up = cb gate_up dx'      dgate_up[s] = sum_t cb y_up dx'
+// A 256-row tile holds whole 64-row blocks (T % 64 == 0), each inside one sample: the per-sample column sums are sums over a
+// thread's four rows of a block, then over the 16 threads that share its columns (one xor-shuffle + eight LDS rows), then over
+// the blocks of the sample - all in a fixed order: no atomics, bit-reproducible.
+struct EpiRmb {
+    const float* dxo; const float* x; const float* shift; const float* scale; const float* gain;
+    const bf16_t* y_up; const float* g_up;
+    float* dx; bf16_t* dx_bf; bf16_t* dy_up; float* dshift; float* dscale; float* dg_up; float* dgain_part;
+    int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb;
+    static constexpr int kBatch = 4;                   // one 64-row block's four chunks per thread in flight together
+    struct Aux { float4 x0, x1, d0, d1; u32x4_t y; };
+    struct Tile { float4 sc0, sc1, sh0, sh1, gu0, gu1; };
+    struct Acc { float sc[8], sh[8], g[8], gain; };    // running sums of the current 64-row block (gain: of the whole tile)
+    __device__ __forceinline__ void coef(float& k, float& kb, float& kd) const {
+        const float gg = *gain, den = sqrtf((1.f - gg) * (1.f - gg) + gg * gg);
+        k = (1.f - gg) / den; kb = gg / den; kd = 1.f / den;
+    }
+    __device__ __forceinline__ Tile block_begin(int m_block, int n) const {     // per-column operands of the block's sample
+        const int smp = m_block / T;
+        Tile t;
+        const float4* sc = (const float4*)(scale + (size_t)smp * ldmod + n);
+        const float4* sh = (const float4*)(shift + (size_t)smp * ldmod + n);
+        t.sc0 = sc[0]; t.sc1 = sc[1]; t.sh0 = sh[0]; t.sh1 = sh[1];
+        t.gu0 = t.gu1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y_up) {
+            const float4* gu = (const float4*)(g_up + (size_t)smp * ldg_up + n);
+            t.gu0 = gu[0]; t.gu1 = gu[1];
+        }
+        return t;
+    }
+    __device__ __forceinline__ Aux load(int m, int n) const {
+        Aux a;
+        const float4* xi = (const float4*)(x + (size_t)m * ldo + n);
+        a.x0 = xi[0]; a.x1 = xi[1];
+        a.d0 = a.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dxo) {
+            const float4* di = (const float4*)(dxo + (size_t)m * ldo + n);
+            a.d0 = di[0]; a.d1 = di[1];
+        }
+        a.y = u32x4_t{0u, 0u, 0u, 0u};
+        if (y_up) a.y = __builtin_nontemporal_load((const u32x4_t*)(y_up + (size_t)m * ldo + n));
+        return a;
+    }
+    __device__ __forceinline__ void apply_r(int m, int n, const float* v, const Aux& a, const Tile& t, Acc& r, float k, float kb,
+                                            float kd) const {
+        const float xx[8] = {a.x0.x, a.x0.y, a.x0.z, a.x0.w, a.x1.x, a.x1.y, a.x1.z, a.x1.w};
+        const float dd[8] = {a.d0.x, a.d0.y, a.d0.z, a.d0.w, a.d1.x, a.d1.y, a.d1.z, a.d1.w};
+        const float sc[8] = {t.sc0.x, t.sc0.y, t.sc0.z, t.sc0.w, t.sc1.x, t.sc1.y, t.sc1.z, t.sc1.w};
+        const float sh[8] = {t.sh0.x, t.sh0.y, t.sh0.z, t.sh0.w, t.sh1.x, t.sh1.y, t.sh1.z, t.sh1.w};
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = ca * dd[i] + k * sc[i] * v[i];
+            r.sc[i] += k * xx[i] * v[i];
+            r.sh[i] += kb * v[i];
+            r.gain += v[i] * (sh[i] - xx[i] * sc[i]) * kd;
+        }
+        if (dx) {
+            float4* p = (float4*)(dx + (size_t)m * ldo + n);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (dx_bf) store8_bf16(dx_bf + (size_t)m * ldo + n, o);
+        if (y_up) {
+            const float gu[8] = {t.gu0.x, t.gu0.y, t.gu0.z, t.gu0.w, t.gu1.x, t.gu1.y, t.gu1.z, t.gu1.w};
+            const u32x4_t u = a.y;
+            const float yy[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                 __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                 __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+            float w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w[i] = cb * gu[i] * o[i];
+                r.g[i] += cb * yy[i] * o[i];
+            }
+            store8_bf16(dy_up + (size_t)m * ldo + n, w);
+        }
+    }
+    // never instantiated paths (the launcher only takes the 256^2 kernel for this epilogue)
+    typedef EpiNoTile TileUnused;
+    __device__ __forceinline__ void operator()(int, int, const float*, int = 0) const {}
+};
+template <class Epi> constexpr bool kReduce = false;
+template <> constexpr bool kReduce<EpiRmb> = true;
+
 // QKV projection with the head split and the cosine normalisation of q, k fused in.  Every kernel above hands the 8
 // chunks of one 64-column head segment of a row to 8 consecutive lanes, so the per-head sum of squares is three
 // xor-shuffles.  (which, head) are uniform over those 8 lanes; the row's predicate too.
@@ -494,11 +585,18 @@ constexpr int OFF_A0 = 0, OFF_A1 = SLOT_BYTES, OFF_B0 = 2 * SLOT_BYTES, OFF_B1 =
 constexpr int CS2_LD = 260;                               // fp32 row stride of the epilogue image (1040 B)
 constexpr int SMEM2_BYTES = 128 * CS2_LD * 4;             // 133,120 B >= 2 x 64 KiB staging
 #ifdef MAPDIT_GEMM_STAMPS
+constexpr int SMEM_PH1 = 163840;                          // one-phase loop: 3 A + 2 B buffers = all 160 KiB of LDS
+#else
+constexpr int SMEM_PH1 = 163840;
+#endif
+#ifdef MAPDIT_GEMM_STAMPS
 // Timeline instrumentation (tools/gemm_stamps.py builds this variant into its own library; never part of libmapdit_hip.so):
 // lane 0 of waves 0 and 4 of workgroup 0 stamps the shader clock at 11 points of every K-tile into spare LDS, and copies the
 // stamps out when the tile is done.
 constexpr int STAMP_TILES = 12, STAMP_POINTS = 11;
 __device__ long long* g_stamps = nullptr;
+__device__ long long* g_wg_times = nullptr;     // [grid][4]: s_memrealtime at entry / exit (100 MHz), cycles in between, XCC id
+extern "C" __global__ void mapdit_debug_set_wg_times_kernel(long long* p) { g_wg_times = p; }
 __device__ int g_stamp_block = -1;
 extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int block) { g_stamps = p; g_stamp_block = block; }
 #define G256_STAMP(PT)                                                                              \
@@ -525,6 +623,12 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 // (copied out at the very end of the kernel: a copy placed after the K loop held the stamping waves back by ~10 k cycles and the
 // workgroup with them, and made the loop look that much longer)
 #define G256_STAMPS_OUT()                                                                           \
+    if (g_wg_times && wave == 0 && lane == 0) {                                                     \
+        long long* r_ = g_wg_times + 4 * (long long)blockIdx.x;                                     \
+        r_[0] = wg_r0; r_[1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
+        r_[2] = (long long)__builtin_readcyclecounter() - wg_t0;                                    \
+        r_[3] = (long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);              \
+    }                                                                                               \
     if (stamp_on) {                                                                                 \
         for (int i = 0; i < STAMP_TILES * STAMP_POINTS; ++i)                                        \
             g_stamps[wm * STAMP_TILES * STAMP_POINTS + i] = stamp_lds[wm * STAMP_TILES * STAMP_POINTS + i]; \
@@ -538,6 +642,13 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 #define G256_STAMPS_OUT()
 #endif
 
+// Ablation builds (tools/gemm_ablate.py; timing experiments, results are garbage): MAPDIT_GEMM_ABLATE bit 0 drops the K loop's
+// LDS-DMA (after the prologue), bit 1 its fragment reads (after the first K-tile).
+#ifndef MAPDIT_GEMM_ABLATE
+#define MAPDIT_GEMM_ABLATE 0
+#endif
+#define ABL_DMA(...) do { if (!(MAPDIT_GEMM_ABLATE & 1)) { __VA_ARGS__; } } while (0)
+#define ABL_READ(...) do { if (!(MAPDIT_GEMM_ABLATE & 2) || t == 0) { __VA_ARGS__; } } while (0)
 template <int SIDE> __device__ __forceinline__ int half_map(int i, int h) {
     return SIDE == 0 ? ((i >> 6) * 128 + h * 64 + (i & 63)) : ((i >> 5) * 64 + h * 32 + (i & 31));
 }
@@ -578,13 +689,18 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
     __builtin_amdgcn_s_barrier();                         \
     __builtin_amdgcn_sched_barrier(0)
 
-template <int AK, int BK, class Epi, bool KTAIL = false>
+template <int AK, int BK, class Epi, bool KTAIL = false, int PH = 2>
 __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
 #ifdef MAPDIT_GEMM_STAMPS
-    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES + (2 * STAMP_TILES * STAMP_POINTS + 8) * 8];
-    long long* stamp_lds = (long long*)(smem + SMEM2_BYTES);
+    // (the one-phase loop uses all 160 KiB of LDS: its stamps go straight to the global buffer - the stamping waves then carry a
+    // few extra stores in their vmcnt queues, which the instrumented timeline has to live with)
+    constexpr int SM = PH == 1 ? SMEM_PH1 : SMEM2_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM + (PH == 1 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
+    long long* stamp_lds = PH == 1 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
+    const long long wg_t0 = (long long)__builtin_readcyclecounter();
+    const long long wg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #else
-    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[PH == 1 ? SMEM_PH1 : SMEM2_BYTES];
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -616,6 +732,93 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PH == 1) {
+        // ---- ONE phase per K-tile ------------------------------------------------------------------------------------------
+        // The two wave groups still alternate LOAD and MFMA intervals one barrier apart, but an interval covers a whole K-tile:
+        // 24 fragment reads + 8 LDS-DMA pieces against 64 MFMAs (1024 cycles): half as many barriers per K-tile as the two-phase
+        // loop.  LDS (all 160 KiB): THREE A buffers and TWO B buffers of two 16 KiB slots each {rows of group 0 | rows of group 1}
+        // resp. {columns 0..127 | columns 128..255}, every slot the swizzled [128 idx][64 k] image of the 128^2 kernel.  A wave reads
+        // the A slot of its group and the B slot of its column half.  Group g stages, during its LOAD interval of tile t, B_g of
+        // tile t+1 and then A_g of tile t+2: the A panels stream from HBM and get four intervals (two K-tiles) of prefetch distance,
+        // the B panel is L2-resident and gets one or two.
+        //   RAW  every wait is vmcnt(4): it leaves the four youngest pieces (A_g of tile t+2) in flight.  Group 0's B pieces
+        //        (issued in interval 2t) are waited for at the end of its MFMA interval 2t+1 and read from 2t+2 on; group 1's B
+        //        pieces (issued in 2t+1) are read by group 0 in 2t+2, so group 1 retires them before the barrier that ends 2t+1.
+        //        A_g(t+2), issued in LOAD(t), is retired at the end of MFMA(t+1) at the latest and read in LOAD(t+2).
+        //   WAR  B buffer (t+1)&1 was last read in intervals 2t-2 (group 0) and 2t-1 (group 1); A buffer (t+2)%3 = (t-1)%3 slot g was
+        //        last read by group g itself in LOAD(t-1); all reads were drained (lgkmcnt(0)) before the barrier ending the interval.
+        constexpr int A_BUF = 2 * SLOT_BYTES, B_BASE = 3 * A_BUF, B_BUF = 2 * SLOT_BYTES;
+        static_assert(B_BASE + 2 * B_BUF <= SMEM_PH1, "LDS layout");
+        bf16x8_t fa[8][2], fb[4][2];
+        const int wq = wave & 3;                               // wave within its group: four 1 KiB pieces of every slot it stages
+        auto stage_a = [&](int kt, int abuf) {
+            stage_tile<AK, KTAIL>(p.A, p.lda, m0 + 128 * wm, p.M, kbeg + kt * BKT, p.K, smem + abuf * A_BUF + wm * SLOT_BYTES, wq, lane);
+        };
+        auto stage_b = [&](int kt) {
+            stage_tile<BK, KTAIL>(p.B, p.ldb, n0 + 128 * wm, p.N, kbeg + kt * BKT, p.K, smem + B_BASE + (kt & 1) * B_BUF + wm * SLOT_BYTES, wq, lane);
+        };
+        stage_a(0, 0);
+        stage_b(0);
+        if (nk > 1) {
+            stage_a(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 1) {                                         // stagger: group 1 runs one interval behind
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        G256_TSTAMP(1);
+        G256_RSTAMP(5);
+        int a_cur = 0;                                         // t % 3
+        for (int t = 0; t < nk; ++t) {
+            const char* a_slot = smem + a_cur * A_BUF + wm * SLOT_BYTES;
+            const char* b_slot = smem + B_BASE + (t & 1) * B_BUF + (wn >> 1) * SLOT_BYTES;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            G256_STAMP(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK>(a_slot, i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[j][ks] = read_frag<BK>(b_slot, (wn & 1) * 64 + j * 16, ks, lane);
+            if (has1) stage_b(t + 1);
+            if (has2) stage_a(t + 2, a_cur == 0 ? 2 : a_cur - 1);       // (t + 2) % 3
+            G256_STAMP(1);
+            if (wm == 1 && has1) {
+                if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_STAMP(2);
+            G256_END_LOAD();
+            G256_STAMP(3);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            G256_STAMP(4);
+            if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G256_END_MFMA();
+            G256_STAMP(5);
+            a_cur = a_cur == 2 ? 0 : a_cur + 1;
+        }
+        if (wm == 0) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];               // B half 0 stays in registers for phases 1 and 4
 
     auto load_a = [&](const char* slot) {
@@ -679,11 +882,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
             G256_STAMP(0);
-            load_a(cur + OFF_A0);
-            G256_LOAD_B(fb0, cur + OFF_B0);
-            G256_LOAD_B(fb1, cur + OFF_B1);
+            ABL_READ(load_a(cur + OFF_A0));
+            ABL_READ(G256_LOAD_B(fb0, cur + OFF_B0));
+            ABL_READ(G256_LOAD_B(fb1, cur + OFF_B1));
             if (has1) {
-                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane);
+                ABL_DMA(stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane));
                 G256_STAMP(1);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else {
@@ -697,11 +900,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             G256_STAMP(4);
             G256_END_MFMA();
             G256_STAMP(5);
-            load_a(cur + OFF_A1);
+            ABL_READ(load_a(cur + OFF_A1));
             if (has2) {
-                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane);
-                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane);
-                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane);
+                ABL_DMA(stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane));
+                ABL_DMA(stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane));
+                ABL_DMA(stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane));
                 G256_STAMP(6);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else if (has1) {
@@ -756,6 +959,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+    }   // PH != 1
     __syncthreads();
     G256_TSTAMP(2);
     G256_RSTAMP(6);
@@ -809,6 +1013,133 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         G256_STAMPS_OUT();
         return;
     }
+    if constexpr (kReduce<Epi>) {
+        // Epilogue with per-sample column sums (EpiRmb).  Per pass: the 128-row fp32 image as below, then per 64-row block
+        // (thread rows it = 4 half .. 4 half + 3, all inside one sample) the stream operands of its four chunks are loaded together
+        // and applied; each thread's sums over its rows are added across the two row groups of a wave (lanes l, l ^ 32), parked in
+        // LDS per wave once every read of the image is done, and summed over the eight waves by the thread that owns the column.
+        float* cs = (float*)smem;
+        const int ecol = (tid & 31) * 8, gn = n0 + ecol;
+        const bool col_ok = gn < p.N;
+        float ck, ckb, ckd;
+        epi.coef(ck, ckb, ckd);
+        float gain_acc = 0.f;
+        float tot[2][2][3];                                    // [pass][half][dscale, dshift, dgate] of column n0 + tid (tid < 256)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 64 + i * 16 + (lane & 15);
+                    const int col = wn * 64 + j * 16 + 4 * (lane >> 4);
+                    *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
+                }
+            typename Epi::Acc r[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int mb = m0 + half * 128 + pass * 64;    // first row of this 64-row block
+                typename Epi::Tile tl;
+                typename Epi::Aux aux[4];
+                const bool blk_ok = col_ok && mb < p.M;
+                if (blk_ok) tl = epi.block_begin(mb, gn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gm = mb + (tid >> 5) + 16 * q;
+                    if (blk_ok && gm < p.M) aux[q] = epi.load(gm, gn);
+                }
+                if (half == 0) __syncthreads();                // the image is complete
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[half].sc[i] = r[half].sh[i] = r[half].g[i] = 0.f;
+                r[half].gain = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = half * 64 + (tid >> 5) + 16 * q;
+                    const int gm = mb + (tid >> 5) + 16 * q;
+                    if (blk_ok && gm < p.M) {
+                        float v[8];
+                        *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + ecol);
+                        *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
+                        epi.apply_r(gm, gn, v, aux[q], tl, r[half], ck, ckb, ckd);
+                    }
+                }
+                gain_acc += r[half].gain;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                  // the wave's two row groups
+                    r[half].sc[i] += __shfl_xor(r[half].sc[i], 32, 64);
+                    r[half].sh[i] += __shfl_xor(r[half].sh[i], 32, 64);
+                    r[half].g[i] += __shfl_xor(r[half].g[i], 32, 64);
+                }
+            }
+            __syncthreads();                                   // every read of the image is done: its space holds the partials now
+            float* red = (float*)smem;                         // [half][out][wave][256 columns]
+            if (lane < 32) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float* base = red + ((half * 3) * 8 + wave) * 256 + ecol;
+                    *(float4*)(base) = make_float4(r[half].sc[0], r[half].sc[1], r[half].sc[2], r[half].sc[3]);
+                    *(float4*)(base + 4) = make_float4(r[half].sc[4], r[half].sc[5], r[half].sc[6], r[half].sc[7]);
+                    *(float4*)(base + 8 * 256) = make_float4(r[half].sh[0], r[half].sh[1], r[half].sh[2], r[half].sh[3]);
+                    *(float4*)(base + 8 * 256 + 4) = make_float4(r[half].sh[4], r[half].sh[5], r[half].sh[6], r[half].sh[7]);
+                    *(float4*)(base + 16 * 256) = make_float4(r[half].g[0], r[half].g[1], r[half].g[2], r[half].g[3]);
+                    *(float4*)(base + 16 * 256 + 4) = make_float4(r[half].g[4], r[half].g[5], r[half].g[6], r[half].g[7]);
+                }
+            }
+            __syncthreads();
+            if (tid < 256) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) a += red[((half * 3 + o) * 8 + w) * 256 + tid];
+                        tot[pass][half][o] = a;
+                    }
+            }
+            __syncthreads();                                   // before the next pass' image (or the gain partials) reuse the space
+        }
+        // per-sample sums: the tile's four 64-row blocks in row order, consecutive blocks of one sample added up
+        if (tid < 256 && n0 + tid < p.N) {
+            const int c = n0 + tid;
+            int s_prev = -1;
+            float a[3] = {0.f, 0.f, 0.f};
+            auto flush = [&](int smp) {
+                epi.dscale[(size_t)smp * epi.ldd + c] = a[0];
+                epi.dshift[(size_t)smp * epi.ldd + c] = a[1];
+                if (epi.y_up) epi.dg_up[(size_t)smp * epi.ldd_up + c] = a[2];
+            };
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int half = b >> 1, pass = b & 1;
+                const int mb = m0 + 64 * b;
+                if (mb < p.M) {
+                    const int smp = mb / epi.T;
+                    if (smp != s_prev) {
+                        if (s_prev >= 0) flush(s_prev);
+                        a[0] = a[1] = a[2] = 0.f;
+                        s_prev = smp;
+                    }
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) a[o] += tot[pass][half][o];
+                }
+            }
+            if (s_prev >= 0) flush(s_prev);
+        }
+        // the tile's share of the scalar gain gradient: one partial per tile, summed in tile order by reduce_partials
+        gain_acc = wave_sum(gain_acc);
+        float* gred = (float*)smem;
+        if (lane == 0) gred[wave] = gain_acc;
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += gred[w];
+            epi.dgain_part[z * p.tiles + tile] = a;
+        }
+        G256_STAMPS_OUT();
+        return;
+    } else {
     float* cs = (float*)smem;
     const int ecol = (tid & 31) * 8, gn = n0 + ecol;
     const bool col_ok = gn < p.N;
@@ -847,6 +1178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
         G256_TSTAMP(3 + pass);
     }
     G256_STAMPS_OUT();
+    }   // !kReduce
 }
 
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
@@ -876,6 +1208,10 @@ extern "C" void mapdit_debug_set_stamps(long long* p) {
     hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p, -1);
     (void)hipDeviceSynchronize();
 }
+extern "C" void mapdit_debug_set_wg_times(long long* p) {
+    hipLaunchKernelGGL(mapdit_debug_set_wg_times_kernel, dim3(1), dim3(1), 0, 0, p);
+    (void)hipDeviceSynchronize();
+}
 extern "C" void mapdit_debug_set_stamps_block(long long* p, int block) {      // stamp workgroup `block` instead of 8
     hipLaunchKernelGGL(mapdit_debug_set_stamps_kernel, dim3(1), dim3(1), 0, 0, p, block);
     (void)hipDeviceSynchronize();
@@ -889,7 +1225,7 @@ struct GemmEnv {
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -902,7 +1238,7 @@ static GemmEnv& gemm_env() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : 2;
     e.band = band;
 }
 
@@ -930,6 +1266,12 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (!a_kmaj && lda % 8 != 0) mfma = false;
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
+    if constexpr (kReduce<Epi>) {      // per-tile reductions exist in the 256^2 kernel only
+        if (!mfma || ktail || mapdit_gemm_tile_size(M, N) != 256) {
+            mapdit_set_error("gemm: this epilogue needs the 256x256 MFMA path (M=%d N=%d K=%d: K %% 64 == 0, M >= 512, N >= 256, aligned operands)", M, N, K);
+            return MAPDIT_ERR_ARG;
+        }
+    }
     if (split_k > 1 && (!mfma || split_k > (K + BKT - 1) / BKT)) {
         mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= ceil(K/64) (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
@@ -947,18 +1289,25 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
         const int grid = p.tiles * split_k;
+        auto go = [&](auto tail, auto ph) {
+            constexpr bool TAIL = decltype(tail)::value;
+            constexpr int PH = decltype(ph)::value;
+            if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi, TAIL, PH>), dim3(grid), dim3(512), 0, st, p, epi);
+            else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi, TAIL, PH>), dim3(grid), dim3(512), 0, st, p, epi);
+            else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi, TAIL, PH>), dim3(grid), dim3(512), 0, st, p, epi);
+        };
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        bool done = false;
         if constexpr (kHasTail<Epi>) {
             if (ktail) {
-                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
-                else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
-                else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi, true>), dim3(grid), dim3(512), 0, st, p, epi);
-                MD_LAUNCH_CHECK();
-                return MAPDIT_OK;
+                if (p.phases == 1) go(std::true_type(), T1()); else go(std::true_type(), T2());
+                done = true;
             }
         }
-        if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
-        else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
-        else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(512), 0, st, p, epi);
+        if (!done) {
+            if (p.phases == 1) go(std::false_type(), T1()); else go(std::false_type(), T2());
+        }
     } else if (mfma) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4};
         p.tiles = cdiv(M, BM) * p.tiles_n;
@@ -998,34 +1347,12 @@ void mapdit_set_error(const char* fmt, ...) {
 extern "C" const char* mapdit_last_error(void) { return g_err; }
 extern "C" int mapdit_abi_version(void) { return 2; }
 
-extern "C" int mapdit_device_error_poll(void* stream) {
-    int a = 0, b = 0, c = 0;
-    const int rc = mapdit_dev_error_take_embed((hipStream_t)stream, &a) | mapdit_dev_error_take_diffusion((hipStream_t)stream, &b) |
-                   mapdit_dev_error_take_precise((hipStream_t)stream, &c);
-    if (rc) {
-        mapdit_set_error("device_error_poll: reading the device error words failed");
-        return MAPDIT_ERR_HIP;
-    }
-    const int code = a | b | c;
-    if (code & MAPDIT_DEVERR_LABEL) {
-        mapdit_set_error("index out of range: a class label outside [0, embedding rows) reached the label embedding (the kernels "
-                         "clamped it; results of that call are invalid)");
-        return MAPDIT_ERR_ARG;
-    }
-    if (code & MAPDIT_DEVERR_TIMESTEP) {
-        mapdit_set_error("index out of range: a timestep outside [0, num_timesteps) reached the diffusion tables (clamped; results "
-                         "of that call are invalid)");
-        return MAPDIT_ERR_ARG;
-    }
-    return MAPDIT_OK;
-}
-
 extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {
     MD_CHECK(layout >= MAPDIT_NT && layout <= MAPDIT_TN, "gemm: bad layout %d", layout);
     MD_CHECK(M > 0 && N > 0 && K > 0 && A && B && e, "gemm: null/empty argument (M=%d N=%d K=%d)", M, N, K);
     MD_CHECK(e->out || e->kind == MAPDIT_EPI_SILU2 || e->kind == MAPDIT_EPI_SILU2_COND || e->kind == MAPDIT_EPI_RESID ||
-                 e->kind == MAPDIT_EPI_SILU2_GRAD,
+                 e->kind == MAPDIT_EPI_SILU2_GRAD || e->kind == MAPDIT_EPI_RMB,
              "gemm: null output");
     MD_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
     MD_CHECK(e->ldo % 8 == 0 || e->kind == MAPDIT_EPI_QKV_HEADS, "gemm: ldo=%d must be a multiple of 8", e->ldo);
@@ -1062,6 +1389,20 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
         case MAPDIT_EPI_DSILU:
             MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
+        case MAPDIT_EPI_RMB: {
+            const mapdit_resid_mod_bwd_t* a = (const mapdit_resid_mod_bwd_t*)e->rmb;
+            MD_CHECK(a, "gemm: RMB needs rmb");
+            MD_CHECK(a->x && a->shift && a->scale && a->gain && a->dshift && a->dscale && a->dgain_part && (a->dx || a->dx_bf),
+                     "gemm: RMB needs x, shift, scale, gain, dshift, dscale, dgain_part and dx or dx_bf");
+            MD_CHECK(!a->y_up || (a->g_up && a->dy_up && a->dg_up), "gemm: RMB residual backward needs g_up, dy_up, dg_up");
+            MD_CHECK(a->T > 0 && a->T % 64 == 0 && M % a->T == 0 && N == a->D,
+                     "gemm: RMB needs T %% 64 == 0, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
+            MD_CHECK(a->ldmod % 4 == 0 && a->ldg_up % 4 == 0 && e->ldo % 8 == 0, "gemm: RMB row strides must be multiples of 4 / 8");
+            return launch(layout, M, N, K, A, lda, B, ldb,
+                          EpiRmb{a->dxo, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx, (bf16_t*)a->dx_bf,
+                                 (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod, a->ldg_up, a->ldd,
+                                 a->ldd_up, a->T, a->ca, a->cb}, st);
+        }
         case MAPDIT_EPI_QKV_HEADS: {
             MD_CHECK(e->out2 && e->out3 && e->out4 && e->rows_per_sample > 0, "gemm: QKV_HEADS needs out2, out3, out4, rows_per_sample");
             MD_CHECK(N % 192 == 0 && M % e->rows_per_sample == 0, "gemm: QKV_HEADS needs N = 3 * 64 * heads, M = samples * rows_per_sample");

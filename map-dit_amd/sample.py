@@ -46,6 +46,8 @@ def main(argv=None):
 
     n = 4                                                                  # sample.py:40
     z = torch.randn(n, train_args["in_channels"], train_args["input_size"], train_args["input_size"], device=device)
+    if not 0 <= args.class_label < int(train_args["num_classes"]):       # the reference fails inside F.embedding (IndexError)
+        raise ValueError(f"--class-label {args.class_label} is outside the trained model's {train_args['num_classes']} classes")
     y = torch.tensor([args.class_label] * n, device=device)
     z = torch.cat([z, z], dim=0)                                          # CFG batch: conditional | null class
     y = torch.cat([y, torch.tensor([train_args["num_classes"]] * n, device=device)], dim=0)

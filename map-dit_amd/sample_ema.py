@@ -42,6 +42,8 @@ def main(argv=None):
     diffusion = create_diffusion(str(args.num_sampling_steps))
     n = 8
     shape = (2 * n, train_args["in_channels"], train_args["input_size"], train_args["input_size"])
+    if not 0 <= args.class_label < int(train_args["num_classes"]):       # the reference fails inside F.embedding (IndexError)
+        raise ValueError(f"--class-label {args.class_label} is outside the trained model's {train_args['num_classes']} classes")
     y = torch.cat([torch.tensor([args.class_label] * n), torch.tensor([train_args["num_classes"]] * n)]).to(device)
     graphed = None
     res = []

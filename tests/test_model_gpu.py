@@ -530,7 +530,7 @@ def test_torch_compile_wrapper_runs():
     cm = torch.compile(m)
     with torch.no_grad():
         a, b = m(x, t, y), cm(x, t, y)
-        c = torch.compile(m.forward_with_cfg)(x, t, y, 1.5)
+        c = cm.forward_with_cfg(x, t, y, 1.5)        # sample.py:25,54 passes the compiled module's bound method to the sampler
     assert torch.equal(a, b) and c.shape == a.shape
     m.train()
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels

@@ -80,10 +80,13 @@ def test_sample_and_sample_ema_cli(exp_dir, tmp_path):
     assert img.size == (2 * 34 + 2, 2 * 34 + 2) and img.mode == "RGBA"     # 2x2 grid, 2-pixel padding like torchvision
     # bf16x3 precision and the eager loop run through the same CLI
     c = sample.main(["--result-dir", exp_dir, "--use-vae", "false", "--num-sampling-steps", "2", "--output-file", out, "--seed", "5",
-                     "--precision", "bf16x3", "--no-graph", "--ckpt", "0000008"])
+                     "--precision", "bf16x3", "--no-graph", "--ckpt", "0000008", "--class-label", "9"])
     assert c.shape == (4, 4, 32, 32) and torch.isfinite(c).all()
     out2 = str(tmp_path / "ema.png")
-    e = sample_ema.main(["--result-dir", exp_dir, "--use-vae", "false", "--num-sampling-steps", "2", "--output-file", out2])
+    with pytest.raises(ValueError, match="class-label"):      # default label 88, model trained on 10 classes (reference: IndexError)
+        sample_ema.main(["--result-dir", exp_dir, "--use-vae", "false", "--num-sampling-steps", "2", "--output-file", out2])
+    e = sample_ema.main(["--result-dir", exp_dir, "--use-vae", "false", "--num-sampling-steps", "2", "--output-file", out2,
+                         "--class-label", "0"])
     assert e.shape == (8 * 5, 4, 32, 32)
     assert Image.open(out2).size == (5 * 34 + 2, 8 * 34 + 2)
     assert np.load(out2 + ".npy").shape == (40, 4, 32, 32)

@@ -239,21 +239,30 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
 
     Reduced gradients / weights vs the single process: summation order differs (mean of two half-batch means), so 2e-5 on the
     fp32-accurate engine; the bf16 engine computes each sample independently of its batch, same bound on gradients of 1e-4."""
-    single = _run_dp(tmp_path, "w1", 1, "allreduce", precision)[0]
     ar = _run_dp(tmp_path, "ar", 2, "allreduce", precision)
     z1 = _run_dp(tmp_path, "z1", 2, "zero1", precision)
     for k in ("p", "g", "m", "v", "e0", "e1"):
         assert torch.equal(ar[0][k], ar[1][k]), f"allreduce replicas differ in {k}"
         assert torch.equal(z1[0][k], z1[1][k]), f"zero1 replicas differ in {k}"
-    tol = 2e-5 if precision == "bf16x3" else 1e-4
-    for k in ("g", "p", "m", "e0"):
-        e = rel_err(ar[0][k].numpy(), single[k].numpy())
-        print(f"{precision}: 2-rank all-reduce vs single process, {k}: {e:.2e}")
-        assert e < tol, (k, e)
     # the sharded optimiser is the replicated one, bit for bit (same reduced gradients: gloo's all-reduce on both paths)
     for k in ("p", "m", "v", "e0", "e1"):
         assert torch.equal(z1[0][k], ar[0][k]), f"zero1 != replicated optimiser in {k}"
     assert z1[0]["shards"] != z1[1]["shards"] and len(z1[0]["shards"]) == 6 + 2        # DiT-XS: 6 blocks + final + embedders
+    # against ONE process on the whole batch.  After the first step only the summation order differs (identical weights in).
+    # Over several steps the bf16 engine amplifies that 1e-7 through bf16 re-rounding of the re-normalised weights (a flipped
+    # rounding is a 2^-9 change: DESIGN.md section 2), so its multi-step comparison is loose; the fp32-accurate engine stays tight.
+    single1 = _run_dp(tmp_path, "w1s1", 1, "allreduce", precision, steps=1)[0]
+    ar1 = _run_dp(tmp_path, "ars1", 2, "allreduce", precision, steps=1)[0]
+    for k in ("g", "p", "m", "e0"):
+        e = rel_err(ar1[k].numpy(), single1[k].numpy())
+        print(f"{precision}: 2-rank all-reduce vs single process after 1 step, {k}: {e:.2e}")
+        assert e < 2e-5, (k, e)
+    single3 = _run_dp(tmp_path, "w1s3", 1, "allreduce", precision)[0]
+    tol = 2e-5 if precision == "bf16x3" else 2e-2
+    for k in ("g", "p", "m", "e0"):
+        e = rel_err(ar[0][k].numpy(), single3[k].numpy())
+        print(f"{precision}: 2-rank all-reduce vs single process after 3 steps, {k}: {e:.2e}")
+        assert e < tol, (k, e)
 
 
 def test_ema_class_matches_fused_optimizer(tmp_path):
