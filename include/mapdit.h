@@ -90,6 +90,9 @@ int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda
                      const mapdit_epilogue_t* epi, void* stream);
 /* Edge (128 or 256) of the output tile the dispatcher picks for an [M, N] result (to size split_k). */
 int mapdit_gemm_tile_size(int M, int N);
+/* The same for a launch that will cut K (split_k > 1): such launches fill the chip through the cut, so the 256 edge is kept
+ * for all but the smallest outputs. */
+int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch);
 /* Benchmarking hook: force the tile edge (0 = by shape, 128, 256), the K-loop schedule (2 | 4 phases per K-tile) and the
  * band width of the tile order (0 = derived from K).  The environment (MAPDIT_GEMM_TILE / _PHASES / _BAND) is read once, at the
  * first launch; this overrides it afterwards. */

@@ -113,6 +113,7 @@ _OTHER = {
     "mapdit_last_error": (C.c_char_p, []),
     "mapdit_abi_version": (ci, []),
     "mapdit_gemm_tile_size": (ci, [ci, ci]),
+    "mapdit_gemm_tile_size_ex": (ci, [ci, ci, ci]),
     "mapdit_gemm_tuning": (None, [ci, ci, cl]),
     "mapdit_engine_workspace_bytes": (C.c_size_t, [C.POINTER(Config), ci]),
     "mapdit_engine_destroy": (None, [vp]),

@@ -341,7 +341,7 @@ mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const floa
 // Largest divisor s of K/64 with tiles*s <= ~1024 blocks (4 per CU) and s <= max_slabs.
 int pick_split_k(int rows, int cols, int K, long max_slabs) {
     if (K % 64 != 0 || rows % 8 != 0 || cols % 8 != 0) return 1;       // not on the MFMA path
-    const int edge = mapdit_gemm_tile_size(rows, cols);
+    const int edge = mapdit_gemm_tile_size_ex(rows, cols, 1);
     const int tiles = cdiv(rows, edge) * cdiv(cols, edge);
     const int units = K / 64;
     // One full round of the chip (256 CUs x 1 workgroup of the 256^2 kernel, x 2 of the 128^2 kernel): every block
@@ -361,7 +361,9 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     static const bool no_fuse = [] { const char* v = getenv("MAPDIT_NO_FUSED_RMB"); return v && v[0] == '1'; }();
     const int D = e->D;
     int npart;
-    if (!no_fuse && e->T % 64 == 0 && M >= 512 && D >= 256 && K % 64 == 0) {
+    // (fused where the dX result takes the 256^2 kernel and a pointwise pass over it would run on a small grid: measured 1.3 %
+    // of the step at 32 and 64 samples, nothing at 256, where the separate pass streams at 5.3 TB/s)
+    if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_ex(M, D, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
         a.dxm = nullptr;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
 
 // ---- fragment reads ---------------------------------------------------------------------------------
 // 16x16x32 operand fragment: lane l holds [idx = i0 + (l & 15)][k = 32 ks + 8 (l >> 4) + j], j = 0..7.
-template <int KIND>
+template <int KIND, bool TR_ASM = true>
 __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, int lane) {
     if (KIND == OP_ROW) {
         const int row = i0 + (lane & 15);
@@ -93,14 +93,39 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int i0, int ks, 
         return *(const bf16x8_t*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
     } else {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-        const int k_a = 32 * ks + 8 * g + q, k_b = k_a + 4;
         const int c = (i0 >> 3) + (pp >> 1);
         const int sub = (pp & 1) << 3;
-        const int off_a = k_a * 256 + ((c ^ (kswz(k_a) << 1)) << 4) + sub;
-        const int off_b = k_b * 256 + ((c ^ (kswz(k_b) << 1)) << 4) + sub;
-        typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
-        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_a));
-        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_b));
+        bf16x4_t lo, hi;
+#ifdef MAPDIT_TR_BUILTIN        // A/B builds only (tools/_stamps): the builtin form everywhere
+        constexpr bool use_asm = false;
+#else
+        constexpr bool use_asm = TR_ASM;
+#endif
+        if constexpr (!use_asm) {
+            // The builtin form: hipcc puts an s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA is in flight.  Kept where that
+            // measured FASTER: the NN layout of the 256^2 kernel (1,295 vs 1,238 TFLOP/s at K = 3072, same box).
+            const int k_a = 32 * ks + 8 * g + q, k_b = k_a + 4;
+            const int off_a = k_a * 256 + ((c ^ (kswz(k_a) << 1)) << 4) + sub;
+            const int off_b = k_b * 256 + ((c ^ (kswz(k_b) << 1)) << 4) + sub;
+            typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_a));
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + off_b));
+        } else {
+        // Inline asm, not __builtin_amdgcn_ds_read_tr16_b64: hipcc puts an s_waitcnt vmcnt(0) in front of the builtin whenever an
+        // LDS-DMA is in flight (it cannot tell the read from the DMA's LDS destination), which drains the whole prefetch pipeline
+        // once per K-tile (same box, asm vs builtin: dW GEMMs of the 256^2 kernel 812 vs 736 and 704 vs 660 TFLOP/s, the 128^2
+        // kernel 694 vs 526 (TN) and 980 vs 832 (NN)).  An asm read is invisible to that pass - and to hipcc's lgkmcnt bookkeeping: every caller waits for its reads
+        // itself (s_waitcnt lgkmcnt(0) + sched_barrier before the first MFMA that uses them; guide section 5.7, form iii).
+        // The swizzle key of row k depends on k & 3 and on bit 3 of k only: it is the same for k = 8g + q, for k + 4 and for
+        // k + 32 ks, so one per-lane address serves the four reads of a column block and the k-step / k + 4 displacements are
+        // instruction offsets (no address arithmetic per read).
+        const int k0 = 8 * g + q;
+        const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(tile + k0 * 256 + ((c ^ (kswz(k0) << 1)) << 4) + sub);
+        if (ks == 0)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+        else
+            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:8192\n\tds_read_b64_tr_b16 %1, %2 offset:9216" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+        }
         bf16x8_t r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -278,57 +303,32 @@ struct EpiResid {
         Aux a; a.x0 = xi[0]; a.x1 = xi[1];
         return a;
     }
+    // One arithmetic path for both kernels (the 128^2 kernel calls operator(), the 256^2 kernel the three-step form), with the
+    // roundings spelled out: a row's result must not depend on which kernel the batch size selects (-ffp-contract=fast would
+    // otherwise be free to contract the two call sites differently).
     __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile& tc) const {
         Tile t = tc;
         if (tc.smp < 0) per_sample(m / rows, n, t);
-        const float4 g0 = t.g0, g1 = t.g1, x0 = a.x0, x1 = a.x1;
+        const float g[8] = {t.g0.x, t.g0.y, t.g0.z, t.g0.w, t.g1.x, t.g1.y, t.g1.z, t.g1.w};
+        const float x[8] = {a.x0.x, a.x0.y, a.x0.z, a.x0.w, a.x1.x, a.x1.y, a.x1.z, a.x1.w};
         float o[8];
-        o[0] = ca * x0.x + cb * g0.x * v[0]; o[1] = ca * x0.y + cb * g0.y * v[1];
-        o[2] = ca * x0.z + cb * g0.z * v[2]; o[3] = ca * x0.w + cb * g0.w * v[3];
-        o[4] = ca * x1.x + cb * g1.x * v[4]; o[5] = ca * x1.y + cb * g1.y * v[5];
-        o[6] = ca * x1.z + cb * g1.z * v[6]; o[7] = ca * x1.w + cb * g1.w * v[7];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(cb * g[i], v[i], ca * x[i]);
         float4* xo = (float4*)(xout + (size_t)m * ldo + n);
         xo[0] = make_float4(o[0], o[1], o[2], o[3]);
         xo[1] = make_float4(o[4], o[5], o[6], o[7]);
         if (y) store8_bf16(y + (size_t)m * ldo + n, v);
         if (xm) {
-            const float ka = t.ka, kb = t.kb;
-            const float4 c0 = t.c0, c1 = t.c1, h0 = t.h0, h1 = t.h1;
+            const float c[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
+            const float h[8] = {t.h0.x, t.h0.y, t.h0.z, t.h0.w, t.h1.x, t.h1.y, t.h1.z, t.h1.w};
             float w[8];
-            w[0] = ka * o[0] * c0.x + kb * h0.x; w[1] = ka * o[1] * c0.y + kb * h0.y;
-            w[2] = ka * o[2] * c0.z + kb * h0.z; w[3] = ka * o[3] * c0.w + kb * h0.w;
-            w[4] = ka * o[4] * c1.x + kb * h1.x; w[5] = ka * o[5] * c1.y + kb * h1.y;
-            w[6] = ka * o[6] * c1.z + kb * h1.z; w[7] = ka * o[7] * c1.w + kb * h1.w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
             store8_bf16(xm + (size_t)m * ldo + n, w);
         }
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
-        const int smp = m / rows;
-        const float4* g = (const float4*)(gate + (size_t)smp * ldg + n);
-        const float4* xi = (const float4*)(xin + (size_t)m * ldo + n);
-        float4 g0 = g[0], g1 = g[1], x0 = xi[0], x1 = xi[1];
-        float o[8];
-        o[0] = ca * x0.x + cb * g0.x * v[0]; o[1] = ca * x0.y + cb * g0.y * v[1];
-        o[2] = ca * x0.z + cb * g0.z * v[2]; o[3] = ca * x0.w + cb * g0.w * v[3];
-        o[4] = ca * x1.x + cb * g1.x * v[4]; o[5] = ca * x1.y + cb * g1.y * v[5];
-        o[6] = ca * x1.z + cb * g1.z * v[6]; o[7] = ca * x1.w + cb * g1.w * v[7];
-        float4* xo = (float4*)(xout + (size_t)m * ldo + n);
-        xo[0] = make_float4(o[0], o[1], o[2], o[3]);
-        xo[1] = make_float4(o[4], o[5], o[6], o[7]);
-        if (y) store8_bf16(y + (size_t)m * ldo + n, v);
-        if (xm) {
-            const float gg = *ngain, den = sqrtf((1.f - gg) * (1.f - gg) + gg * gg);
-            const float ka = (1.f - gg) / den, kb = gg / den;
-            const float4* sc = (const float4*)(nscale + (size_t)smp * ldn + n);
-            const float4* sh = (const float4*)(nshift + (size_t)smp * ldn + n);
-            const float4 c0 = sc[0], c1 = sc[1], h0 = sh[0], h1 = sh[1];
-            float w[8];
-            w[0] = ka * o[0] * c0.x + kb * h0.x; w[1] = ka * o[1] * c0.y + kb * h0.y;
-            w[2] = ka * o[2] * c0.z + kb * h0.z; w[3] = ka * o[3] * c0.w + kb * h0.w;
-            w[4] = ka * o[4] * c1.x + kb * h1.x; w[5] = ka * o[5] * c1.y + kb * h1.y;
-            w[6] = ka * o[6] * c1.z + kb * h1.z; w[7] = ka * o[7] * c1.w + kb * h1.w;
-            store8_bf16(xm + (size_t)m * ldo + n, w);
-        }
+        apply(m, n, v, 0, load(m, n), tile_begin(m, m, n));
     }
 };
 struct EpiDSilu {
@@ -362,7 +362,7 @@ struct EpiDSilu {
 
 // The dX GEMM of a branch fused with the backward of modulate() and of the residual mp_sum above it (what
 // resid_mod_bwd_kernel in pointwise.hip does as a separate pass; reference src/utils.py:11-16 through autograd).  v = the gradient
-// wrt u = modulate(x', shift, scale, gain) straight from the accumulators:
+// wrt u = modulate(x', shift, scale, gain) from the accumulators (rounded to bf16 as the unfused path stores it):
 //   dx' = ca dxo + k scale v                       k = (1-g)/den, kb = g/den, kd = 1/den, den = sqrt((1-g)^2 + g^2)
 //   dscale[s] = sum_t k x' v    dshift[s] = sum_t kb v    dgain += sum v (shift - x' scale) kd
 //   dy_up = cb gate_up dx'      dgate_up[s] = sum_t cb y_up dx'
@@ -417,10 +417,13 @@ struct EpiRmb {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            o[i] = ca * dd[i] + k * sc[i] * v[i];
-            r.sc[i] += k * xx[i] * v[i];
-            r.sh[i] += kb * v[i];
-            r.gain += v[i] * (sh[i] - xx[i] * sc[i]) * kd;
+            // the unfused path sees this gradient as a bf16 tensor: round it the same way, so that a sample's gradients do not
+            // depend on which path its batch size selects
+            const float vi = bf2f(f2bf(v[i]));
+            o[i] = ca * dd[i] + k * sc[i] * vi;
+            r.sc[i] += k * xx[i] * vi;
+            r.sh[i] += kb * vi;
+            r.gain += vi * (sh[i] - xx[i] * sc[i]) * kd;
         }
         if (dx) {
             float4* p = (float4*)(dx + (size_t)m * ldo + n);
@@ -524,6 +527,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
             for (int i = 0; i < 4; ++i) fa[i] = read_frag<AK>(cur, wm * 64 + i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = read_frag<BK>(cur + TILE_BYTES, wn * 64 + j * 16, ks, lane);
+            if (AK == OP_KMAJ || BK == OP_KMAJ) {              // the transposing reads are inline asm: wait for them here
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -694,13 +701,13 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
 #ifdef MAPDIT_GEMM_STAMPS
     // (the one-phase loop uses all 160 KiB of LDS: its stamps go straight to the global buffer - the stamping waves then carry a
     // few extra stores in their vmcnt queues, which the instrumented timeline has to live with)
-    constexpr int SM = PH == 1 ? SMEM_PH1 : SMEM2_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM + (PH == 1 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
-    long long* stamp_lds = PH == 1 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
+    constexpr int SM = PH != 2 ? SMEM_PH1 : SMEM2_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM + (PH != 2 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
+    long long* stamp_lds = PH != 2 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
     const long long wg_t0 = (long long)__builtin_readcyclecounter();
     const long long wg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #else
-    __shared__ __attribute__((aligned(16))) char smem[PH == 1 ? SMEM_PH1 : SMEM2_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -818,18 +825,111 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (PH == 3) {
+        // ---- software-pipelined loop: no LOAD / MFMA alternation -----------------------------------------------------------------
+        // Every wave keeps TWO fragment sets (the two 32-deep k-steps of a K-tile: 2 x 48 registers) and always has 32 MFMAs whose
+        // operands were read one step earlier: the fragment reads of the next step are issued first, then the MFMAs of the current
+        // one.  Both waves of a SIMD offer MFMAs all the time, so the matrix pipe only idles at the ONE barrier per K-tile (the
+        // two-phase loop has four, and at any time only one of its two wave groups issues MFMAs: 77 % pipe occupancy even with empty
+        // LOAD intervals, tools/gemm_ablate.py).  LDS and staging as in the one-phase loop: three A and two B buffers of two 16 KiB
+        // slots; group g stages B_g of tile t+2 and then A_g of tile t+3 right after the barrier of tile t.
+        //   RAW  the barrier of iteration t follows every wave's vmcnt(4) (its pieces of tile t+1 have landed; the four youngest,
+        //        A of tile t+2, stay in flight) and precedes the first read of tile t+1.
+        //   WAR  B buffer t&1 and A buffer t%3 are re-staged after that same barrier, which follows every wave's lgkmcnt(0) on its
+        //        last reads of tile t (step ks = 1; the ks = 0 reads were issued an iteration earlier).
+        constexpr int A_BUF = 2 * SLOT_BYTES, B_BASE = 3 * A_BUF, B_BUF = 2 * SLOT_BYTES;
+        static_assert(B_BASE + 2 * B_BUF <= SMEM_PH1, "LDS layout");
+        bf16x8_t f0a[8], f0b[4], f1a[8], f1b[4];
+        const int wq = wave & 3;
+        auto stage_a = [&](int kt, int abuf) {
+            stage_tile<AK, KTAIL>(p.A, p.lda, m0 + 128 * wm, p.M, kbeg + kt * BKT, p.K, smem + abuf * A_BUF + wm * SLOT_BYTES, wq, lane);
+        };
+        auto stage_b = [&](int kt) {
+            stage_tile<BK, KTAIL>(p.B, p.ldb, n0 + 128 * wm, p.N, kbeg + kt * BKT, p.K, smem + B_BASE + (kt & 1) * B_BUF + wm * SLOT_BYTES, wq, lane);
+        };
+#define G256_SP_READ(FA, FB, ABUF, KT, KS)                                                                              \
+        {                                                                                                               \
+            const char* a_slot_ = smem + (ABUF) * A_BUF + wm * SLOT_BYTES;                                              \
+            const char* b_slot_ = smem + B_BASE + ((KT) & 1) * B_BUF + (wn >> 1) * SLOT_BYTES;                          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) FA[i] = read_frag<AK>(a_slot_, i * 16, KS, lane);             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = read_frag<BK>(b_slot_, (wn & 1) * 64 + j * 16, KS, lane); \
+        }
+#define G256_SP_MFMA(FA, FB)                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);                      \
+        __builtin_amdgcn_s_setprio(0)
+        stage_a(0, 0);
+        stage_b(0);
+        if (nk > 1) { stage_a(1, 1); stage_b(1); }
+        if (nk > 2) stage_a(2, 2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        G256_TSTAMP(1);
+        G256_RSTAMP(5);
+        G256_SP_READ(f0a, f0b, 0, 0, 0);
+        int a_cur = 0;                                         // t % 3
+        for (int t = 0; t < nk; ++t) {
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk, has3 = t + 3 < nk;
+            const int a_nxt = a_cur == 2 ? 0 : a_cur + 1;
+            // the first MFMA of the step goes BEFORE the next step's reads: the wait for the f0 fragments (hipcc's own for tracked
+            // row-major reads, the explicit one for the inline-asm transposing reads) is then an lgkmcnt(0) with only those, long
+            // finished, reads outstanding; placed after the new reads it would wait for them too
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0b[0], f0a[0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            G256_SP_READ(f1a, f1b, a_cur, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0b[j], f0a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_END_LOAD();                                   // lgkmcnt(0) + barrier
+            if (has2) stage_b(t + 2);
+            if (has3) stage_a(t + 3, a_cur);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[0], f1a[0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            G256_SP_READ(f0a, f0b, a_nxt, t + 1, 0);           // (after the last tile: a harmless read of stale LDS, no branch)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[j], f1a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+        }
+#undef G256_SP_READ
+#undef G256_SP_MFMA
     } else {
     bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];               // B half 0 stays in registers for phases 1 and 4
+    constexpr bool TR_ASM2 = AK == OP_KMAJ;                // transposing reads: asm for TN; NN keeps the builtin (see read_frag)
 
     auto load_a = [&](const char* slot) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK>(slot, wm * 64 + i * 16, ks, lane);
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK, TR_ASM2>(slot, wm * 64 + i * 16, ks, lane);
     };
 #define G256_LOAD_B(FB, SLOT)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) FB[j][ks] = read_frag<BK>(SLOT, wn * 32 + j * 16, ks, lane)
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) FB[j][ks] = read_frag<BK, TR_ASM2>(SLOT, wn * 32 + j * 16, ks, lane)
 #define G256_MFMA(MQ, NQ, FB)                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
@@ -1225,7 +1325,7 @@ struct GemmEnv {
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -1238,15 +1338,23 @@ static GemmEnv& gemm_env() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : 2;
     e.band = band;
 }
 
-extern "C" int mapdit_gemm_tile_size(int M, int N) {
+// 256 (8 waves, one workgroup per CU) for results that give most of the chip a tile, 128 (4 waves, two per CU) otherwise:
+//  * plain launches: fewer than 128 tiles of 256^2 leave more than half the CUs idle (e.g. [8192, 768] = 96 tiles at a per-GPU
+//    batch of 32), while the 128^2 kernel has 4x the tiles for 2x the slots;
+//  * split-K launches fill the chip through the K cut either way: there the 128^2 kernel wins only for the smallest outputs
+//    ([768, 768]: 781 vs 704 TFLOP/s; [3072, 768]: 694 vs 812).
+extern "C" int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch) {
     const int force = gemm_env().tile;
     if (force == 128 || force == 256) return force;
-    return (M >= 512 && N >= 256) ? 256 : 128;
+    if (!(M >= 512 && N >= 256)) return 128;
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+    return tiles < (split_k_launch ? 12 : 128) ? 128 : 256;
 }
+extern "C" int mapdit_gemm_tile_size(int M, int N) { return mapdit_gemm_tile_size_ex(M, N, 0); }
 
 namespace {
 
@@ -1267,7 +1375,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
     if constexpr (kReduce<Epi>) {      // per-tile reductions exist in the 256^2 kernel only
-        if (!mfma || ktail || mapdit_gemm_tile_size(M, N) != 256) {
+        if (!mfma || ktail || mapdit_gemm_tile_size_ex(M, N, 0) != 256) {
             mapdit_set_error("gemm: this epilogue needs the 256x256 MFMA path (M=%d N=%d K=%d: K %% 64 == 0, M >= 512, N >= 256, aligned operands)", M, N, K);
             return MAPDIT_ERR_ARG;
         }
@@ -1276,7 +1384,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= ceil(K/64) (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
-    if (mfma && mapdit_gemm_tile_size(M, N) == 256) {
+    if (mfma && mapdit_gemm_tile_size_ex(M, N, split_k > 1) == 256) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
         p.phases = gemm_env().phases;
@@ -1296,17 +1404,28 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi, TAIL, PH>), dim3(grid), dim3(512), 0, st, p, epi);
             else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi, TAIL, PH>), dim3(grid), dim3(512), 0, st, p, epi);
         };
+#ifdef MAPDIT_GEMM_EXPERIMENTS
         using T1 = std::integral_constant<int, 1>;
+        using T3 = std::integral_constant<int, 3>;
+#endif
         using T2 = std::integral_constant<int, 2>;
         bool done = false;
         if constexpr (kHasTail<Epi>) {
             if (ktail) {
-                if (p.phases == 1) go(std::true_type(), T1()); else go(std::true_type(), T2());
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+                if (p.phases == 1) go(std::true_type(), T1()); else if (p.phases == 3) go(std::true_type(), T3()); else
+#endif
+                go(std::true_type(), T2());
                 done = true;
             }
         }
         if (!done) {
-            if (p.phases == 1) go(std::false_type(), T1()); else go(std::false_type(), T2());
+            // The one-phase (1) and software-pipelined (3) K loops are measured-and-rejected experiments (profiles/r02_gemm_kloop_
+            // experiments.log): compiled only with -DMAPDIT_GEMM_EXPERIMENTS (tools/gemm_stamps.py builds do), never in the product.
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+            if (p.phases == 1) go(std::false_type(), T1()); else if (p.phases == 3) go(std::false_type(), T3()); else
+#endif
+            go(std::false_type(), T2());
         }
     } else if (mfma) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4};

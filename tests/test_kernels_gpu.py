@@ -340,7 +340,7 @@ def test_modulate_and_fused_backward(L):
 def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo):
     """EPI_RMB: the dX GEMM whose epilogue is the backward of modulate() + the residual mp_sum above it (what
     mapdit_resid_mod_bwd does as a separate pass), against autograd of the oracle ops.  The gradient wrt the modulated input is
-    the fp32 accumulator here (never rounded to bf16), so the fp32 outputs hold 1e-5.  Covers one / two / four samples per
+    the accumulator rounded to bf16 (exactly what the unfused path stores and re-reads).  Covers one / two / four samples per
     256-row tile, a ragged last tile (N*T not a multiple of 256), NT and NN layouts, with and without the upstream residual."""
     from oracle.dit_oracle import modulate, mp_sum
     M = N * T
@@ -352,7 +352,7 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     gain = torch.tensor(0.37)
     dyo = bf16_exact(M, K, seed=9)                                    # gradient entering the dX GEMM
     w = bf16_exact(K, D, seed=10) * 0.25 if layout == 1 else bf16_exact(D, K, seed=10) * 0.25
-    dxm = dyo @ (w if layout == 1 else w.t())                         # fp32 reference of the GEMM result
+    dxm = (dyo @ (w if layout == 1 else w.t())).bfloat16().float()    # the GEMM result as the backward sees it: bf16
     dxo = torch.randn(N, T, D, generator=g)
     ca, cb = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58)
     leaves = [t.clone().requires_grad_(True) for t in (x_up, y_up, mod_up, mod, gain)]
@@ -386,25 +386,28 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     e = L.Epilogue()
     e.kind, e.ldo, e.rmb = L.EPI_RMB, D, C.addressof(a)
     ad, bd = to_bf(dyo), to_bf(w)
+    L.lib().gemm_tuning(256, 2, 0)            # these small results would take the 128^2 kernel by themselves (too few 256^2 tiles)
     L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
     dgain = torch.zeros((), device=DEV)
     L.lib().reduce_partials(p(part), tiles, p(dgain), 0, st())
     torch.cuda.synchronize()
     assert torch.isnan(part[tiles:]).all() and torch.isfinite(part[:tiles]).all()          # exactly one partial per tile
     want_dxp = xu.grad / ca if with_up else xu.grad            # d x' (autograd: xu.grad = ca * d x' through the mp_sum)
-    assert rel_err(dx.cpu().numpy(), want_dxp.numpy()) < 1e-5
+    # (the reference rounds a CPU fp32 product to bf16, the kernel its own fp32 accumulation: a few roundings flip -> ~2e-5)
+    assert rel_err(dx.cpu().numpy(), want_dxp.numpy()) < 1e-4
     assert rel_err(dxbf.float().cpu().numpy(), dx.cpu().numpy()) < 3e-3
-    assert rel_err(dmod[:, 3 * D:5 * D].cpu().numpy(), mm.grad[:, 3 * D:5 * D].numpy()) < 2e-5
-    assert abs(dgain.item() - gg.grad.item()) < 2e-5 * (dxm.abs().sum().item() ** 0.5 + 1) + 1e-4 * abs(gg.grad.item())
+    assert rel_err(dmod[:, 3 * D:5 * D].cpu().numpy(), mm.grad[:, 3 * D:5 * D].numpy()) < 1e-4
+    assert abs(dgain.item() - gg.grad.item()) < 1e-4 * (dxm.abs().sum().item() ** 0.5 + 1) + 1e-3 * abs(gg.grad.item())
     if with_up:
         assert rel_err(dy.float().cpu().numpy(), yu.grad.numpy()) < 3e-3
-        assert rel_err(dmod_up[:, 5 * D:].cpu().numpy(), mu.grad[:, 5 * D:].numpy()) < 2e-5
+        assert rel_err(dmod_up[:, 5 * D:].cpu().numpy(), mu.grad[:, 5 * D:].numpy()) < 1e-4
     # bit-reproducible (no atomics): a second launch gives the same bits
     dx2, dmod2 = dx.clone(), dmod.clone()
     L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
     torch.cuda.synchronize()
     assert torch.equal(dx, dx2) and torch.equal(dmod, dmod2)
     # shapes the 256x256 path does not take are refused, not mis-computed
+    L.lib().gemm_tuning(0, 2, 0)
     with pytest.raises(L.MapditError):
         L.lib().gemm_bf16(layout, 256, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
 

@@ -21,7 +21,7 @@ if "--build" in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "map-dit_amd", "csrc", "gemm.hip")
     procs = [subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-                               "-fno-slp-vectorize", "-DMAPDIT_GEMM_STAMPS", f"-DMAPDIT_GEMM_ABLATE={n}", "-Wno-unused-function", src,
+                               "-fno-slp-vectorize", "-DMAPDIT_GEMM_STAMPS", "-DMAPDIT_GEMM_EXPERIMENTS", f"-DMAPDIT_GEMM_ABLATE={n}", "-Wno-unused-function", src,
                                "-o", so(n)]) for n in range(4)]
     assert all(p.wait() == 0 for p in procs)
     print("built")

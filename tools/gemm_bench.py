@@ -74,7 +74,7 @@ def main():
         ("fc1  dW  TN split", 2, 4 * D, D, M, dh, 4 * D, x, D, None),
         ("proj dW  TN split", 2, D, D, M, dy, D, x, D, None),
     ]
-    variants = [("128", 128, 4), ("256/2ph", 256, 2), ("256/1ph", 256, 1)]
+    variants = [("128", 128, 4), ("256/2ph", 256, 2), ("256/SP", 256, 3)]
     print(f"{'case':20s} {'kernel':>8s} {'ms':>8s} {'TFLOP/s':>9s}")
     for name, layout, m, n, k, a, lda, b, ldb, e in cases:
         flops = 2.0 * m * n * k

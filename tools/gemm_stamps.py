@@ -23,7 +23,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "map-dit_amd", "csrc", "gemm.hip")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-                           "-fno-slp-vectorize", "-DMAPDIT_GEMM_STAMPS", "-Wno-unused-function", src, "-o", SO])
+                           "-fno-slp-vectorize", "-DMAPDIT_GEMM_STAMPS", "-DMAPDIT_GEMM_EXPERIMENTS", "-Wno-unused-function", src, "-o", SO])
     print("built", SO)
 
 
