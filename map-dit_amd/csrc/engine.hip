@@ -96,6 +96,15 @@ struct mapdit_engine {
         bf16_t *AsT, *BsT;
     } pg;
     long G_cap = 0;                       // floats available in G (split-K slabs)
+    // bf16 engines: the conditioning path (timestep MLP, every modulation linear, the MPScale linears: [samples, D] rows, a
+    // negligible share of the FLOPs) runs its forward products fp32-accurately on split operands like the bf16x3 engine.  With
+    // bf16 operands it is the largest single source of the logits' distance to the reference (tools/precision_rank.py, DiT-B/2:
+    // 1.08e-2 with it, 6.0e-3 without).  cimg3[i] = [hi|lo|hi] image of conditioning weight i (K' = 3K), as the bf16x3 engine keeps.
+    struct {
+        float *four32 = nullptr, *h1 = nullptr, *wtmp = nullptr;
+        bf16_t* As = nullptr;
+        std::vector<bf16_t*> img3;        // indexed like the parameter table; block modulation images are contiguous
+    } cp;
     // optional HIP-event timing of one kernel family (bench.py roofline)
     int prof_which = -1;
     size_t prof_used = 0;
@@ -219,6 +228,21 @@ size_t carve(mapdit_engine* e, void* base) {
             g.AsT = cv.take<bf16_t>(3 * M * wide);
             g.BsT = cv.take<bf16_t>(3 * M * (size_t)(Hm > e->ldp ? Hm : e->ldp));
         }
+    }
+    if (!precise) {
+        const int FW = D > FOURIER ? D : FOURIER;
+        e->cp.four32 = cv.take<float>((size_t)N * FOURIER);
+        e->cp.h1 = cv.take<float>((size_t)N * D);
+        e->cp.wtmp = cv.take<float>((size_t)6 * D * (D > FOURIER ? D : FOURIER));
+        e->cp.As = cv.take<bf16_t>((size_t)N * 3 * FW);
+        e->cp.img3.assign(np, nullptr);
+        e->cp.img3[MAPDIT_P_T0] = cv.take<bf16_t>((size_t)3 * D * FOURIER);
+        e->cp.img3[MAPDIT_P_T2] = cv.take<bf16_t>((size_t)3 * D * D);
+        e->cp.img3[MAPDIT_P_F_MOD] = cv.take<bf16_t>((size_t)3 * 2 * D * D);
+        e->cp.img3[MAPDIT_P_MS_LIN] = cv.take<bf16_t>((size_t)3 * NSCALE * D);
+        e->cp.img3[MAPDIT_P_SS_LIN] = cv.take<bf16_t>((size_t)3 * NSCALE * D);
+        bf16_t* modall = cv.take<bf16_t>((size_t)3 * L * 6 * D * D);                 // one [L*6D][3D] operand
+        for (int i = 0; i < L; ++i) e->cp.img3[pidx_block(i, MAPDIT_B_MOD)] = modall + (size_t)i * 6 * D * 3 * D;
     }
     if (e->train) {
         size_t gmax = (size_t)6 * D * D;
@@ -542,7 +566,16 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
             MD_CHECK(he == hipSuccess, "engine_prepare_weights: job table upload failed: %s", hipGetErrorString(he));
             e->wn_table_ready = true;
         }
-        return mapdit_weightnorm_fwd_batch(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st);
+        TRY(mapdit_weightnorm_fwd_batch(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st));
+        // split images of the conditioning weights for the fp32-accurate conditioning forward; the batch pass above has already
+        // applied the forced normalisation to the masters (forced = 0 here: the effective weight of the stored W)
+        for (size_t i = 0; i < e->cp.img3.size(); ++i) {
+            if (!e->cp.img3[i]) continue;
+            const WeightImg& w = e->wimg[i];
+            TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, 0, 1.f, nullptr, e->cp.wtmp, nullptr, st));
+            TRY(mapdit_split3(e->cp.wtmp, w.cols, e->cp.img3[i], w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
+        }
+        return MAPDIT_OK;
     }
     for (size_t i = 0; i < e->wimg.size(); ++i) {
         const WeightImg& w = e->wimg[i];
@@ -767,14 +800,21 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     const int M = N * T;
     auto W = [&](int idx) { return e->wimg[idx].img; };
 
-    // conditioning: c = mp_sum(t_embedder(t), y_embedder(y), 0.5)        (dit.py:86-88)
-    TRY(mapdit_fourier_fwd(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], e->four, N, FOURIER, st));
-    {
-        mapdit_epilogue_t ep = epi_silu2(e->h1_pre, e->h1_act, D);
-        ep.kind = MAPDIT_EPI_SILU2_COND;
-        TRY(gemm(MAPDIT_NT, N, D, FOURIER, e->four, FOURIER, W(MAPDIT_P_T0), FOURIER, ep, st));
+    // conditioning: c = mp_sum(t_embedder(t), y_embedder(y), 0.5)        (dit.py:86-88), fp32-accurate: every product of this
+    // [samples, D] path runs on two-term split operands (see mapdit_engine::cp).  The backward keeps its bf16 operands: the
+    // Fourier features, the timestep MLP's pre-activation and activation are also written as bf16 for it.
+    auto cond_linear = [&](const float* src, int K, int op, int widx, int nout, float* dst, int ldo) -> int {
+        TRY(mapdit_split3(src, K, e->cp.As, N, K, MAPDIT_SPLIT_A, op, st));
+        return gemm(MAPDIT_NT, N, nout, 3 * K, e->cp.As, 3 * K, e->cp.img3[widx], 3 * K, epi_f32(dst, ldo), st);
+    };
+    TRY(mapdit_fourier32(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], e->cp.four32, N, FOURIER, st));
+    TRY(cond_linear(e->cp.four32, FOURIER, MAPDIT_SPLIT_OP_NONE, MAPDIT_P_T0, D, e->cp.h1, D));
+    TRY(cond_linear(e->cp.h1, D, MAPDIT_SPLIT_OP_MPSILU, MAPDIT_P_T2, D, e->temb, D));
+    if (save) {
+        TRY(mapdit_f32_to_bf16(e->cp.four32, e->four, (long)N * FOURIER, 1.f, st));
+        TRY(mapdit_f32_to_bf16(e->cp.h1, e->h1_pre, (long)N * D, 1.f, st));
+        TRY(mapdit_mpsilu_to_bf16(e->cp.h1, e->h1_act, (long)N * D, st));
     }
-    TRY(gemm(MAPDIT_NT, N, D, D, e->h1_act, D, W(MAPDIT_P_T2), D, epi_f32(e->temb, D), st));
     TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));
     if (save) {
         hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
@@ -787,8 +827,9 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // contiguous [L*6D, D] weight image, plus the final layer's (shift, scale); all later modulate()s are fused into
     // the residual GEMM epilogues that produce their inputs.
     const int ldm = e->ldm;
-    TRY(gemm(MAPDIT_NT, N, ldm, D, e->c_silu, D, W(pidx_block(0, MAPDIT_B_MOD)), D, epi_f32(e->mod_all, ldm), st));
-    TRY(gemm(MAPDIT_NT, N, 2 * D, D, e->c_silu, D, W(MAPDIT_P_F_MOD), D, epi_f32(e->fmod, 2 * D), st));
+    TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_MPSILU, st));
+    TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm), st));
+    TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D), st));
     TRY(mapdit_modulate_fwd(e->X[0], e->mod_all, e->mod_all + D, ldm, e->params[pidx_block(0, MAPDIT_B_GAIN_MSA)],
                             e->blk[0].xm, N, T, D, st));
     for (int i = 0; i < L; ++i) {
@@ -829,8 +870,9 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // final layer                                                       (final_layer.py:53-59, dit.py:96-101)
     (void)xL;   // xmodf = modulate(xL, ...) was written by the last block's fc2 epilogue
     TRY(gemm(MAPDIT_NT, M, 2 * e->P, D, e->xmodf, D, W(MAPDIT_P_F_LIN), D, epi_f32(e->lin, 2 * e->P), st));
-    TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_MS_LIN), D, epi_f32(e->a_mean, NSCALE), st));
-    TRY(gemm(MAPDIT_NT, N, NSCALE, D, e->c_bf, D, W(MAPDIT_P_SS_LIN), D, epi_f32(e->a_sigma, NSCALE), st));
+    TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_NONE, st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_MS_LIN], 3 * D, epi_f32(e->a_mean, NSCALE), st));
+    TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_SS_LIN], 3 * D, epi_f32(e->a_sigma, NSCALE), st));
     TRY(mapdit_final_out_fwd(e->lin, 2 * e->P, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], out, N,
                              c.in_channels, c.input_size, c.patch, st));
     e->last_N = N;

@@ -56,6 +56,30 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _host_staged(group, t) -> bool:
+    """gloo with device tensors (the one-GPU rehearsals of the N > 1 path, MAPDIT_DIST_BACKEND=gloo): the collective is run on a
+    host copy, synchronously - RCCL collectives are ordered on the compute stream and asynchronous, gloo's own CUDA staging (pool
+    streams, pinned buffers, worker threads) is not something the rehearsal should depend on (it produced stale 1-KiB pieces of the
+    reduced buffer now and then on this stack)."""
+    return t.is_cuda and _world(group) > 1 and dist.get_backend(group) == "gloo"
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_reduce_sum(t, group):
+    """Sum-all-reduce of `t` in place; returns a work handle."""
+    if _host_staged(group, t):
+        h = t.detach().cpu()                    # synchronises with the stream that produced t
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        torch.cuda.synchronize(t.device)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 class GradReducer:
     """Sum-all-reduce of a flat gradient buffer after backward, in a few large buckets.  Works with any
     torch.distributed backend: RCCL on GPUs, gloo on CPU for tests."""
@@ -125,7 +149,7 @@ class OverlappedGradReducer:
         if self.world == 1 and not self.force_collective:
             return
         lo, hi = self.slices[stage]
-        self.works.append(dist.all_reduce(self.model._gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.works.append(_all_reduce_sum(self.model._gflat[lo:hi], self.group))
 
     def finish(self):
         """Make the current stream wait for every outstanding reduction (call before the optimiser step)."""
@@ -213,7 +237,7 @@ class Zero1Reducer(_ReducerBase):
             # in place: the output is the rank-th part of the input (RCCL's in-place reduce-scatter layout)
             self.works.append(dist.reduce_scatter_tensor(mine, g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:                                   # gloo has no reduce-scatter: all-reduce the slice, every rank then reads its own part
-            self.works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.works.append(_all_reduce_sum(g[lo:hi], self.group))
 
     def finish(self):
         for w in self.works:
@@ -240,6 +264,11 @@ class Zero1Reducer(_ReducerBase):
             mine = p[lo + self.rank * n: lo + (self.rank + 1) * n]
             if self._native_rs or self.world == 1:
                 works.append(dist.all_gather_into_tensor(p[lo:hi], mine, group=self.group, async_op=True))
+            elif _host_staged(self.group, p):
+                parts = [torch.empty(n, dtype=p.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, mine.detach().cpu(), group=self.group)
+                p[lo:hi].copy_(torch.cat(parts))
+                torch.cuda.synchronize(p.device)
             else:
                 works.append(dist.all_gather(list(p[lo:hi].chunk(self.world)), mine.clone(), group=self.group, async_op=True))
         for w in works:

@@ -134,6 +134,38 @@ def bf16_round(x: Tensor) -> Tensor:
     return x.bfloat16().to(x.dtype)
 
 
+class EnginePlan:
+    """The bf16 engine's precision plan as a per-site rounding policy: bf16 GEMM / attention operands on the token path, an
+    fp32-accurate conditioning path (timestep MLP, modulation linears, MPScale linears: the engine runs those [samples, D]
+    products on two-term split operands)."""
+    COND = ("t0", "t2", "mod", "fmod", "scale")
+
+    def at(self, site: str):
+        return _ident if site[:2] in ("x:", "w:") and site[2:] in self.COND else bf16_round
+
+
+engine_plan = EnginePlan()
+
+
+def _at(rnd, site: str):
+    """A rounding policy may differ per site (tools/precision_rank.py ranks the engine's bf16 roundings with one): an object with
+    ``at(site) -> callable``; a plain callable applies everywhere.  Sites: "w:<layer>", "x:<layer>" (GEMM operands; layer in qkv,
+    proj, fc1, fc2, mod, t0, t2, flin, fmod, scale), "v", "qk" (the normalised q, k), "p" (exp(logits))."""
+    return rnd.at(site) if hasattr(rnd, "at") else rnd
+
+
+_LAYER_OF = {"t_embedder.mlp.net.0": "t0", "t_embedder.mlp.net.2": "t2", "attn.qkv_proj": "qkv", "attn.out_proj": "proj",
+             "mlp.net.0": "fc1", "mlp.net.2": "fc2", "final_layer.modulation.1": "fmod", "modulation.1": "mod",
+             "final_layer.linear": "flin", "scale.linear": "scale"}
+
+
+def _layer_of(key: str) -> str:
+    for frag, name in _LAYER_OF.items():                   # (insertion order: the more specific fragments first)
+        if frag in key:
+            return name
+    return "other"
+
+
 def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_ident) -> Tensor:
     """MPLinear / MPLinearChunk forward (src/basic/mp_linear.py:31-46, 67-75), gain == 1.
     Training forward first overwrites the stored weight with its normalised value (F9)."""
@@ -142,7 +174,8 @@ def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_iden
         with torch.no_grad():
             w.copy_(normalize(w))
     w_eff = normalize(w) / math.sqrt(w.shape[1])
-    return torch.nn.functional.linear(rnd(x), rnd(w_eff))
+    layer = _layer_of(key)
+    return torch.nn.functional.linear(_at(rnd, "x:" + layer)(x), _at(rnd, "w:" + layer)(w_eff))
 
 
 def mp_embedding(idx: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
@@ -258,30 +291,30 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
     # engine: head_dim 64 with 64/128/256 tokens normalises q, k from the fp32 accumulators inside the QKV GEMM's epilogue
     # (one rounding, after the normalisation); the generic attention path stores qkv in bf16 first
     if not (hd == 64 and T in (64, 128, 256)):
-        qkv = rnd(qkv)
+        qkv = _at(rnd, "qkv")(qkv)
     _rec(trace, prefix + "qkv", qkv)
     q, k, v = qkv.chunk(3, dim=-1)
-    v = rnd(v)
+    v = _at(rnd, "v")(v)
     q = q.view(B, T, H, hd).transpose(1, 2)
     k = k.view(B, T, H, hd).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)
-    q, k = rnd(normalize(q)), rnd(normalize(k))
+    q, k = _at(rnd, "qk")(normalize(q)), _at(rnd, "qk")(normalize(k))
     _rec(trace, prefix + "qn", q); _rec(trace, prefix + "kn", k); _rec(trace, prefix + "v", v)
     logits = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
     if rnd is _ident:
         out = torch.softmax(logits, dim=-1) @ v
     else:   # the kernels keep exp(logit) un-normalised (cosine logits are bounded), round it for the PV product
         p = torch.exp(logits)
-        out = (rnd(p) @ v) / p.sum(-1, keepdim=True)
+        out = (_at(rnd, "p")(p) @ v) / p.sum(-1, keepdim=True)
     out = out.transpose(1, 2).reshape(B, T, D)
-    _rec(trace, prefix + "o", rnd(out))
+    _rec(trace, prefix + "o", _at(rnd, "x:proj")(out))
     return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd)
 
 
 def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/layers/mlp.py:16-25."""
     h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
-    _rec(trace, prefix + "hact", rnd(h))
+    _rec(trace, prefix + "hact", _at(rnd, "x:fc2")(h))
     return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
 
 
@@ -292,11 +325,11 @@ def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd
     _rec(trace, p + "mod", mod)
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
     xm = modulate(x, sh_a, sc_a, sd[p + "gain_msa"])
-    _rec(trace, p + "xm", rnd(xm))
+    _rec(trace, p + "xm", _at(rnd, "x:qkv")(xm))
     x = mp_sum(x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace), RESIDUAL_T)
     _rec(trace, p + "xmid", x)
     xm2 = modulate(x, sh_m, sc_m, sd[p + "gain_mlp"])
-    _rec(trace, p + "xm2", rnd(xm2))
+    _rec(trace, p + "xm2", _at(rnd, "x:fc1")(xm2))
     x = mp_sum(x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace), RESIDUAL_T)
     _rec(trace, p + "xout", x)
     return x
@@ -315,7 +348,7 @@ def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_iden
     p = "final_layer."
     shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
     x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
-    _rec(trace, p + "xmod", rnd(x_mod))
+    _rec(trace, p + "xmod", _at(rnd, "x:flin")(x_mod))
     out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd)
     _rec(trace, p + "lin", out)
     if cfg.learn_sigma:
@@ -346,7 +379,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: 
 
     four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
     four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
-    _rec(trace, "x0", h); _rec(trace, "four", rnd(four))
+    _rec(trace, "x0", h); _rec(trace, "four", _at(rnd, "x:t0")(four))
     temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd)
     temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
     yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train)

@@ -26,6 +26,9 @@ def main():
     rank, world, _ = parallel.init_from_env()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if os.environ.get("MAPDIT_TEST_POISON"):               # tools/determinism_check.py: stale allocator memory of a known pattern
+        junk = torch.full((1 << 28,), int(os.environ["MAPDIT_TEST_POISON"]), dtype=torch.uint8, device=dev)
+        del junk
     torch.manual_seed(21)
     m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7).to(dev).train()
     m.gemm_precision = precision

@@ -55,7 +55,7 @@ def test_eval_forward_matches_reference(name):
 @pytest.mark.parametrize("name", ["tiny_a", "tiny_c", "s2_n2"])
 def test_eval_forward_matches_bf16_emulating_oracle(name):
     """The gap to the fp32 goldens above is operand rounding and nothing else: when the oracle rounds to bf16 at the
-    points where the engine stores bf16 (GEMM / attention operands; oracle.bf16_round), the engine is 2-10x closer to
+    points where the engine stores bf16 (GEMM / attention operands of the token path; oracle.engine_plan), the engine is 2-10x closer to
     it than to the fp32 reference.  It cannot be much closer than ~2^-9: two implementations of the same precision plan
     that differ only in fp32 accumulation order (relative difference d) disagree after ONE more bf16 rounding by about
     sqrt(d * 2^-8) (a fraction d/2^-8 of the elements lands on the other side of a rounding boundary), so 1e-7 becomes
@@ -67,13 +67,13 @@ def test_eval_forward_matches_bf16_emulating_oracle(name):
     x, t, y = dev(g, "x", "t", "y")
     with torch.no_grad():
         out = m(x, t, y).cpu()
-        ref_emul = O.dit_forward(sd, cfg, x.cpu(), t.cpu(), y.cpu(), train=False, rnd=O.bf16_round)
+        ref_emul = O.dit_forward(sd, cfg, x.cpu(), t.cpu(), y.cpu(), train=False, rnd=O.engine_plan)
         ref_fp32 = O.dit_forward(sd, cfg, x.cpu(), t.cpu(), y.cpu(), train=False)
     e_emul = rel_err(out.numpy(), ref_emul.numpy())
     e_fp32 = rel_err(out.numpy(), ref_fp32.numpy())
     print(f"{name}: vs bf16-emulating oracle {e_emul:.3e}, vs fp32 oracle {e_fp32:.3e}")
     assert e_emul < 4e-3
-    assert e_emul < 0.6 * e_fp32
+    assert e_emul < 0.85 * e_fp32
 
 
 PRECISE_TOL = 1e-3      # BASELINE.json north_star: "forward logits within 1e-3 rel of reference"
@@ -177,7 +177,7 @@ def test_forward_stage_by_stage_against_emulating_oracle(name):
     sd_o = {k: v.clone() for k, v in sd.items()}
     with torch.no_grad():
         ref = O.dit_forward(sd_o, cfg, x.cpu(), t.cpu(), torch.from_numpy(g["y_eff"]), train=True,
-                            drop=torch.zeros(x.shape[0], dtype=torch.bool), rnd=O.bf16_round, trace=trace)
+                            drop=torch.zeros(x.shape[0], dtype=torch.bool), rnd=O.engine_plan, trace=trace)
     D = cfg.hidden_size
     rows = []
 
@@ -185,17 +185,18 @@ def test_forward_stage_by_stage_against_emulating_oracle(name):
         e = rel_err(got.float().cpu().numpy().reshape(-1), want.float().numpy().reshape(-1))
         rows.append((label, e, tol))
 
-    # tolerances: the conditioning path and the embedded tokens see at most one bf16 rounding of bit-identical inputs
-    # (Fourier features must be EXACT); block 0 is 1-3 roundings deep; from block 1 on the rounding-flip noise has
-    # saturated (see test_eval_forward_matches_bf16_emulating_oracle) and stays flat with depth.
-    cmp("four", m._peek("four"), trace["four"], 1e-9)
-    cmp("temb", m._peek("temb"), trace["temb"], 1e-4)
-    cmp("c", m._peek("c"), trace["c"], 1e-4)
+    # tolerances: the conditioning path is fp32-accurate in the engine (split operands) and unrounded in the oracle's engine
+    # plan: 2e-5 (the Fourier features' bf16 copy for the backward must be EXACT); the embedded tokens see one bf16 rounding
+    # of bit-identical inputs; block 0 is 1-3 roundings deep; from block 1 on the rounding-flip noise has saturated (see
+    # test_eval_forward_matches_bf16_emulating_oracle) and stays flat with depth.
+    cmp("four", m._peek("four"), O.bf16_round(trace["four"]), 1e-9)
+    cmp("temb", m._peek("temb"), trace["temb"], 2e-5)
+    cmp("c", m._peek("c"), trace["c"], 2e-5)
     cmp("x0", m._peek("x0"), trace["x0"], 1e-6)
     mod_all = m._peek("mod_all")
     for i in range(cfg.depth):
         p = f"blocks.{i}."
-        cmp(p + "mod", mod_all[:, i * 6 * D:(i + 1) * 6 * D], trace[p + "mod"], 1e-4)
+        cmp(p + "mod", mod_all[:, i * 6 * D:(i + 1) * 6 * D], trace[p + "mod"], 2e-5)
         for nm, key in (("xm", "xm"), ("qkv", "attn.qkv"), ("qn", "attn.qn"), ("kn", "attn.kn"), ("v", "attn.v"), ("o", "attn.o"),
                         ("xmid", "xmid"), ("xm2", "xm2"), ("hact", "mlp.hact"), ("xout", "xout")):
             tol = (3e-4 if nm == "xm" else 2.5e-3) if i == 0 else 6e-3
