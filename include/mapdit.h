@@ -325,6 +325,24 @@ enum { MAPDIT_PEEK_G_FOUR = 0, MAPDIT_PEEK_G_TEMB, MAPDIT_PEEK_G_C, MAPDIT_PEEK_
        MAPDIT_PEEK_B_XM2, MAPDIT_PEEK_B_HACT, MAPDIT_PEEK_B_XMID, MAPDIT_PEEK_B_XOUT, MAPDIT_PEEK_COUNT };
 int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long* elems, int* ld, int* dtype);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: flat fp32 buckets over RCCL (xGMI), for a host program that is not
+ * PyTorch (the Python integration uses torch.distributed, which owns its own RCCL communicator: map-dit_amd/parallel.py).
+ * One process per GPU.  Rank 0 obtains a 128-byte id, the host program distributes it, every rank creates its communicator.
+ * All collectives are in place, asynchronous on `stream`, and sum (the mean is the optimiser's grad_scale = 1/world):
+ *   allreduce_bucket:       buf[0..count) <- sum over ranks
+ *   reduce_scatter_bucket:  part r = buf[r*count/world ..) of rank r <- sum over ranks of that part (ZeRO-1: then update it)
+ *   allgather_bucket:       every part r of buf <- rank r's part r
+ * RCCL is bound at run time (dlopen); without it the calls return MAPDIT_ERR_HIP with a message.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mapdit_comm mapdit_comm_t;
+int mapdit_comm_unique_id(void* id128);
+int mapdit_comm_create(const void* id128, int rank, int world, mapdit_comm_t** out);
+void mapdit_comm_destroy(mapdit_comm_t* comm);
+int mapdit_allreduce_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
+int mapdit_reduce_scatter_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
+int mapdit_allgather_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

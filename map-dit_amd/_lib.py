@@ -90,6 +90,11 @@ _SIGS = {
     "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
     "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
     "mapdit_device_error_poll": [vp],
+    "mapdit_comm_unique_id": [vp],
+    "mapdit_comm_create": [vp, ci, ci, C.POINTER(vp)],
+    "mapdit_allreduce_bucket": [vp, vp, cl, vp],
+    "mapdit_reduce_scatter_bucket": [vp, vp, cl, vp],
+    "mapdit_allgather_bucket": [vp, vp, cl, vp],
     "mapdit_final_out_fwd": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_cfg_combine": [vp, vp, ci, ci, ci, cf, vp],
@@ -117,6 +122,7 @@ _OTHER = {
     "mapdit_gemm_tuning": (None, [ci, ci, cl]),
     "mapdit_engine_workspace_bytes": (C.c_size_t, [C.POINTER(Config), ci]),
     "mapdit_engine_destroy": (None, [vp]),
+    "mapdit_comm_destroy": (None, [vp]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_OTHER))
 

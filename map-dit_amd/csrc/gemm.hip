@@ -374,7 +374,6 @@ struct EpiRmb {
     const bf16_t* y_up; const float* g_up;
     float* dx; bf16_t* dx_bf; bf16_t* dy_up; float* dshift; float* dscale; float* dg_up; float* dgain_part;
     int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb;
-    static constexpr int kBatch = 4;                   // one 64-row block's four chunks per thread in flight together
     struct Aux { float4 x0, x1, d0, d1; u32x4_t y; };
     struct Tile { float4 sc0, sc1, sh0, sh1, gu0, gu1; };
     struct Acc { float sc[8], sh[8], g[8], gain; };    // running sums of the current 64-row block (gain: of the whole tile)

@@ -799,3 +799,31 @@ def test_cfg_combine(L):
     L.lib().cfg_combine(p(md), p(out), n, C_, HW, 1.5, st())
     torch.cuda.synchronize()
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-6
+
+
+def test_c_abi_collectives_single_rank(L):
+    """mapdit_comm_* / mapdit_*_bucket: RCCL bound at run time behind the C ABI (for a host program without torch.distributed).
+    One rank here (a one-GPU box): the id / communicator life cycle and the in-place layouts of the three collectives - an
+    all-reduce, reduce-scatter and all-gather over one rank must leave the buffer unchanged - through RCCL's own kernels on the
+    caller's stream, followed by an engine kernel on the same stream."""
+    lib = L.lib()
+    uid = C.create_string_buffer(128)
+    lib.comm_unique_id(uid)
+    assert any(b != 0 for b in uid.raw)
+    comm = C.c_void_p()
+    lib.comm_create(uid, 0, 1, C.byref(comm))
+    try:
+        g = torch.Generator(device=DEV).manual_seed(3)
+        buf = torch.randn(1 << 20, device=DEV, generator=g)
+        want = buf.clone()
+        lib.allreduce_bucket(comm, p(buf), buf.numel(), st())
+        lib.reduce_scatter_bucket(comm, p(buf), buf.numel(), st())
+        lib.allgather_bucket(comm, p(buf), buf.numel(), st())
+        out = torch.empty(buf.numel(), device=DEV, dtype=torch.bfloat16)
+        lib.f32_to_bf16(p(buf), p(out), buf.numel(), 1.0, st())          # an engine kernel queued behind the collectives
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want) and torch.equal(out, want.bfloat16())
+        with pytest.raises(L.MapditError):
+            lib.reduce_scatter_bucket(comm, p(buf), 0, st())
+    finally:
+        lib.comm_destroy(comm)

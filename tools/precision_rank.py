@@ -99,3 +99,13 @@ e = run(Policy(lambda s: split2 if (s[2:] in COND and s[:2] in ("w:", "x:")) els
 print(f"(f) conditioning path (both operands of mod, t0, t2, fmod, scale) two-term split, the token path bf16:   {e:.3e}")
 e = run(Policy(lambda s: ident if (s[2:] in COND and s[:2] in ("w:", "x:")) else bf16))
 print(f"    same with an exact (fp32) conditioning path:                                                        {e:.3e}")
+CONDSITE = lambda s: s[2:] in COND and s[:2] in ("w:", "x:")
+print("(g) on top of the fp32-accurate conditioning path (what the bf16 engine runs): two-term split at further sites")
+for label, extra in [("nothing more (= the engine)", lambda s: False),
+                     ("final linear, both operands", lambda s: s in ("x:flin", "w:flin")),
+                     ("weights of the four block GEMMs (2x their forward FLOPs)", lambda s: s in ("w:qkv", "w:proj", "w:fc1", "w:fc2")),
+                     ("block GEMM weights + final linear", lambda s: s in ("w:qkv", "w:proj", "w:fc1", "w:fc2", "x:flin", "w:flin")),
+                     ("block GEMM weights + final linear + inputs of proj, fc1, fc2 (3x their FLOPs)",
+                      lambda s: s in ("w:qkv", "w:proj", "w:fc1", "w:fc2", "x:flin", "w:flin", "x:proj", "x:fc1", "x:fc2"))]:
+    e = run(Policy(lambda s, extra=extra: ident if CONDSITE(s) else (split2 if extra(s) else bf16)))
+    print(f"    {label:84s} {e:.3e}")
