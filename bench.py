@@ -216,6 +216,8 @@ def main():
                     help="bf16x3: the fp32-accurate parity engine (informational; the headline metric is bf16)")
     ap.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
                     help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce)")
+    ap.add_argument("--rotation-modulation", action="store_true",
+                    help="BASELINE config 3's block conditioning (README.md:1-3; not in the reference snapshot: parity unpinned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -249,11 +251,12 @@ def main():
     global_batch = B * world
 
     parity = None
-    if rank == 0 and not args.no_parity:
+    if rank == 0 and not args.no_parity and not args.rotation_modulation:
         parity = parity_leg(args.model, args.precision, dev)
 
     torch.manual_seed(0)                                   # model seed 0 on every rank: identical replicas, no broadcast needed
-    model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000).to(dev).train()
+    mkw = dict(rotation_modulation=True) if args.rotation_modulation else {}
+    model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000, **mkw).to(dev).train()
     model.gemm_precision = args.precision
     torch.manual_seed(1000 + rank)                         # from here on every rank draws its OWN timesteps, noise and label drops
     diffusion = create_diffusion(timestep_respacing="")
@@ -313,7 +316,7 @@ def main():
     achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if cnt.value else None
     at = f"@{global_batch}" if args.scaling == "strong" else f"@{B}/GPU"
     out = {
-        "metric": f"latent-images/sec training step, {args.model} {args.precision} {at}",
+        "metric": f"latent-images/sec training step, {args.model} {args.precision}{' rotation-modulation' if args.rotation_modulation else ''} {at}",
         "value": value, "unit": "latent-img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": statistics.median(per_step),
         "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
@@ -334,7 +337,7 @@ def main():
                      "launches_timed": cnt.value, "avg_launch_ms": fc1_ms, "flops_per_launch": fc1_flops},
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.rotation_modulation:
             out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps, args.cpu_c1_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -170,6 +170,14 @@ typedef struct {
     float ca, cb;          /* 0.7/sqrt(0.58), 0.3/sqrt(0.58) for t = 0.3 */
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
+
+/* Rotation modulation (the reference's README.md:1-3; NOT in its snapshot - parity unpinned, semantics: oracle.modulate_rot):
+ * in place on the bf16 operand u [n_samples*T, D] = x * scale: (u[2i], u[2i+1]) <- R(*gain * theta[n, i]) (u[2i], u[2i+1]);
+ * theta fp32 rows of D/2 angles, stride ldt.  The backward rotates the gradient back in place (dy <- R^T dy), writes
+ * dtheta[n, i] = *gain * sum_t (dy1 y0 - dy0 y1) (y = the saved rotated operand) and n_samples * D/128 partial sums of dgain. */
+int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D, void* stream);
+int mapdit_rotate_bwd(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta, int ldd,
+                      float* dgain_part, int n_samples, int T, int D, void* stream);
 int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream);
 
 int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream);          /* mp_silu.py:7 */
@@ -274,6 +282,8 @@ typedef struct {
                      * backward - fp32 activations and gradients, every product on the same MFMA kernel with both operands
                      * split into hi+lo bf16 terms along the reduction index (3x the GEMM work, unfused fp32 pointwise and
                      * attention kernels); logits, losses and parameter gradients agree with the fp32 reference to ~1e-5. */
+    int rotation;   /* != 0: rotation modulation (README.md:1-3; parity unpinned): a block's modulation linear has 5*hidden rows
+                     * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m).  MAPDIT_PREC_BF16 only. */
 } mapdit_config_t;
 enum { MAPDIT_PREC_BF16 = 0, MAPDIT_PREC_BF16X3 = 1 };
 

@@ -44,7 +44,7 @@ class AdamScalars(C.Structure):    # mapdit_adam_scalars_t
 
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
-                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci)]
+                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci), ("rotation", ci)]
 
 
 PRECISIONS = {"bf16": 0, "bf16x3": 1}
@@ -72,6 +72,8 @@ _SIGS = {
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
+    "mapdit_rotate_fwd": [vp, vp, ci, vp, ci, ci, ci, vp],
+    "mapdit_rotate_bwd": [vp, vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp],
     "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],

@@ -48,6 +48,11 @@ struct mapdit_engine {
     mapdit_config_t cfg;
     int train;
     int T, P, P1, ldp, ldl, D, Hm, heads, hd, M_max;
+    // A block's modulation row: (shift | scale | gate) x 2 = 6 D wide, or with rotation modulation (theta [D/2] | scale | gate) x 2 =
+    // 5 D wide.  MW = its width, o_* = the offsets of the chunks (o_sh* = the shift resp. angle chunk).
+    bool rot = false;
+    int MW = 0, o_sha = 0, o_sca = 0, o_ga = 0, o_shm = 0, o_scm = 0, o_gm = 0;
+    float *zero_rows = nullptr, *sink_rows = nullptr, *zero_gain = nullptr, *sink_gain = nullptr;   // rotation mode: see engine_create
     bool generic_attn = false;
     int last_N = 0;
     int next_stage = 0;                   // backward stage expected next (stages run in order)
@@ -135,7 +140,7 @@ size_t carve(mapdit_engine* e, void* base) {
     img(MAPDIT_P_F_MOD, 2 * D, D, 2 * D);
     img(MAPDIT_P_MS_LIN, NSCALE, D, NSCALE);
     img(MAPDIT_P_SS_LIN, NSCALE, D, NSCALE);
-    for (int i = 0; i < L; ++i) img(pidx_block(i, MAPDIT_B_MOD), 6 * D, D, 6 * D);   // contiguous: one [L*6D, D] operand
+    for (int i = 0; i < L; ++i) img(pidx_block(i, MAPDIT_B_MOD), e->MW, D, e->MW);   // contiguous: one [L*MW, D] operand
     for (int i = 0; i < L; ++i) {
         img(pidx_block(i, MAPDIT_B_QKV), 3 * D, D, 3 * D);
         img(pidx_block(i, MAPDIT_B_PROJ), D, D, D);
@@ -177,8 +182,8 @@ size_t carve(mapdit_engine* e, void* base) {
     }
     e->patches = e->train && !precise ? cv.take<bf16_t>(M * e->ldp) : nullptr;
     e->fmod = cv.take<float>((size_t)N * 2 * D);
-    e->mod_all = cv.take<float>((size_t)N * L * 6 * D);
-    e->ldm = L * 6 * D;
+    e->mod_all = cv.take<float>((size_t)N * L * e->MW);
+    e->ldm = L * e->MW;
     e->lin = cv.take<float>(M * 2 * e->P);
     e->a_mean = cv.take<float>((size_t)N * NSCALE);
     e->a_sigma = cv.take<float>((size_t)N * NSCALE);
@@ -241,8 +246,14 @@ size_t carve(mapdit_engine* e, void* base) {
         e->cp.img3[MAPDIT_P_F_MOD] = cv.take<bf16_t>((size_t)3 * 2 * D * D);
         e->cp.img3[MAPDIT_P_MS_LIN] = cv.take<bf16_t>((size_t)3 * NSCALE * D);
         e->cp.img3[MAPDIT_P_SS_LIN] = cv.take<bf16_t>((size_t)3 * NSCALE * D);
-        bf16_t* modall = cv.take<bf16_t>((size_t)3 * L * 6 * D * D);                 // one [L*6D][3D] operand
-        for (int i = 0; i < L; ++i) e->cp.img3[pidx_block(i, MAPDIT_B_MOD)] = modall + (size_t)i * 6 * D * 3 * D;
+        bf16_t* modall = cv.take<bf16_t>((size_t)3 * L * e->MW * D);                 // one [L*MW][3D] operand
+        for (int i = 0; i < L; ++i) e->cp.img3[pidx_block(i, MAPDIT_B_MOD)] = modall + (size_t)i * e->MW * 3 * D;
+        if (e->rot) {
+            e->zero_rows = cv.take<float>((size_t)N * L * e->MW);
+            e->sink_rows = cv.take<float>((size_t)N * L * e->MW);
+            e->zero_gain = cv.take<float>(64);
+            e->sink_gain = e->zero_gain + 32;
+        }
     }
     if (e->train) {
         size_t gmax = (size_t)6 * D * D;
@@ -254,7 +265,7 @@ size_t carve(mapdit_engine* e, void* base) {
         e->G_cap = (long)gmax;
         e->DXa = cv.take<float>(M * D);
         e->DXb = cv.take<float>(M * D);
-        e->dmod = cv.take<float>((size_t)L * N * 6 * D);
+        e->dmod = cv.take<float>((size_t)L * N * e->MW);
         e->dfmod = cv.take<float>((size_t)N * 2 * D);
         e->dcs = cv.take<float>((size_t)N * D);
         e->dcd = cv.take<float>((size_t)N * D);
@@ -277,7 +288,7 @@ size_t carve(mapdit_engine* e, void* base) {
         e->zero_bytes_dlin = M * e->ldl * sizeof(bf16_t);
         e->da_bf = cv.take<bf16_t>((size_t)2 * N * NSCALE);
         e->dref_part = cv.take<float>((size_t)2 * N * NSCALE);
-        e->dmod_bf = cv.take<bf16_t>((size_t)N * L * 6 * D);
+        e->dmod_bf = cv.take<bf16_t>((size_t)N * L * e->MW);
         e->dx0_bf = cv.take<bf16_t>(M * D);
         e->dtemb_bf = cv.take<bf16_t>((size_t)N * D);
         e->dh1_bf = cv.take<bf16_t>((size_t)N * D);
@@ -290,6 +301,7 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
     MD_CHECK(c->precision == MAPDIT_PREC_BF16 || c->precision == MAPDIT_PREC_BF16X3, "engine: unknown precision %d", c->precision);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
+    MD_CHECK(!c->rotation || c->precision == MAPDIT_PREC_BF16, "engine: rotation modulation is built for the bf16 engine only");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
              "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
     MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
@@ -317,6 +329,11 @@ void init_dims(mapdit_engine* e) {
     // generic fp32 path of attention_generic.hip
     e->generic_attn = !(e->hd == 64 && (e->T == 64 || e->T == 128 || e->T == 256));
     e->M_max = c.max_batch * e->T;
+    const int D = c.hidden;
+    e->rot = c.rotation != 0;
+    e->MW = (e->rot ? 5 : 6) * D;
+    if (e->rot) { e->o_sha = 0; e->o_sca = D / 2; e->o_ga = D / 2 + D; e->o_shm = D / 2 + 2 * D; e->o_scm = 3 * D; e->o_gm = 4 * D; }
+    else { e->o_sha = 0; e->o_sca = D; e->o_ga = 2 * D; e->o_shm = 3 * D; e->o_scm = 4 * D; e->o_gm = 5 * D; }
 }
 
 #define TRY(call)                    \
@@ -380,11 +397,27 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
 // allows (whole 64-row blocks per sample, 256x256 tiles) both run as ONE launch: the GEMM's epilogue consumes the fp32 accumulators
 // (MAPDIT_EPI_RMB) - the bf16 dxm tensor is neither written nor re-read and the pointwise pass disappears; otherwise the GEMM stores
 // dxm and mapdit_resid_mod_bwd follows.  `a` arrives filled except for dxm.  Ends with the deterministic sum of the gain partials.
+// Rotation modulation (rot != nullptr): the dX result is first rotated back in place (mapdit_rotate_bwd: also the angle and gain
+// gradients), then the usual backward runs on it with shift = 0 and gain = 0, its shift / gain gradients going to sinks.
+struct RotBwd {
+    const bf16_t* y;       // the saved rotated operand (xm / xm2 of the block)
+    const float* theta;    // the block's angle chunk in mod_all
+    float* dtheta;         // its slot in dmod
+    const float* gain;     // the block's learnable gain
+};
 int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy, const bf16_t* wimg, mapdit_resid_mod_bwd_t& a,
-                     float* dgain, void* st) {
+                     float* dgain, void* st, const RotBwd* rot = nullptr) {
     static const bool no_fuse = [] { const char* v = getenv("MAPDIT_NO_FUSED_RMB"); return v && v[0] == '1'; }();
     const int D = e->D;
     int npart;
+    if (rot) {
+        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
+        TRY(mapdit_rotate_bwd(e->dxm, rot->y, rot->theta, e->ldm, rot->gain, rot->dtheta, e->ldm, e->gain_part, a.n_samples, a.T, D, st));
+        TRY(mapdit_reduce_partials(e->gain_part, a.n_samples * (D / 128), dgain, 0, st));
+        a.dxm = e->dxm;
+        TRY(mapdit_resid_mod_bwd(&a, st));              // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
+        return MAPDIT_OK;
+    }
     // (fused where the dX result takes the 256^2 kernel and a pointwise pass over it would run on a small grid: measured 1.3 %
     // of the step at 32 and 64 samples, nothing at 256, where the separate pass streams at 5.3 TB/s)
     if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_ex(M, D, 0) == 256) {
@@ -474,6 +507,9 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t) * (cfg->precision == MAPDIT_PREC_BF16X3 ? 3 : 1),
                                    (hipStream_t)stream);
     if (he == hipSuccess && train && e->dlin) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
+    // rotation mode: the fused modulate kernels run with shift = 0 and gain = 0 (u = x * scale); their shift / gain gradients go to sinks
+    if (he == hipSuccess && e->rot) he = hipMemsetAsync(e->zero_rows, 0, (size_t)cfg->max_batch * e->ldm * sizeof(float), (hipStream_t)stream);
+    if (he == hipSuccess && e->rot) he = hipMemsetAsync(e->zero_gain, 0, 64 * sizeof(float), (hipStream_t)stream);
     if (he != hipSuccess) {
         delete e;
         mapdit_set_error("engine_create: memset failed: %s", hipGetErrorString(he));
@@ -830,15 +866,20 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_MPSILU, st));
     TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm), st));
     TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D), st));
-    TRY(mapdit_modulate_fwd(e->X[0], e->mod_all, e->mod_all + D, ldm, e->params[pidx_block(0, MAPDIT_B_GAIN_MSA)],
+    // rotation modulation: the fused modulates run with shift = 0, gain = 0 (u = x * scale) and mapdit_rotate_fwd turns u in place
+    const float* sh_base = e->rot ? e->zero_rows : e->mod_all;            // where the "shift" chunks are read from
+    auto gain_of = [&](int pidx) -> const float* { return e->rot ? e->zero_gain : e->params[pidx]; };
+    TRY(mapdit_modulate_fwd(e->X[0], sh_base + e->o_sha, e->mod_all + e->o_sca, ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)),
                             e->blk[0].xm, N, T, D, st));
     for (int i = 0; i < L; ++i) {
         BlockBufs& b = e->blk[save ? i : 0];
-        const float* mod = e->mod_all + (size_t)i * 6 * D;
+        const float* mod = e->mod_all + (size_t)i * e->MW;
+        const float* shm = sh_base + (size_t)i * e->MW;                    // the block's row of shift chunks (zeros with rotation)
         float* xin = e->X[save ? 2 * i : (2 * i) % 3];
         float* xmid = e->X[save ? 2 * i + 1 : (2 * i + 1) % 3];
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
-        float* gmlp = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
+        const float* gmlp = gain_of(pidx_block(i, MAPDIT_B_GAIN_MLP));
+        if (e->rot) TRY(mapdit_rotate_fwd(b.xm, mod + e->o_sha, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], N, T, D, st));
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         if (e->generic_attn) {
             TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
@@ -854,16 +895,17 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         }
         TRY(mapdit_attn_cos_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
-                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + 2 * D, ldm, T, D, b.xm2, mod + 3 * D, mod + 4 * D, ldm, gmlp), st));
+                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, shm + e->o_shm, mod + e->o_scm, ldm, gmlp), st));
+        if (e->rot) TRY(mapdit_rotate_fwd(b.xm2, mod + e->o_shm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], N, T, D, st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
-                 i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->blk[save ? i + 1 : 0].xm, mod + 6 * D,
-                                       mod + 7 * D, ldm, e->params[pidx_block(i + 1, MAPDIT_B_GAIN_MSA)])
-                           : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + 5 * D, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
+                 i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
+                                       shm + e->MW + e->o_sha, mod + e->MW + e->o_sca, ldm, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)))
+                           : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
                                        e->params[MAPDIT_P_F_GAIN]), st));
     }
     float* xL = e->X[save ? 2 * L : (2 * L) % 3];
@@ -963,8 +1005,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
         a.x = e->X[2 * L]; a.shift = e->fmod; a.scale = e->fmod + D; a.gain = e->params[MAPDIT_P_F_GAIN];
         a.ldmod = 2 * D; a.dshift = e->dfmod; a.dscale = e->dfmod + D; a.ldd = 2 * D; a.dgain_part = e->gain_part;
-        a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * 6 * D + 5 * D; a.ldg_up = e->ldm; a.dy_up = e->dy;
-        a.dg_up = e->dmod + (size_t)(L - 1) * 6 * D + 5 * D; a.ldd_up = e->ldm;
+        a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * e->MW + e->o_gm; a.ldg_up = e->ldm; a.dy_up = e->dy;
+        a.dg_up = e->dmod + (size_t)(L - 1) * e->MW + e->o_gm; a.ldd_up = e->ldm;
         a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
         TRY(dx_resid_mod_bwd(e, M, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), a, G(MAPDIT_P_F_GAIN), st));
     }
@@ -978,21 +1020,26 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         const int stage = L - i;
         if (stage < stage_from || stage > stage_to) continue;
         const BlockBufs& b = e->blk[i];
-        float* dmod = e->dmod + (size_t)i * 6 * D;            // [N][L*6D] like mod_all
-        const float* mod = e->mod_all + (size_t)i * 6 * D;
+        float* dmod = e->dmod + (size_t)i * e->MW;            // [N][L*MW] like mod_all
+        const float* mod = e->mod_all + (size_t)i * e->MW;
         const int ldm = e->ldm;
+        // rotation modulation: shift chunks read as zeros, their gradients (and the fused modulate's gain partials) written to sinks
+        const float* shm = (e->rot ? e->zero_rows : e->mod_all) + (size_t)i * e->MW;
+        float* dshm = (e->rot ? e->sink_rows : e->dmod) + (size_t)i * e->MW;
         // MLP branch
         TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = mod + 3 * D; a.scale = mod + 4 * D;
-            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldm;
-            a.dshift = dmod + 3 * D; a.dscale = dmod + 4 * D; a.ldd = ldm; a.dgain_part = e->gain_part;
-            a.y_up = b.y; a.g_up = mod + 2 * D; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + 2 * D; a.ldd_up = ldm;
+            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = shm + e->o_shm; a.scale = mod + e->o_scm;
+            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldm;
+            a.dshift = dshm + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
+            a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
             a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st));
+            const RotBwd rb{b.xm2, mod + e->o_shm, dmod + e->o_shm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
+            TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st,
+                                 e->rot ? &rb : nullptr));
         }
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
@@ -1006,24 +1053,26 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = mod; a.scale = mod + D;
-            a.gain = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldm;
-            a.dshift = dmod; a.dscale = dmod + D; a.ldd = ldm; a.dgain_part = e->gain_part;
+            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = shm + e->o_sha; a.scale = mod + e->o_sca;
+            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldm;
+            a.dshift = dshm + e->o_sha; a.dscale = dmod + e->o_sca; a.ldd = ldm; a.dgain_part = e->gain_part;
             if (i > 0) {
                 const BlockBufs& bp = e->blk[i - 1];
-                a.y_up = bp.y2; a.g_up = mod - D; a.ldg_up = ldm; a.dy_up = e->dy;     // gate_mlp of block i-1
-                a.dg_up = dmod - D; a.ldd_up = ldm;
+                a.y_up = bp.y2; a.g_up = mod - e->MW + e->o_gm; a.ldg_up = ldm; a.dy_up = e->dy;     // gate_mlp of block i-1
+                a.dg_up = dmod - e->MW + e->o_gm; a.ldd_up = ldm;
                 a.dx = e->DXa;
             } else {
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
             }
             a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            TRY(dx_resid_mod_bwd(e, M, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), a, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), st));
+            const RotBwd rb{b.xm, mod + e->o_sha, dmod + e->o_sha, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]};
+            TRY(dx_resid_mod_bwd(e, M, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), a, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), st,
+                                 e->rot ? &rb : nullptr));
         }
         // modulation linear of this block (its six gradient chunks are complete now): dW here, so the block's gradient
         // slice is final when its stage ends (the DP reducer relies on that); d c_silu for all blocks in one GEMM below
-        TRY(mapdit_f32_to_bf16_2d(dmod, ldm, e->dmod_bf + (size_t)i * 6 * D, ldm, N, 6 * D, 1.f, st));
-        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * 6 * D, ldm, e->c_silu, D, N, 1.f, st));
+        TRY(mapdit_f32_to_bf16_2d(dmod, ldm, e->dmod_bf + (size_t)i * e->MW, ldm, N, e->MW, 1.f, st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * e->MW, ldm, e->c_silu, D, N, 1.f, st));
         if (i == 0) {
             // d c_silu += dmod_all W_mod_all: ONE split-K GEMM over K = L*6D, slabs summed into dcs
             mapdit_epilogue_t ep = epi_f32(e->G, D, 1.f);

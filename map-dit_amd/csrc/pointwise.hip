@@ -132,6 +132,77 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     }
 }
 
+// ---- rotation modulation (PARITY UNPINNED: not in the reference snapshot, its README.md:1-3 only; oracle.modulate_rot) ----------
+// The engine runs the rotation as a pass of its own over the bf16 operand u = x * scale that the fused modulate already produced
+// (shift = 0, gain = 0 there): (u[2i], u[2i+1]) <- R(g theta[n, i]) (u[2i], u[2i+1]), g = the block's learnable gain.
+__global__ __launch_bounds__(256) void rot_fwd_kernel(bf16_t* __restrict__ u, const float* __restrict__ theta, int ldt,
+                                                    const float* __restrict__ gain, long total8, int D, int T) {
+    const float g = *gain;
+    const int d8 = D >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / d8;
+        const int d = (int)(i % d8) * 8;
+        const int n = (int)(m / T);
+        const float4 th = *(const float4*)(theta + (size_t)n * ldt + (d >> 1));
+        const float ang[4] = {g * th.x, g * th.y, g * th.z, g * th.w};
+        uint4 v = *(const uint4*)(u + m * D + d);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sn, cs;
+            sincosf(ang[j], &sn, &cs);
+            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+            w[j] = pack2bf(cs * a - sn * b, sn * a + cs * b);
+        }
+        *(uint4*)(u + m * D + d) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Backward of the pass above, in place on the gradient: dy <- R^T dy (the gradient wrt x * scale, which the resid / modulate
+// backward then consumes as before), dtheta[n, i] = g * sum_t (dy1 y0 - dy0 y1) with y the saved rotated operand, and the block's
+// share of dgain = sum_i theta[n, i] * sum_t (...).  Block = one sample x 128 columns; 32 column-lanes (two pairs each) x 8 row
+// groups; LDS reduce over the row groups (no atomics).
+__global__ __launch_bounds__(256) void rot_bwd_kernel(bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                    const float* __restrict__ theta, int ldt, const float* __restrict__ gain,
+                                                    float* __restrict__ dtheta, int ldd, float* __restrict__ dgain_part, int T, int D) {
+    __shared__ float red[8][32][2];
+    const int n = blockIdx.x, cb0 = blockIdx.y * 128;
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int d = cb0 + cl * 4;
+    const float g = *gain;
+    const float2 th = *(const float2*)(theta + (size_t)n * ldt + (d >> 1));
+    float sn[2], cs[2];
+    sincosf(g * th.x, &sn[0], &cs[0]);
+    sincosf(g * th.y, &sn[1], &cs[1]);
+    float acc[2] = {0.f, 0.f};
+    for (int t = rg; t < T; t += 8) {
+        const size_t off = ((size_t)n * T + t) * D + d;
+        const uint2 gv = *(const uint2*)(dy + off), yv = *(const uint2*)(y + off);
+        const uint32_t gw[2] = {gv.x, gv.y}, yw[2] = {yv.x, yv.y};
+        uint32_t o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
+            const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+            acc[j] += g1 * y0 - g0 * y1;
+            o[j] = pack2bf(cs[j] * g0 + sn[j] * g1, cs[j] * g1 - sn[j] * g0);
+        }
+        *(uint2*)(dy + off) = make_uint2(o[0], o[1]);
+    }
+    red[rg][cl][0] = acc[0]; red[rg][cl][1] = acc[1];
+    __syncthreads();
+    if (rg == 0) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { s0 += red[r][cl][0]; s1 += red[r][cl][1]; }
+        *(float2*)(dtheta + (size_t)n * ldd + (d >> 1)) = make_float2(g * s0, g * s1);
+        float gs = th.x * s0 + th.y * s1;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
+        if (cl == 0) dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gs;
+    }
+}
+
 // Deterministic final reduction of per-block partials into a scalar gradient (gain_msa / gain_mlp / gain_mod).
 __global__ void reduce_partials_kernel(const float* __restrict__ part, int count, float* __restrict__ out, int accumulate) {
     float a = 0.f;
@@ -281,6 +352,27 @@ extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* strea
     p.dgain_part = a->dgain_part; p.dy_up = a->dy_up; p.dg_up = a->dg_up;
     p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
     hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128), dim3(256), 0, (hipStream_t)stream, p);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D,
+                                 void* stream) {
+    MD_CHECK(u && theta && gain && n_samples > 0, "rotate_fwd: null/empty argument");
+    MD_CHECK(D % 8 == 0 && ldt % 4 == 0 && ((uintptr_t)theta & 15) == 0, "rotate_fwd: D %% 8, ldt %% 4 and a 16-byte aligned theta");
+    const long total8 = (long)n_samples * T * (D / 8);
+    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(rot_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)u, theta, ldt, gain, total8, D, T);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_rotate_bwd(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta,
+                                 int ldd, float* dgain_part, int n_samples, int T, int D, void* stream) {
+    MD_CHECK(dy && y && theta && gain && dtheta && dgain_part && n_samples > 0, "rotate_bwd: null/empty argument");
+    MD_CHECK(D % 128 == 0 && ldt % 2 == 0 && ldd % 2 == 0, "rotate_bwd: D=%d must be a multiple of 128, even row strides", D);
+    hipLaunchKernelGGL(rot_bwd_kernel, dim3(n_samples, D / 128), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, (const bf16_t*)y,
+                       theta, ldt, gain, dtheta, ldd, dgain_part, T, D);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -89,13 +89,19 @@ class MLP(_Fused):
 
 
 class DiTBlock(_Fused):
-    """reference src/blocks/dit_block.py:10-29."""
+    """reference src/blocks/dit_block.py:10-29.  ``rotation_modulation`` (not in the reference snapshot, README.md:1-3 only; parity
+    unpinned, semantics in oracle.dit_oracle.modulate_rot): the modulation linear yields (theta [D/2], scale, gate) x 2 = 5 D rows
+    instead of (shift, scale, gate) x 2 = 6 D."""
 
-    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0):
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, rotation_modulation=False):
         super().__init__()
         self.attn = Attention(hidden_size, num_heads)
         self.mlp = MLP(hidden_size, hidden_size, mlp_ratio=mlp_ratio)
-        self.modulation = nn.Sequential(MPSiLU(), MPLinearChunk(hidden_size, hidden_size, 6))
+        if rotation_modulation:
+            assert hidden_size % 2 == 0
+            self.modulation = nn.Sequential(MPSiLU(), MPLinearChunk(hidden_size, hidden_size // 2, 10))      # 5 D rows
+        else:
+            self.modulation = nn.Sequential(MPSiLU(), MPLinearChunk(hidden_size, hidden_size, 6))
         self.gain_msa = nn.Parameter(torch.tensor(0.0))
         self.gain_mlp = nn.Parameter(torch.tensor(0.0))
 
@@ -185,7 +191,7 @@ class _Runtime:
         self.cfg = L.Config(depth=len(model.blocks), hidden=model.hidden_size, patch=model.patch_size,
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
                             mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
-                            precision=L.PRECISIONS[precision])
+                            precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)))
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
             raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
@@ -270,7 +276,7 @@ class DiT(nn.Module):
 
     def __init__(self, depth: int, hidden_size: int, patch_size: int, input_size: int = 32, in_channels: int = 3,
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
-                 learn_sigma: bool = True):
+                 learn_sigma: bool = True, rotation_modulation: bool = False):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -285,6 +291,7 @@ class DiT(nn.Module):
         self.mlp_ratio = mlp_ratio
         self.class_dropout_prob = class_dropout_prob
         self.num_classes = num_classes
+        self.rotation_modulation = bool(rotation_modulation)      # README.md:1-3; not in the snapshot: parity unpinned
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
@@ -292,7 +299,8 @@ class DiT(nn.Module):
         pe = torch.from_numpy(get_2d_sincos_pos_embed(hidden_size, input_size // patch_size)).float().unsqueeze(0)
         pe = pe * math.sqrt(pe.shape[-1]) / (torch.linalg.vector_norm(pe, dim=-1, keepdim=True) + 1e-4)   # dit.py:46-48
         self.register_buffer("pos_embed", pe)
-        self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, rotation_modulation=self.rotation_modulation)
+                                     for _ in range(depth)])
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
 
         self._rt = {}                 # {train (bool) | ("bf16x3", train): _Runtime}
@@ -490,7 +498,8 @@ class DiT(nn.Module):
     def __deepcopy__(self, memo):
         new = DiT(depth=self.depth, hidden_size=self.hidden_size, patch_size=self.patch_size, input_size=self.input_size,
                   in_channels=self.in_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
-                  class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma)
+                  class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
+                  rotation_modulation=self.rotation_modulation)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

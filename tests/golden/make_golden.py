@@ -53,7 +53,7 @@ def rel(a, b):
 
 
 def build_ref(cfg: O.DiTConfig, sd):
-    m = RefDiT(**cfg.to_dict())
+    m = RefDiT(**cfg.to_dict())            # (to_dict leaves the build-only rotation switch out unless it is set)
     missing = m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
     return m
 

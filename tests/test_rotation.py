@@ -1,0 +1,142 @@
+"""Rotation modulation (BASELINE config 3; reference README.md:1-3).  The reference SNAPSHOT does not contain it, so
+nothing here is pinned by the reference: the semantics are the build's own restatement (oracle.dit_oracle.modulate_rot), held by
+invariants - the parameter saving the README states, identity at zero angle / zero gain (bit for bit the snapshot's modulate at
+gain 0), norm preservation - and the engine is checked against that oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, sub
+from oracle import dit_oracle as O
+
+TINY = dict(depth=2, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
+
+
+def test_parameter_saving_matches_the_readme():
+    """README.md:3 "~5.4 % fewer parameters": two D-wide shift chunks -> two D/2-wide angle chunks per block."""
+    for name in ("DiT-B/2", "DiT-XL/2", "DiT-S/2"):
+        a = O.param_shapes(O.model_config(name, in_channels=4, input_size=32, num_classes=1000))
+        b = O.param_shapes(O.model_config(name, in_channels=4, input_size=32, num_classes=1000, rotation_modulation=True))
+        count = lambda s: sum(int(np.prod(v)) for k, v in s.items() if k not in O.BUFFER_KEYS)
+        saving = 1 - count(b) / count(a)
+        print(name, f"{saving:.4f}")
+        assert 0.050 < saving < 0.058, (name, saving)
+    from mapdit_amd.src.models import DIT_MODELS
+    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=10, rotation_modulation=True)
+    assert m.blocks[0].modulation[1].weight.shape == (5 * 256, 256)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
+        {k: tuple(v) for k, v in O.param_shapes(O.model_config("DiT-XS/2", in_channels=4, input_size=32, num_classes=10,
+                                                               rotation_modulation=True)).items()}
+
+
+def test_rotation_invariants_of_the_restatement():
+    g = torch.Generator().manual_seed(1)
+    x, scale = torch.randn(3, 5, 16, generator=g), torch.randn(3, 16, generator=g)
+    theta, shift = torch.randn(3, 8, generator=g), torch.randn(3, 16, generator=g)
+    # zero gain or zero angle: exactly x * scale = the snapshot's modulate() at gain 0 (utils.py:11-16)
+    want = O.modulate(x, shift, scale, torch.tensor(0.0))
+    assert torch.equal(O.modulate_rot(x, theta, scale, torch.tensor(0.0)), want)
+    assert torch.equal(O.modulate_rot(x, torch.zeros_like(theta), scale, torch.tensor(0.7)), want)
+    assert torch.equal(want, x * scale.unsqueeze(1))
+    # a rotation: every feature pair keeps its magnitude, and R(a) R(b) = R(a + b)
+    y = O.modulate_rot(x, theta, scale, torch.tensor(0.6))
+    pair = lambda v: v.reshape(*v.shape[:-1], -1, 2).norm(dim=-1)
+    assert torch.allclose(pair(y), pair(want), rtol=1e-5, atol=1e-6)
+    ones = torch.ones_like(scale)
+    twice = O.modulate_rot(O.modulate_rot(x, theta, ones, torch.tensor(0.25)), theta, ones, torch.tensor(0.35))
+    assert torch.allclose(twice, O.modulate_rot(x, theta, ones, torch.tensor(0.6)), rtol=1e-5, atol=1e-6)
+    # a quarter turn maps (a, b) -> (-b, a)
+    q = O.modulate_rot(x, torch.full_like(theta, math.pi / 2), ones, torch.tensor(1.0))
+    assert torch.allclose(q[..., 0::2], -x[..., 1::2], atol=1e-6) and torch.allclose(q[..., 1::2], x[..., 0::2], atol=1e-6)
+
+
+def _rot_state_from(sd, cfg):
+    """The rotation model whose (scale, gate) rows are those of an AdaLN state dict (angle rows: fresh N(0,1))."""
+    D = cfg.hidden_size
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("modulation.1.weight") and k.startswith("blocks."):
+            sh_a, sc_a, g_a, sh_m, sc_m, g_m = v.chunk(6, dim=0)
+            out[k] = torch.cat([torch.randn(D // 2, D, generator=g), sc_a, g_a, torch.randn(D // 2, D, generator=g), sc_m, g_m], 0)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def test_oracle_network_at_zero_gain_equals_the_snapshot_network():
+    cfg = O.DiTConfig(**TINY)
+    rcfg = O.DiTConfig(**TINY, rotation_modulation=True)
+    sd = O.init_state_dict(cfg, seed=4)                       # gains 0 (the reference's init)
+    rsd = _rot_state_from(sd, cfg)
+    g = torch.Generator().manual_seed(5)
+    x, t, y = torch.randn(3, 4, 16, 16, generator=g), torch.randint(0, 1000, (3,), generator=g), torch.randint(0, 10, (3,), generator=g)
+    with torch.no_grad():
+        a = O.dit_forward(sd, cfg, x, t, y, train=False)
+        b = O.dit_forward(rsd, rcfg, x, t, y, train=False)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gain():
+    from mapdit_amd import _lib as L
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.dit import DiT
+    from oracle.diffusion_oracle import DiffusionOracle
+    dev = "cuda"
+    cfg = O.DiTConfig(**TINY)
+    rcfg = O.DiTConfig(**TINY, rotation_modulation=True)
+    g = torch.Generator().manual_seed(6)
+    n = 4
+    x, t, y = torch.randn(n, 4, 16, 16, generator=g), torch.randint(0, 1000, (n,), generator=g), torch.randint(0, 10, (n,), generator=g)
+    noise = torch.randn(n, 4, 16, 16, generator=g)
+    # (1) zero gains: bit for bit the logits of the snapshot's AdaLN engine with the same scale / gate rows
+    sd0 = O.init_state_dict(cfg, seed=4)
+    ma, mr = DiT(**cfg.to_dict()), DiT(**rcfg.to_dict())
+    ma.load_state_dict(sd0)
+    mr.load_state_dict(_rot_state_from(sd0, cfg))
+    ma, mr = ma.to(dev).eval(), mr.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(ma(x.to(dev), t.to(dev), y.to(dev)), mr(x.to(dev), t.to(dev), y.to(dev)))
+    # (2) non-zero gains: eval logits, training loss and every gradient against the oracle's restatement (bf16 tolerances)
+    rsd = O.init_state_dict(rcfg, seed=7, gains=0.4, perturb_reference=0.3)
+    m = DiT(**rcfg.to_dict())
+    m.load_state_dict(rsd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        out = m(x.to(dev), t.to(dev), y.to(dev)).cpu()
+        want = O.dit_forward({k: v.clone() for k, v in rsd.items()}, rcfg, x, t, y, train=False)
+    e = rel_err(out.numpy(), want.numpy())
+    print(f"rotation: eval logits vs oracle {e:.3e}")
+    assert e < 2e-2
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    losses = create_diffusion("").training_losses(m, x.to(dev), t.to(dev), dict(y=y.to(dev)), noise=noise.to(dev))
+    losses["loss"].mean().backward()
+    torch.cuda.synchronize()
+    osd = {k: v.clone().requires_grad_(k not in O.BUFFER_KEYS) for k, v in rsd.items()}
+    drop = torch.zeros(n, dtype=torch.bool)
+    ref = DiffusionOracle("").training_losses(lambda xx, tt, **kw: O.dit_forward(osd, rcfg, xx, tt, kw["y"], train=True, drop=drop),
+                                              x, t, dict(y=y), noise=noise)
+    ref["loss"].mean().backward()
+    assert rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy()) < 2e-2
+    gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if "gain_" in k)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        gref = osd[k].grad
+        if p.dim() == 0:
+            assert abs(float(p.grad) - float(gref)) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            continue
+        e = rel_err(sub(p.grad), sub(gref))
+        worst = max(worst, e)
+        assert e < 6e-2 or float(gref.norm()) < 1e-7, (k, e)
+    print(f"rotation: worst gradient rel err vs oracle {worst:.3e}")
+    # the modulation weight's angle rows do receive gradient
+    mw = dict(m.named_parameters())["blocks.0.modulation.1.weight"].grad
+    assert float(mw[:64].abs().sum()) > 0
+    # (3) the fp32-accurate engine does not carry the rotation: refused, not silently ignored
+    m.gemm_precision = "bf16x3"
+    with pytest.raises(L.MapditError):
+        m(x.to(dev), t.to(dev), y.to(dev))
