@@ -66,6 +66,7 @@ def main():
          ep(L.EPI_QKV_HEADS, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), out3=out_bf3.data_ptr(), out4=scales.data_ptr(),
             rows_per_sample=256, alpha=1.0)),
         ("fc1  fwd NT silu2", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_SILU2, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), ldo=4 * D)),
+        ("fc1  fwd NT silugrad", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_SILU2_GRAD, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), ldo=4 * D)),
         ("fc2  fwd NT resid", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D,
          ep(L.EPI_RESID, out=out_bf.data_ptr(), out2=xout.data_ptr(), aux=xres.data_ptr(), gate=gate.data_ptr(), ldg=6 * D,
             rows_per_sample=256, ldo=D, alpha=0.9, beta=0.4)),
