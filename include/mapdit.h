@@ -168,6 +168,11 @@ typedef struct {
     int ldmod, ldg_up, ldd, ldd_up;
     int n_samples, T, D;
     float ca, cb;          /* 0.7/sqrt(0.58), 0.3/sqrt(0.58) for t = 0.3 */
+    /* optional (may stay zero): scratch for the row-split form that small batches take (>= 8 * n_samples * 3 * D floats gives the
+     * kernel every choice); dgain_part must then hold 8x the partials, and *gain_partials_out receives how many were written */
+    float* part_scratch;
+    size_t part_scratch_bytes;
+    int* gain_partials_out;
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
 

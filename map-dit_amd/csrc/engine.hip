@@ -77,7 +77,7 @@ struct mapdit_engine {
     int ldm;                              // = L*6D
     bf16_t* xmodf;
     // backward scratch
-    float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part, *dref_part;
+    float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part, *dref_part, *rmb_part = nullptr;
     bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
     // one-launch weight pass: job table (host copy + device copy in the workspace), rebuilt by engine_bind
@@ -275,7 +275,8 @@ size_t carve(mapdit_engine* e, void* base) {
     }
     if (e->train && !precise) {                            // bf16 gradient operands of the fast path
         e->delta = cv.take<float>((size_t)N * c.num_heads * T);
-        e->gain_part = cv.take<float>((size_t)N * (D / 128));
+        e->gain_part = cv.take<float>((size_t)8 * N * (D / 128));      // x8: the row-split form of resid_mod_bwd (small batches)
+        e->rmb_part = cv.take<float>((size_t)8 * N * 3 * D);
         e->dy = cv.take<bf16_t>(M * D);
         e->dh = cv.take<bf16_t>(M * Hm);
         e->dxm = cv.take<bf16_t>(M * D);
@@ -393,10 +394,10 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
     return want < 1 ? 1 : (int)want;
 }
 
-// dX GEMM of a branch, dxm = dy W, followed by the backward of modulate() and of the residual mp_sum above it.  Where the shape
-// allows (whole 64-row blocks per sample, 256x256 tiles) both run as ONE launch: the GEMM's epilogue consumes the fp32 accumulators
-// (MAPDIT_EPI_RMB) - the bf16 dxm tensor is neither written nor re-read and the pointwise pass disappears; otherwise the GEMM stores
-// dxm and mapdit_resid_mod_bwd follows.  `a` arrives filled except for dxm.  Ends with the deterministic sum of the gain partials.
+// dX GEMM of a branch, dxm = dy W, followed by the backward of modulate() and of the residual mp_sum above it: the GEMM stores
+// dxm (bf16) and mapdit_resid_mod_bwd follows (row-split at small batches).  Both can also run as ONE launch whose epilogue consumes
+// the accumulators (MAPDIT_EPI_RMB; whole 64-row blocks per sample, 256x256 tiles) - measured, not faster, opt-in (see below).
+// `a` arrives filled except for dxm.  Ends with the deterministic sum of the gain partials.
 // Rotation modulation (rot != nullptr): the dX result is first rotated back in place (mapdit_rotate_bwd: also the angle and gain
 // gradients), then the usual backward runs on it with shift = 0 and gain = 0, its shift / gain gradients going to sinks.
 struct RotBwd {
@@ -407,9 +408,15 @@ struct RotBwd {
 };
 int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy, const bf16_t* wimg, mapdit_resid_mod_bwd_t& a,
                      float* dgain, void* st, const RotBwd* rot = nullptr) {
-    static const bool no_fuse = [] { const char* v = getenv("MAPDIT_NO_FUSED_RMB"); return v && v[0] == '1'; }();
+    // The fused form (MAPDIT_EPI_RMB) is opt-in (MAPDIT_FUSED_RMB=1): with one workgroup per CU the epilogue's ~16 B/element of
+    // residual-stream traffic is serialised with the tile's K loop, while the separate pass streams at 5.3 TB/s; measured on one box,
+    // fused vs separate: 16.97 vs 16.75 ms (64 samples), 28.48 vs 28.17 (128), equal at 256.
+    static const bool no_fuse = [] { const char* v = getenv("MAPDIT_FUSED_RMB"); return !(v && v[0] == '1'); }();
     const int D = e->D;
-    int npart;
+    int npart = 0;
+    a.part_scratch = e->rmb_part;                       // lets small batches take the row-split form (more blocks)
+    a.part_scratch_bytes = (size_t)8 * e->cfg.max_batch * 3 * D * sizeof(float);
+    a.gain_partials_out = &npart;
     if (rot) {
         TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
         TRY(mapdit_rotate_bwd(e->dxm, rot->y, rot->theta, e->ldm, rot->gain, rot->dtheta, e->ldm, e->gain_part, a.n_samples, a.T, D, st));
@@ -418,8 +425,6 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
         TRY(mapdit_resid_mod_bwd(&a, st));              // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
         return MAPDIT_OK;
     }
-    // (fused where the dX result takes the 256^2 kernel and a pointwise pass over it would run on a small grid: measured 1.3 %
-    // of the step at 32 and 64 samples, nothing at 256, where the separate pass streams at 5.3 TB/s)
     if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_ex(M, D, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
@@ -429,8 +434,7 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     } else {
         TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
         a.dxm = e->dxm;
-        TRY(mapdit_resid_mod_bwd(&a, st));
-        npart = a.n_samples * (D / 128);
+        TRY(mapdit_resid_mod_bwd(&a, st));              // sets npart
     }
     return mapdit_reduce_partials(e->gain_part, npart, dgain, 0, st);
 }

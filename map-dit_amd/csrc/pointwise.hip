@@ -49,6 +49,9 @@ struct RmbP {
     float* dx; bf16_t* dx_bf; float* dshift; float* dscale; float* dgain_part; bf16_t* dy_up; float* dg_up;
     int ldmod, ldg_up, ldd, ldd_up;   // row strides of (shift,scale), g_up, dshift/dscale and dg_up
     int T, D; float ca, cb;
+    // gridDim.z > 1: each block handles T / gridDim.z rows and parks its column sums in `part` ([z][sample][3][D]) and its gain
+    // partial in dgain_part[(z * samples + n) * D/128 + column block]; rmb_finish_kernel adds the z slices in order
+    float* part;
 };
 
 __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     if (p.y_up) gu = *(const float4*)(p.g_up + (size_t)n * p.ldg_up + d);
     float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0}, a_g[4] = {0, 0, 0, 0}, a_gain = 0.f;
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, guv[4] = {gu.x, gu.y, gu.z, gu.w};
-    for (int t = rg; t < p.T; t += 8) {
+    const int rows_z = p.T / gridDim.z, t_beg = blockIdx.z * rows_z;
+    for (int t = t_beg + rg; t < t_beg + rows_z; t += 8) {
         const size_t off = ((size_t)n * p.T + t) * p.D + d;
         float dx[4] = {0, 0, 0, 0};
         if (p.dxo) {
@@ -120,16 +124,33 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
             for (int r = 0; r < 8; ++r) a += red[r][cl][j];
             s[j] = a;
         }
+        const bool split = gridDim.z > 1;
+        float* pz = split ? p.part + ((size_t)blockIdx.z * gridDim.x + n) * 3 * p.D : nullptr;
         if (p.dxm) {
-            *(float4*)(p.dscale + (size_t)n * p.ldd + d) = make_float4(s[0], s[1], s[2], s[3]);
-            *(float4*)(p.dshift + (size_t)n * p.ldd + d) = make_float4(s[4], s[5], s[6], s[7]);
+            *(float4*)(split ? pz + d : p.dscale + (size_t)n * p.ldd + d) = make_float4(s[0], s[1], s[2], s[3]);
+            *(float4*)(split ? pz + p.D + d : p.dshift + (size_t)n * p.ldd + d) = make_float4(s[4], s[5], s[6], s[7]);
             float gsum = s[12];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
-            if (cl == 0) p.dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gsum;
+            if (cl == 0) p.dgain_part[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y] = gsum;
         }
-        if (p.y_up) *(float4*)(p.dg_up + (size_t)n * p.ldd_up + d) = make_float4(s[8], s[9], s[10], s[11]);
+        if (p.y_up) *(float4*)(split ? pz + 2 * p.D + d : p.dg_up + (size_t)n * p.ldd_up + d) = make_float4(s[8], s[9], s[10], s[11]);
     }
+}
+
+// Second stage of the row-split form: out[n, d] = sum_z part[z][n][which][d], z in order (deterministic).
+__global__ void rmb_finish_kernel(const float* __restrict__ part, int Z, int N, int D, float* __restrict__ dscale,
+                                  float* __restrict__ dshift, int ldd, float* __restrict__ dg_up, int ldd_up) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i % D;
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int z = 0; z < Z; ++z) {
+        const float* pz = part + ((size_t)z * N + n) * 3 * D + d;
+        a[0] += pz[0]; a[1] += pz[D]; a[2] += pz[2 * D];
+    }
+    if (dscale) { dscale[(size_t)n * ldd + d] = a[0]; dshift[(size_t)n * ldd + d] = a[1]; }
+    if (dg_up) dg_up[(size_t)n * ldd_up + d] = a[2];
 }
 
 // ---- rotation modulation (PARITY UNPINNED: not in the reference snapshot, its README.md:1-3 only; oracle.modulate_rot) ----------
@@ -351,8 +372,24 @@ extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* strea
     p.y_up = a->y_up; p.g_up = a->g_up; p.dx = a->dx; p.dx_bf = a->dx_bf; p.dshift = a->dshift; p.dscale = a->dscale;
     p.dgain_part = a->dgain_part; p.dy_up = a->dy_up; p.dg_up = a->dg_up;
     p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
-    hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128), dim3(256), 0, (hipStream_t)stream, p);
+    // Small batches: one block per (sample, 128 columns) is too few blocks to stream at the HBM rate (32 samples x 6 = 192 blocks:
+    // 60 us for 25 us of traffic).  With scratch given, the rows of a sample are cut into Z pieces (grid z), the column sums
+    // parked per piece and added in order by a second small kernel; the gain partials simply become Z times as many.
+    int Z = 1;
+    if (a->part_scratch) {
+        const int blocks = a->n_samples * (a->D / 128);
+        while (Z < 8 && blocks * Z < 1024 && a->T % (2 * Z * 8) == 0 && (size_t)(2 * Z) * a->n_samples * 3 * a->D * sizeof(float) <= a->part_scratch_bytes)
+            Z *= 2;
+    }
+    p.part = Z > 1 ? a->part_scratch : nullptr;
+    hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
     MD_LAUNCH_CHECK();
+    if (Z > 1) {
+        hipLaunchKernelGGL(rmb_finish_kernel, dim3(cdiv((long)a->n_samples * a->D, 256)), dim3(256), 0, (hipStream_t)stream, p.part, Z,
+                           a->n_samples, a->D, a->dxm ? a->dscale : nullptr, a->dshift, a->ldd, a->y_up ? a->dg_up : nullptr, a->ldd_up);
+        MD_LAUNCH_CHECK();
+    }
+    if (a->gain_partials_out) *a->gain_partials_out = a->n_samples * (a->D / 128) * Z;
     return MAPDIT_OK;
 }
 

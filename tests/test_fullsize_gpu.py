@@ -178,9 +178,9 @@ def test_full_size_step_is_reproducible_and_gradients_add_over_batch_halves(b2):
         e = float((whole - parts).norm() / whole.norm())
         worst = max(worst, e)
         # Conditioning-path weights (timestep MLP, label table, modulation linears) see the per-sample sums dshift / dscale / dgate
-        # after a rounding to bf16.  A batch of 256 and a batch of 128 take different kernels for those sums (separate pointwise
-        # pass vs the dX GEMM's fused epilogue, same arithmetic, different fp32 summation order): a few bf16 roundings flip, and
-        # these strongly cancelling gradients move by up to ~3e-4.  Everything else is per-row work: 2e-4.
+        # after a rounding to bf16.  A batch of 256 and a batch of 128 may sum them in a different order (the pointwise pass cuts a
+        # sample's rows into pieces at small batches; MAPDIT_FUSED_RMB=1 sums them in the dX GEMM's epilogue): a few bf16 roundings
+        # flip, and these strongly cancelling gradients move by up to ~3e-4.  Everything else is per-row work: 2e-4.
         cond_path = k.startswith(("t_embedder.", "y_embedder.")) or ".modulation." in k
         assert e < (1e-3 if cond_path else 2e-4), (k, e)
     print(f"gradient additivity over batch halves: worst relative difference {worst:.2e}")

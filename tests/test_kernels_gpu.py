@@ -332,6 +332,23 @@ def test_modulate_and_fused_backward(L):
     assert rel_err(dmod.cpu().numpy(), mm.grad.numpy()) < 1e-5
     assert rel_err(dmod_up.cpu().numpy(), mu.grad.numpy()) < 1e-5
     assert abs(dgain.item() - gg.grad.item()) < 1e-4 * abs(gg.grad.item()) + 1e-5
+    # the row-split form small batches take (scratch given: a sample's rows are cut into Z pieces, sums added by a second kernel)
+    scratch = torch.full((8 * N * 3 * D,), float("nan"), device=DEV)
+    part8 = torch.full((8 * N * (D // 128),), float("nan"), device=DEV)
+    nparts = C.c_int(0)
+    dmod2, dmod_up2, dx2, dy2 = torch.zeros_like(dmod), torch.zeros_like(dmod_up), torch.zeros_like(dx), torch.zeros_like(dy)
+    a.part_scratch, a.part_scratch_bytes, a.gain_partials_out = p(scratch), scratch.numel() * 4, C.pointer(nparts)
+    a.dgain_part, a.dx, a.dy_up = p(part8), p(dx2), p(dy2)
+    a.dshift, a.dscale = dmod2.data_ptr() + 4 * 3 * D, dmod2.data_ptr() + 4 * 4 * D
+    a.dg_up = dmod_up2.data_ptr() + 4 * 5 * D
+    L.lib().resid_mod_bwd(C.byref(a), st())
+    dgain2 = torch.zeros((), device=DEV)
+    L.lib().reduce_partials(p(part8), nparts.value, p(dgain2), 0, st())
+    torch.cuda.synchronize()
+    assert nparts.value == 8 * N * (D // 128)                 # T = 64 rows -> 8 pieces of 8 rows
+    assert torch.equal(dx2, dx) and torch.equal(dy2, dy)      # per-element work does not depend on the split
+    assert rel_err(dmod2.cpu().numpy(), mm.grad.numpy()) < 1e-5 and rel_err(dmod_up2.cpu().numpy(), mu.grad.numpy()) < 1e-5
+    assert abs(dgain2.item() - gg.grad.item()) < 1e-4 * abs(gg.grad.item()) + 1e-5
 
 
 @pytest.mark.parametrize("N,T,D,K,layout,with_up,with_dxo", [(2, 256, 256, 128, 1, True, True), (8, 64, 512, 192, 1, True, True),

@@ -5,6 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r02_final
 mkdir -p $out
+sha256sum map-dit_amd/csrc/gemm.hip > $out/gemm_hip.sha256
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "bench default done: $(tail -c 300 $out/bench_default.json | head -c 200)"
 for b in 128 64 32; do python bench.py --steps 30 --warmup 5 --batch-per-gpu $b --no-cpu-baseline --no-parity > $out/bench_b$b.json 2>/dev/null; done
