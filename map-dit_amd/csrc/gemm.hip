@@ -627,6 +627,11 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 // slots 5 / 6 = the 100 MHz s_memrealtime at K loop start / end: (stamp 2 - stamp 1) / (slot 6 - slot 5) x 100 MHz is the clock the
 // K loop ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
 #define G256_TSTAMP(IDX)                                                                            \
+    if (wave == 0 && (IDX) < 3) {                       /* per-workgroup record: K loop begin / end, in registers */ \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        kl_[(IDX) % 3] = (long long)__builtin_readcyclecounter();                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                               \
     if (stamp_on && wave == 0) {                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         stamp_lds[2 * STAMP_TILES * STAMP_POINTS + (IDX)] = (long long)__builtin_readcyclecounter(); \
@@ -644,8 +649,12 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
     if (g_wg_times && wave == 0 && lane == 0) {                                                     \
         long long* r_ = g_wg_times + 4 * (long long)blockIdx.x;                                     \
         r_[0] = wg_r0; r_[1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
-        r_[2] = (long long)__builtin_readcyclecounter() - wg_t0;                                    \
-        r_[3] = (long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);              \
+        const long long now_ = (long long)__builtin_readcyclecounter();                             \
+        r_[2] = now_ - wg_t0;                                                                       \
+        /* XCC id | K-loop cycles << 8 | fill cycles << 32 | epilogue cycles << 48 */               \
+        r_[3] = ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xff) |    \
+                (((kl_[2] - kl_[1]) & 0xffffff) << 8) | (((kl_[1] - wg_t0) & 0xffff) << 32) |       \
+                (((now_ - kl_[2]) & 0xffff) << 48);                                                 \
     }                                                                                               \
     if (stamp_on) {                                                                                 \
         for (int i = 0; i < STAMP_TILES * STAMP_POINTS; ++i)                                        \
@@ -717,6 +726,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     long long* stamp_lds = PH != 2 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
     const long long wg_t0 = (long long)__builtin_readcyclecounter();
     const long long wg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long kl_[3] = {0, 0, 0};
 #else
     __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
 #endif

@@ -78,4 +78,6 @@ for name, layout, m, n, k, a, lda, b, ldb, split in cases:
             dur = (r[:, 1] - r[:, 0]).float() / 100.0
             if rnd_ == 1:
                 print(f"   {names[ab]:28s} {ms * 1e3:7.1f} us  {2.0 * m * n * k / ms / 1e9:7.0f} TFLOP/s   cycles per workgroup {cyc.mean():8.0f}"
-                      f"   clock {cyc.mean() / dur.mean() / 1e3:.2f} GHz")
+                      f"   clock {cyc.mean() / dur.mean() / 1e3:.2f} GHz   fill {((r[:, 3] >> 32) & 0xffff).float().mean():6.0f}"
+                      f"  K loop {((r[:, 3] >> 8) & 0xffffff).float().mean():7.0f} ({k // (split or 1) // 64} K-tiles)"
+                      f"  epilogue {((r[:, 3] >> 48) & 0xffff).float().mean():6.0f}")

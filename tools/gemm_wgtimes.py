@@ -44,7 +44,7 @@ def run(name, layout, m, n, k, a, lda, b, ldb, phases):
     ms = ev0.elapsed_time(ev1) / 20
     nwg = ((m + 255) // 256) * ((n + 255) // 256)
     r = rec.cpu()[:nwg * 4].view(nwg, 4)
-    t0, t1, cyc, xcc = r[:, 0], r[:, 1], r[:, 2].float(), r[:, 3]
+    t0, t1, cyc, xcc = r[:, 0], r[:, 1], r[:, 2].float(), r[:, 3] & 0xff
     span = (t1.max() - t0.min()).item() / 100.0          # us (100 MHz)
     dur = (t1 - t0).float() / 100.0
     order = torch.argsort(t0)
