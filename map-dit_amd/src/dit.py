@@ -276,7 +276,7 @@ class DiT(nn.Module):
 
     def __init__(self, depth: int, hidden_size: int, patch_size: int, input_size: int = 32, in_channels: int = 3,
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
-                 learn_sigma: bool = True, rotation_modulation: bool = False):
+                 learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -292,6 +292,10 @@ class DiT(nn.Module):
         self.class_dropout_prob = class_dropout_prob
         self.num_classes = num_classes
         self.rotation_modulation = bool(rotation_modulation)      # README.md:1-3; not in the snapshot: parity unpinned
+        # README.md:61 --use-forced-weight-normalization.  Off = the training forward skips the in-place rewrite of the weights
+        # (mp_linear.py:38-40, 68-70, mp_embedding.py:17-19) and keeps everything else: the one flag whose off-path can be read
+        # off the snapshot's code; the other seven name layers the snapshot does not contain.
+        self.forced_weight_normalization = bool(forced_weight_normalization)
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
@@ -458,7 +462,8 @@ class DiT(nn.Module):
         rt = self._runtime(x.shape[0], train=need_grad)
         with torch.cuda.device(x.device):
             if self.training:
-                rt.lib.engine_prepare_weights(rt.handle, 1, L.cur_stream())    # forced weight norm: rewrites weights
+                # forced weight norm (1): rewrites the fp32 weights in place, then images them
+                rt.lib.engine_prepare_weights(rt.handle, 1 if self.forced_weight_normalization else 0, L.cur_stream())
                 rt.weights_key = None
                 for other in self._rt.values():
                     other.weights_key = None
@@ -499,7 +504,7 @@ class DiT(nn.Module):
         new = DiT(depth=self.depth, hidden_size=self.hidden_size, patch_size=self.patch_size, input_size=self.input_size,
                   in_channels=self.in_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
                   class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
-                  rotation_modulation=self.rotation_modulation)
+                  rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

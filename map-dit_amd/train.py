@@ -33,6 +33,8 @@ def get_model(args):
     """reference utils.py:9-17."""
     a = vars(args) if isinstance(args, argparse.Namespace) else args
     kw = dict(rotation_modulation=True) if a.get("use_rotation_modulation") else {}
+    if not a.get("use_forced_weight_normalization", True):
+        kw["forced_weight_normalization"] = False
     return DIT_MODELS[a["model"]](in_channels=a["in_channels"], input_size=a["input_size"], num_classes=a["num_classes"], **kw)
 
 
@@ -101,7 +103,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    off = [f for f in MP_FLAGS if not getattr(args, "use_" + f.replace("-", "_"))]
+    # --no-use-forced-weight-normalization is the one off-path the snapshot's code defines (skip the in-place rewrite)
+    off = [f for f in MP_FLAGS if not getattr(args, "use_" + f.replace("-", "_")) and f != "forced-weight-normalization"]
     if off:
         raise NotImplementedError(f"--no-use-{off[0]}: the reference snapshot hard-wires every magnitude-preserving "
                                   "feature on (SURVEY F5) and so does this engine")

@@ -537,3 +537,58 @@ def test_torch_compile_wrapper_runs():
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     cm(x, t, y).sum().backward()
     assert m.blocks[0].mlp.net[0].weight.grad is not None
+
+
+@pytest.mark.parametrize("precision,ltol,gtol", [("bf16", LOGIT_TOL, GRAD_TOL), ("bf16x3", 1e-4, 2e-4)])
+def test_forced_weight_normalization_off(precision, ltol, gtol):
+    """README.md:61 `--no-use-forced-weight-normalization`: the training forward leaves the fp32 weights alone (the in-place
+    rewrite of mp_linear.py:38-40 is the only thing the flag removes) - i.e. the snapshot's eval-mode arithmetic on weights of
+    any norm, with training-mode label drop.  Outputs equal the eval forward bit for bit, weights are unchanged, and the
+    gradients are those of the oracle's autograd through the same arithmetic (weight-norm Jacobian at |w| != 1)."""
+    import oracle.dit_oracle as O
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.dit import DiT
+    from oracle.diffusion_oracle import DiffusionOracle
+    g = load_golden("tiny_a")
+    cfg = golden_cfg(g)
+    sd = golden_state_dict(g, cfg)
+    m = DiT(**cfg.to_dict(), forced_weight_normalization=False)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    m.gemm_precision = precision
+    x, t, y_eff, noise = dev(g, "x", "t", "y_eff", "noise")
+    m.eval()
+    with torch.no_grad():
+        ref_out = m(x, t, y_eff)
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels      # golden labels already carry the drop
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    losses = create_diffusion(timestep_respacing="").training_losses(m, x, t, dict(y=y_eff), noise=noise)
+    losses["loss"].mean().backward()
+    torch.cuda.synchronize()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), f"{k} was rewritten although forced weight normalisation is off"
+    with torch.no_grad():
+        assert torch.equal(m(x, t, y_eff), ref_out)                           # training forward == eval arithmetic
+    osd = {k: v.clone().requires_grad_(k not in O.BUFFER_KEYS) for k, v in sd.items()}
+    xc, tc, yc, nc = (torch.from_numpy(g[k]) for k in ("x", "t", "y_eff", "noise"))
+    ref = DiffusionOracle("").training_losses(lambda xx, tt, **kw: O.dit_forward(osd, cfg, xx, tt, kw["y"], train=False),
+                                              xc, tc, dict(y=yc), noise=nc)
+    ref["loss"].mean().backward()
+    assert rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy()) < ltol
+    gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if osd[k].dim() == 0 and osd[k].grad is not None)
+    for k, p in m.named_parameters():
+        gref = osd[k].grad
+        if p.dim() == 0:
+            assert abs(float(p.grad) - float(gref)) < (0.05 if precision == "bf16" else 1e-3) * gain_scale + 1e-7, k
+            continue
+        e = rel_err(p.grad.cpu().numpy(), gref.numpy())
+        assert e < (gtol if gref.numel() >= 64 else 10 * gtol) or float(gref.norm()) < 1e-7, (k, e)
+    # the harness accepts exactly this flag's off form, the seven others still refuse
+    from mapdit_amd import train
+    args = train.build_parser().parse_args(["--synthetic", "--results-dir", "unused", "--no-use-forced-weight-normalization",
+                                            "--model", "DiT-XS/8", "--num-classes", "10"])
+    args.in_channels, args.input_size = 4, 32
+    assert train.get_model(args).forced_weight_normalization is False
+    with pytest.raises(NotImplementedError):
+        train.main(["--synthetic", "--results-dir", "unused", "--no-use-mp-silu"])
