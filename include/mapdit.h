@@ -116,6 +116,7 @@ typedef struct {
     int first_block;
     uint16_t* w_bf16; /* may be NULL */
     float* w_f32;     /* may be NULL */
+    uint16_t* w_split3; /* may be NULL: [rows][3 cols] two-term bf16 split [hi | lo | hi] of the effective weight (fp32-accurate GEMMs) */
 } mapdit_wn_job_t;
 int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream);
 /* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)).  G rows have stride ldg; G may be

@@ -36,7 +36,8 @@ class ResidModBwd(C.Structure):
 
 
 class WnJob(C.Structure):          # mapdit_wn_job_t
-    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp)]
+    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp),
+                ("w_split3", vp)]
 
 
 class AdamScalars(C.Structure):    # mapdit_adam_scalars_t

@@ -581,15 +581,18 @@ extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host,
     e->wn_jobs.clear();
     e->wn_blocks = 0;
     e->wn_table_ready = false;
-    auto job = [&](float* W, int rows, int cols, float out_scale, bf16_t* wb, float* wf) {
+    auto job = [&](float* W, int rows, int cols, float out_scale, bf16_t* wb, float* wf, bf16_t* w3 = nullptr) {
         mapdit_wn_job_t j;
         j.W = W; j.rows = rows; j.cols = cols; j.out_scale = out_scale; j.first_block = e->wn_blocks; j.w_bf16 = wb; j.w_f32 = wf;
+        j.w_split3 = w3;
         e->wn_jobs.push_back(j);
         e->wn_blocks += (rows + 3) / 4;
     };
     if (e->cfg.precision == MAPDIT_PREC_BF16) {
         for (size_t i = 0; i < e->wimg.size(); ++i)
-            if (e->wimg[i].img) job(e->params[i], e->wimg[i].rows, e->wimg[i].cols, 1.f, e->wimg[i].img, nullptr);
+            if (e->wimg[i].img)                 // (+ the split image of a conditioning weight: fp32-accurate conditioning forward)
+                job(e->params[i], e->wimg[i].rows, e->wimg[i].cols, 1.f, e->wimg[i].img, nullptr,
+                    i < e->cp.img3.size() ? e->cp.img3[i] : nullptr);
         job(e->params[MAPDIT_P_X_EMB], e->D, e->P1, 1.f, nullptr, e->wx_eff);
         job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff);
     }
@@ -607,14 +610,7 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
             e->wn_table_ready = true;
         }
         TRY(mapdit_weightnorm_fwd_batch(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st));
-        // split images of the conditioning weights for the fp32-accurate conditioning forward; the batch pass above has already
-        // applied the forced normalisation to the masters (forced = 0 here: the effective weight of the stored W)
-        for (size_t i = 0; i < e->cp.img3.size(); ++i) {
-            if (!e->cp.img3[i]) continue;
-            const WeightImg& w = e->wimg[i];
-            TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, 0, 1.f, nullptr, e->cp.wtmp, nullptr, st));
-            TRY(mapdit_split3(e->cp.wtmp, w.cols, e->cp.img3[i], w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
-        }
+        // (the same launch writes the split images of the conditioning weights, cp.img3, for the fp32-accurate conditioning forward)
         return MAPDIT_OK;
     }
     for (size_t i = 0; i < e->wimg.size(); ++i) {

@@ -8,8 +8,11 @@ namespace {
 // One wave per row.  Pass 1: sum of squares.  Pass 2 (row is L1/L2-hot): rewrite the master weight
 // (forced weight norm, reference mp_linear.py:38-40 / mp_embedding.py:17-19) and emit the effective
 // weight  w = out_scale * Wn / (|Wn| + eps)  (mp_linear.py:44: normalize(W)/sqrt(in) == W/(|W|+eps)).
+// w3 (may be NULL): the effective row as a two-term bf16 split laid out along the reduction index, [hi | lo | hi] with row stride
+// 3 cols - the B operand of the fp32-accurate GEMMs (precise.hip, MAPDIT_SPLIT_B): x = hi + lo to ~2^-17.
 __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int row, int rows, int cols, int forced, float out_scale,
-                                                   bf16_t* __restrict__ wb, float* __restrict__ wf, float* __restrict__ inv) {
+                                                   bf16_t* __restrict__ wb, float* __restrict__ wf, float* __restrict__ inv,
+                                                   bf16_t* __restrict__ w3 = nullptr) {
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     float* w = W + (size_t)row * cols;
@@ -45,6 +48,18 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
                 u.y = pack2bf(o.z, o.w);
                 *(uint2*)(wb + (size_t)row * cols + c) = u;
             }
+            if (w3) {
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                bf16_t hi[4], lo[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hi[k] = f2bf(ov[k]); lo[k] = f2bf(ov[k] - bf2f(hi[k])); }
+                bf16_t* d = w3 + (size_t)row * 3 * cols + c;
+                const uint2 uh = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+                const uint2 ul = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+                *(uint2*)(d) = uh;
+                *(uint2*)(d + cols) = ul;
+                *(uint2*)(d + 2 * cols) = uh;
+            }
         }
     } else {
         for (int c = lane; c < cols; c += 64) {
@@ -52,6 +67,11 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
             if (forced) w[c] = v * f;
             if (wf) wf[(size_t)row * cols + c] = v * e;
             if (wb) wb[(size_t)row * cols + c] = f2bf(v * e);
+            if (w3) {
+                const bf16_t hi = f2bf(v * e), lo = f2bf(v * e - bf2f(hi));
+                bf16_t* d = w3 + (size_t)row * 3 * cols + c;
+                d[0] = hi; d[cols] = lo; d[2 * cols] = hi;
+            }
         }
     }
 }
@@ -73,8 +93,18 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_batch_kernel(const mapdit_
     }
     const mapdit_wn_job_t j = jobs[lo];
     weightnorm_fwd_row(j.W, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, forced, j.out_scale, j.w_bf16, j.w_f32,
-                       nullptr);
+                       nullptr, j.w_split3);
 }
+
+#ifdef MAPDIT_WN_DEBUG
+// (tools/dw_stress.py builds this variant: the row's reduced scalars and every lane's partial dot product, for bisecting)
+__device__ float* g_wn_dbg = nullptr;       // [rows][4 + 64 + 64]: ss, gw, a1, a2, the 64 per-lane partials of gw, those of ss
+extern "C" __global__ void mapdit_wn_dbg_set_kernel(float* p) { g_wn_dbg = p; }
+extern "C" void mapdit_wn_dbg_set(float* p) {
+    hipLaunchKernelGGL(mapdit_wn_dbg_set_kernel, dim3(1), dim3(1), 0, 0, p);
+    (void)hipDeviceSynchronize();
+}
+#endif
 
 // Backward of w = out_scale * W / (n + eps), n = |W|:  dW = out_scale * (G/(n+eps) - W (G.W) / (n (n+eps)^2)).
 // G may arrive as `nslabs` split-K partial sums: pass 1 adds them in slab order (deterministic) and, when there is
@@ -112,11 +142,17 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
             gw += a * b;
         }
     }
+#ifdef MAPDIT_WN_DEBUG
+    if (g_wn_dbg) { g_wn_dbg[(size_t)row * 132 + 4 + lane] = gw; g_wn_dbg[(size_t)row * 132 + 68 + lane] = ss; }
+#endif
     ss = wave_sum(ss);
     gw = wave_sum(gw);
     const float n = sqrtf(ss);
     const float a1 = out_scale / (n + NORM_EPS);
     const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
+#ifdef MAPDIT_WN_DEBUG
+    if (g_wn_dbg && lane == 0) { float* q = g_wn_dbg + (size_t)row * 132; q[0] = ss; q[1] = gw; q[2] = a1; q[3] = a2; }
+#endif
     if (VEC) {
         for (int c = lane * 4; c < cols; c += 256) {      // each lane re-reads exactly the columns it wrote above
             const float4 b = *(const float4*)(g + c), a = *(const float4*)(w + c);

@@ -59,8 +59,9 @@ def _world(group):
 def _host_staged(group, t) -> bool:
     """gloo with device tensors (the one-GPU rehearsals of the N > 1 path, MAPDIT_DIST_BACKEND=gloo): the collective is run on a
     host copy, synchronously - RCCL collectives are ordered on the compute stream and asynchronous, gloo's own CUDA staging (pool
-    streams, pinned buffers, worker threads) is not something the rehearsal should depend on (it produced stale 1-KiB pieces of the
-    reduced buffer now and then on this stack)."""
+    streams, pinned buffers, worker threads) is not something the rehearsal should depend on.  (The run-to-run differences once
+    blamed on it were a compiler matter: SLP-packed fp32 math going wrong in lanes 48-63 while two processes share a GPU, see
+    csrc/Makefile.)"""
     return t.is_cuda and _world(group) > 1 and dist.get_backend(group) == "gloo"
 
 

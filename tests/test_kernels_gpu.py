@@ -251,6 +251,20 @@ def test_weightnorm_batch_equals_single_launches(L):
             (singles if which == "single" else batch).extend([w.cpu() for w in Ws] + [o.cpu() for o in outs])
         for a, b in zip(singles, batch):
             assert torch.equal(a, b)
+    # the optional two-term split image [hi | lo | hi] of the effective weight (conditioning weights of the bf16 engine):
+    # hi = the bf16 image, hi + lo = the fp32 effective weight to 2^-16 relative, for a vector-width and a ragged column count
+    for r, c in ((96, 256), (10, 257)):
+        W = torch.randn(r, c, generator=g).to(DEV)
+        wb = torch.zeros(r, c, device=DEV, dtype=torch.bfloat16)
+        wf = torch.zeros(r, c, device=DEV)
+        w3 = torch.zeros(r, 3 * c, device=DEV, dtype=torch.bfloat16)
+        jobs = (L.WnJob * 1)()
+        jobs[0] = L.WnJob(W=p(W), rows=r, cols=c, out_scale=1.0, first_block=0, w_bf16=p(wb), w_f32=p(wf), w_split3=p(w3))
+        raw = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(DEV)
+        L.lib().weightnorm_fwd_batch(p(raw), 1, (r + 3) // 4, 1, st())
+        torch.cuda.synchronize()
+        assert torch.equal(w3[:, :c], wb) and torch.equal(w3[:, 2 * c:], wb)
+        assert float(((w3[:, :c].float() + w3[:, c:2 * c].float()) - wf).abs().max()) <= float(wf.abs().max()) * 2.0 ** -16
 
 
 def test_adam_ema(L):
