@@ -93,6 +93,9 @@ int mapdit_gemm_tile_size(int M, int N);
 /* The same for a launch that will cut K (split_k > 1): such launches fill the chip through the cut, so the 256 edge is kept
  * for all but the smallest outputs. */
 int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch);
+/* The same with the reduction length known (what mapdit_gemm_bf16 itself uses): a split-K launch that leaves a workgroup fewer than
+ * ~50 K-tiles takes the 128 edge.  Size split_k with this one when K is at hand. */
+int mapdit_gemm_tile_size_k(int M, int N, int K, int split_k_launch);
 /* Benchmarking hook: force the tile edge (0 = by shape, 128, 256), the K-loop schedule (2 | 4 phases per K-tile) and the
  * band width of the tile order (0 = derived from K).  The environment (MAPDIT_GEMM_TILE / _PHASES / _BAND) is read once, at the
  * first launch; this overrides it afterwards. */

@@ -123,6 +123,7 @@ _OTHER = {
     "mapdit_abi_version": (ci, []),
     "mapdit_gemm_tile_size": (ci, [ci, ci]),
     "mapdit_gemm_tile_size_ex": (ci, [ci, ci, ci]),
+    "mapdit_gemm_tile_size_k": (ci, [ci, ci, ci, ci]),
     "mapdit_gemm_tuning": (None, [ci, ci, cl]),
     "mapdit_engine_workspace_bytes": (C.c_size_t, [C.POINTER(Config), ci]),
     "mapdit_engine_destroy": (None, [vp]),

@@ -383,7 +383,7 @@ mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const floa
 // Largest divisor s of K/64 with tiles*s <= ~1024 blocks (4 per CU) and s <= max_slabs.
 int pick_split_k(int rows, int cols, int K, long max_slabs) {
     if (K % 64 != 0 || rows % 8 != 0 || cols % 8 != 0) return 1;       // not on the MFMA path
-    const int edge = mapdit_gemm_tile_size_ex(rows, cols, 1);
+    const int edge = mapdit_gemm_tile_size_k(rows, cols, K, 1);
     const int tiles = cdiv(rows, edge) * cdiv(cols, edge);
     const int units = K / 64;
     // One full round of the chip (256 CUs x 1 workgroup of the 256^2 kernel, x 2 of the 128^2 kernel): every block
@@ -425,7 +425,7 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
         TRY(mapdit_resid_mod_bwd(&a, st));              // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
         return MAPDIT_OK;
     }
-    if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_ex(M, D, 0) == 256) {
+    if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
         a.dxm = nullptr;

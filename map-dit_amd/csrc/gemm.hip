@@ -1344,7 +1344,9 @@ struct GemmEnv {
     int tile = 0;        // MAPDIT_GEMM_TILE   = 128 | 256: force the tile edge
     int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
+    int old_tile_rule = 0;   // MAPDIT_GEMM_TILE_RULE=old
     GemmEnv() {
+        if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
@@ -1365,16 +1367,32 @@ extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
 
 // 256 (8 waves, one workgroup per CU) for results that give most of the chip a tile, 128 (4 waves, two per CU) otherwise:
 //  * plain launches: fewer than 128 tiles of 256^2 leave more than half the CUs idle (e.g. [8192, 768] = 96 tiles at a per-GPU
-//    batch of 32), while the 128^2 kernel has 4x the tiles for 2x the slots;
-//  * split-K launches fill the chip through the K cut either way: there the 128^2 kernel wins only for the smallest outputs
-//    ([768, 768]: 781 vs 704 TFLOP/s; [3072, 768]: 694 vs 812).
-extern "C" int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch) {
+//    batch of 32), while the 128^2 kernel has 4x the tiles for 2x the slots; likewise a launch of little more than one round of the
+//    chip (257 ... 320 tiles: the second round runs at most a quarter full - [8192, 2304] = 288 tiles: 46 vs 59 us);
+//  * split-K launches fill one round through the K cut either way: there the 128^2 kernel wins for the smallest outputs
+//    ([768, 768]: 781 vs 704 TFLOP/s; [3072, 768]: 694 vs 812) and when the cut leaves a workgroup fewer than 24 K-tiles against
+//    the 256^2 tile's fixed cost of ~8 K-tiles (fill + fp32 epilogue; [3072, 768] over 8,192 rows: 52 vs 63 us).
+// A finer occupancy model (useful tile area x last-round occupancy x a per-flop rate of the 128^2 kernel) fitted the isolated
+// launches of tools/gemm_bench.py and LOST in the step at 64 and 128 samples and on DiT-XL/2 (+0.1 ... +0.3 ms): not used.
+// K = 0: reduction length not known (the older entry points).
+extern "C" int mapdit_gemm_tile_size_k(int M, int N, int K, int split_k_launch) {
     const int force = gemm_env().tile;
     if (force == 128 || force == 256) return force;
     if (!(M >= 512 && N >= 256)) return 128;
-    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
-    return tiles < (split_k_launch ? 12 : 128) ? 128 : 256;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    if (split_k_launch) {
+        if (t256 < 12) return 128;
+        if (K > 0 && !gemm_env().old_tile_rule) {
+            const long slabs = 256 / t256 > 0 ? 256 / t256 : 1;
+            if ((K / 64) / slabs < 24) return 128;
+        }
+        return 256;
+    }
+    if (t256 < 128) return 128;
+    if (!gemm_env().old_tile_rule && t256 > 256 && t256 <= 320) return 128;
+    return 256;
 }
+extern "C" int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch) { return mapdit_gemm_tile_size_k(M, N, 0, split_k_launch); }
 extern "C" int mapdit_gemm_tile_size(int M, int N) { return mapdit_gemm_tile_size_ex(M, N, 0); }
 
 namespace {
@@ -1396,7 +1414,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     if (!b_kmaj && ldb % 8 != 0) mfma = false;
     if (((uintptr_t)A | (uintptr_t)B) & 15) mfma = false;
     if constexpr (kReduce<Epi>) {      // per-tile reductions exist in the 256^2 kernel only
-        if (!mfma || ktail || mapdit_gemm_tile_size_ex(M, N, 0) != 256) {
+        if (!mfma || ktail || mapdit_gemm_tile_size_k(M, N, K, 0) != 256) {
             mapdit_set_error("gemm: this epilogue needs the 256x256 MFMA path (M=%d N=%d K=%d: K %% 64 == 0, M >= 512, N >= 256, aligned operands)", M, N, K);
             return MAPDIT_ERR_ARG;
         }
@@ -1405,7 +1423,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= ceil(K/64) (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
-    if (mfma && mapdit_gemm_tile_size_ex(M, N, split_k > 1) == 256) {
+    if (mfma && mapdit_gemm_tile_size_k(M, N, K, split_k > 1) == 256) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
         p.phases = gemm_env().phases;
