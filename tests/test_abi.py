@@ -74,3 +74,18 @@ def test_build_is_decided_by_source_digest_not_file_times(monkeypatch):
     open(stamp, "w").write("stale\n")
     L.build()
     assert len(calls) == 1 and open(stamp).read().strip() == L._source_digest()
+
+
+def test_gemm_tile_edge_rule():
+    """mapdit_gemm_tile_size_k (host logic, no GPU): the documented decisions of the dispatcher on the DiT-B/2 shapes."""
+    import mapdit_amd
+    lib = mapdit_amd._lib.lib()
+    t = lib.gemm_tile_size_k
+    assert t(65536, 3072, 768, 0) == 256 and t(65536, 768, 3072, 0) == 256        # 256 samples: whole rounds of the chip
+    assert t(8192, 768, 3072, 0) == 128                                            # 96 tiles of 256^2: under half a round
+    assert t(8192, 2304, 768, 0) == 128                                            # 288 tiles: 1.125 rounds
+    assert t(8192, 3072, 768, 0) == 256 and t(16384, 2304, 768, 0) == 256          # 1.5 and 2.25 rounds stay
+    assert t(16, 768, 768, 0) == 128 and t(65536, 16, 768, 0) == 128               # conditioning path, final linear
+    assert t(768, 768, 65536, 1) == 128                                            # split-K, smallest output
+    assert t(3072, 768, 65536, 1) == 256 and t(3072, 768, 8192, 1) == 128          # 146 vs 18 K-tiles per workgroup
+    assert lib.gemm_tile_size_ex(3072, 768, 1) == 256 and lib.gemm_tile_size(8192, 768) == 128   # older entry points (K unknown)
