@@ -19,7 +19,8 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
     float ss = 0.f;
     const bool vec = (cols & 3) == 0;
     if (vec) {
-        for (int c = lane * 4; c < cols; c += 256) {
+#pragma unroll 3
+        for (int c = lane * 4; c < cols; c += 256) {       // (several row chunks in flight: one wave owns the row)
             float4 v = *(const float4*)(w + c);
             ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
@@ -37,6 +38,7 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
     const float e = f * s * out_scale;   // w_eff = W_old * f * s * out_scale
     if (inv && lane == 0) inv[row] = s;
     if (vec) {
+#pragma unroll 3
         for (int c = lane * 4; c < cols; c += 256) {
             float4 v = *(const float4*)(w + c);
             if (forced) *(float4*)(w + c) = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
@@ -121,9 +123,27 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     float* d = dW + (size_t)row * cols;
     float ss = 0.f, gw = 0.f;
     if (VEC) {
+#pragma unroll 3
         for (int c = lane * 4; c < cols; c += 256) {
             float4 b = *(const float4*)(g + c);
-            for (int s = 1; s < nslabs; ++s) {
+            // the slabs are added in slab order (deterministic), but up to six loads are in flight at a time: one wave owns a row, a CU
+            // holds ~12 such waves, and a load-wait-add chain per slab left the kernel latency-bound (61 % of the HBM rate)
+            int s = 1;
+            for (; s + 5 < nslabs; s += 6) {
+                const float* gs = g + (size_t)s * slab_stride + c;
+                float4 t[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t[k] = *(const float4*)(gs + (size_t)k * slab_stride);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { b.x += t[k].x; b.y += t[k].y; b.z += t[k].z; b.w += t[k].w; }
+            }
+            for (; s + 1 < nslabs; s += 2) {
+                const float* gs = g + (size_t)s * slab_stride + c;
+                const float4 t0 = *(const float4*)(gs), t1 = *(const float4*)(gs + slab_stride);
+                b.x += t0.x; b.y += t0.y; b.z += t0.z; b.w += t0.w;
+                b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+            }
+            for (; s < nslabs; ++s) {
                 const float4 t = *(const float4*)(g + (size_t)s * slab_stride + c);
                 b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
             }
@@ -154,6 +174,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     if (g_wn_dbg && lane == 0) { float* q = g_wn_dbg + (size_t)row * 132; q[0] = ss; q[1] = gw; q[2] = a1; q[3] = a2; }
 #endif
     if (VEC) {
+#pragma unroll 3
         for (int c = lane * 4; c < cols; c += 256) {      // each lane re-reads exactly the columns it wrote above
             const float4 b = *(const float4*)(g + c), a = *(const float4*)(w + c);
             float4 r = make_float4(a1 * b.x - a2 * a.x, a1 * b.y - a2 * a.y, a1 * b.z - a2 * a.z, a1 * b.w - a2 * a.w);
