@@ -647,7 +647,7 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 // workgroup with them, and made the loop look that much longer)
 #define G256_STAMPS_OUT()                                                                           \
     if (g_wg_times && wave == 0 && lane == 0) {                                                     \
-        long long* r_ = g_wg_times + 4 * (long long)blockIdx.x;                                     \
+        long long* r_ = g_wg_times + 4 * (long long)bid;                                     \
         r_[0] = wg_r0; r_[1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
         const long long now_ = (long long)__builtin_readcyclecounter();                             \
         r_[2] = now_ - wg_t0;                                                                       \
@@ -716,29 +716,26 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
     __builtin_amdgcn_s_barrier();                         \
     __builtin_amdgcn_sched_barrier(0)
 
-template <int AK, int BK, class Epi, bool KTAIL = false, int PH = 2>
-__global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
+// One output tile (virtual workgroup `bid` of `nwg` in the band-major tile order).  The kernel below calls it once per tile of its
+// workgroup.
+template <int AK, int BK, class Epi, bool KTAIL, int PH>
+__device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, char* smem, const int bid, const int nwg) {
 #ifdef MAPDIT_GEMM_STAMPS
-    // (the one-phase loop uses all 160 KiB of LDS: its stamps go straight to the global buffer - the stamping waves then carry a
-    // few extra stores in their vmcnt queues, which the instrumented timeline has to live with)
-    constexpr int SM = PH != 2 ? SMEM_PH1 : SMEM2_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM + (PH != 2 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
     long long* stamp_lds = PH != 2 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
     const long long wg_t0 = (long long)__builtin_readcyclecounter();
     const long long wg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
     long long kl_[3] = {0, 0, 0};
-#else
-    __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
 #endif
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                         // per tile: nothing derived from the thread index is kept across tiles
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;               // wm doubles as the stagger group (waves 4-7 run behind)
 #ifdef MAPDIT_GEMM_STAMPS
-    const bool stamp_on = g_stamps && blockIdx.x == (g_stamp_block >= 0 ? g_stamp_block : 8) && (wave == 0 || wave == 4) && lane == 0;
+    const bool stamp_on = g_stamps && bid == (g_stamp_block >= 0 ? g_stamp_block : 8) && (wave == 0 || wave == 4) && lane == 0;
 #endif
     G256_TSTAMP(0);
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int z = wg / p.tiles, tile = wg - z * p.tiles;
@@ -1302,6 +1299,27 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }   // !kReduce
 }
 
+// Persistent form: the grid is at most one workgroup per CU; workgroup b takes the virtual workgroups b, b + grid, ... (b & 7 is its
+// XCD either way, so the band-major order keeps its meaning).  What it saves is the hand-over between two workgroups on a CU: the
+// dispatch of the next one waits for the previous one's stores to drain and its LDS to be released (3-7 k cycles per tile of
+// ~50 k); inside one workgroup the next tile's prologue starts behind the last store's issue.
+template <int AK, int BK, class Epi, bool KTAIL = false, int PH = 2>
+__global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
+#ifdef MAPDIT_GEMM_STAMPS
+    // (the one-phase loop uses all 160 KiB of LDS: its stamps go straight to the global buffer - the stamping waves then carry a
+    // few extra stores in their vmcnt queues, which the instrumented timeline has to live with)
+    constexpr int SM = PH != 2 ? SMEM_PH1 : SMEM2_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM + (PH != 2 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
+#else
+    __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
+#endif
+    const int total = p.tiles * p.split_k;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        gemm256_tile<AK, BK, Epi, KTAIL, PH>(p, epi, smem, v, total);
+        __syncthreads();                                   // the tile's last LDS reads are done before the next prologue lands
+    }
+}
+
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
 // One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
 template <class Epi>
@@ -1345,7 +1363,9 @@ struct GemmEnv {
     int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
     int old_tile_rule = 0;   // MAPDIT_GEMM_TILE_RULE=old
+    int persist = 256;       // MAPDIT_GEMM_PERSIST = workgroups of the persistent 256^2 launch (0: one workgroup per tile)
     GemmEnv() {
+        if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : 2;
@@ -1435,7 +1455,10 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         if (!be && band < 4) band = p.tiles_n;
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
-        const int grid = p.tiles * split_k;
+        int grid = p.tiles * split_k;
+        // one workgroup per CU looping over its tiles, from three rounds of the chip on (fewer: a static split of 1.5 rounds over
+        // 256 workgroups only loses to the dispatcher: +0.05 ms on the step at 32 samples per GPU)
+        if (gemm_env().persist && grid >= 3 * gemm_env().persist) grid = gemm_env().persist;
         auto go = [&](auto tail, auto ph) {
             constexpr bool TAIL = decltype(tail)::value;
             constexpr int PH = decltype(ph)::value;
