@@ -469,14 +469,27 @@ template <> constexpr bool kReduce<EpiRmb> = true;
 // xor-shuffles.  (which, head) are uniform over those 8 lanes; the row's predicate too.
 struct EpiQkvHeads {
     bf16_t *qn, *kn, *v; float* s; int T, H;          // D = 64 H
-    EPI_TRIVIAL_STEPS
-    __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
+    long rows_total;                                    // samples * H * T = rows of the head-major tensors
+    int tshift;                                         // log2 T when T is a power of two (every DiT configuration), else -1
+    typedef EpiNoAux Aux;
+    // what depends on the column chunk only - once per tile, not per row chunk (two runtime integer divisions otherwise)
+    struct Tile { bf16_t* dst; float* sdst; int which, h, d; };
+    __device__ __forceinline__ Tile tile_begin(int, int, int n) const {
         const int D = 64 * H;
-        const int which = n / D, c = n - which * D, h = c >> 6, d = c & 63;
-        const int b = m / T, t = m - b * T;
-        const size_t row = ((size_t)b * H + h) * T + t;
+        Tile t;
+        t.which = n / D;
+        const int c = n - t.which * D;
+        t.h = c >> 6; t.d = c & 63;
+        t.dst = (t.which == 0 ? qn : t.which == 1 ? kn : v) + t.d;
+        t.sdst = s + (size_t)t.which * (size_t)rows_total;
+        return t;
+    }
+    __device__ __forceinline__ Aux load(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int, const float* a, int, const Aux&, const Tile& tc) const {
+        const int b = tshift >= 0 ? m >> tshift : m / T, t = m - b * T;
+        const size_t row = ((size_t)b * H + tc.h) * T + t;
         float w[8];
-        if (which < 2) {
+        if (tc.which < 2) {
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
@@ -486,14 +499,16 @@ struct EpiQkvHeads {
             const float sc = 8.f / (sqrtf(ss) + NORM_EPS);
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = a[i] * sc;
-            if (d == 0) s[(size_t)which * (size_t)rows_total + row] = sc;
+            if (tc.d == 0) tc.sdst[row] = sc;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = a[i];
         }
-        store8_bf16((which == 0 ? qn : which == 1 ? kn : v) + row * 64 + d, w);
+        store8_bf16(tc.dst + row * 64, w);
     }
-    long rows_total;                                    // samples * H * T = rows of the head-major tensors
+    __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
+        apply(m, n, a, 0, Aux(), tile_begin(m, m, n));
+    }
 };
 
 // ---- the MFMA kernel -------------------------------------------------------------------------------------
@@ -1590,7 +1605,8 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
             const int H = N / 192;
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiQkvHeads{(bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, (float*)e->out4, e->rows_per_sample, H,
-                                      (long)M * H}, st);
+                                      (long)M * H,
+                                      (e->rows_per_sample & (e->rows_per_sample - 1)) == 0 ? __builtin_ctz(e->rows_per_sample) : -1}, st);
         }
     }
     mapdit_set_error("gemm: unknown epilogue kind %d", e->kind);
