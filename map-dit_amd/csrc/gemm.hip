@@ -496,7 +496,9 @@ struct EpiQkvHeads {
             ss += __shfl_xor(ss, 1, 64);
             ss += __shfl_xor(ss, 2, 64);
             ss += __shfl_xor(ss, 4, 64);
-            const float sc = 8.f / (sqrtf(ss) + NORM_EPS);
+            // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences (~30 instructions per chunk): the scale is rounded
+            // into bf16 products anyway, and the backward reads this very value back
+            const float sc = 8.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(ss) + NORM_EPS);
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = a[i] * sc;
             if (tc.d == 0) tc.sdst[row] = sc;
