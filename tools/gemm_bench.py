@@ -70,6 +70,9 @@ def main():
         ("fc2  fwd NT resid", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D,
          ep(L.EPI_RESID, out=out_bf.data_ptr(), out2=xout.data_ptr(), aux=xres.data_ptr(), gate=gate.data_ptr(), ldg=6 * D,
             rows_per_sample=256, ldo=D, alpha=0.9, beta=0.4)),
+        ("proj fwd NT resid", 0, M, D, D, x, D, w_qkv, D,
+         ep(L.EPI_RESID, out=out_bf.data_ptr(), out2=xout.data_ptr(), aux=xres.data_ptr(), gate=gate.data_ptr(), ldg=6 * D,
+            rows_per_sample=256, ldo=D, alpha=0.9, beta=0.4)),
         ("fc2  dX  NN dsilu", 1, M, 4 * D, D, dy, D, w_fc2, 4 * D, ep(L.EPI_DSILU, out=out_bf.data_ptr(), aux=h.data_ptr(), ldo=4 * D)),
         ("fc1  dX  NN store", 1, M, D, 4 * D, dh, 4 * D, w_fc1, D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=D, alpha=1.0)),
         ("fc1  dW  TN split", 2, 4 * D, D, M, dh, 4 * D, x, D, None),
