@@ -25,4 +25,11 @@ python bench.py --precision bf16x3 --batch-per-gpu 64 --steps 5 --warmup 2 --no-
 python tools/precision_trajectory.py --model DiT-S/2 --batch 64 --steps 300 > gpurun_out/precision_trajectory.log  # bf16 vs bf16x3, 300 steps
 python -m mapdit_amd.train --synthetic --model DiT-B/2 --num-steps 300 --batch-size 256 --log-every 25 --ckpt-every 1000 \
     --ema-snapshot-every 150 --results-dir /tmp/mapdit_res > gpurun_out/train300.log
+# round 2
+bash tools/collect_profiles.sh && python tools/summarise_profiles.py                # bench lines at 256/128/64/32, kernel stats, fc1 PMC traffic
+python tools/precision_rank.py                    > gpurun_out/precision_rank.log   # which bf16 roundings carry the logits error
+python tools/gemm_ablate.py --build && python tools/gemm_ablate.py > gpurun_out/gemm_ablate.log   # fill / K loop / epilogue per tile
+for t in mfma_issue store_rate load_rate; do hipcc --offload-arch=gfx950 -O3 tools/$t.hip -o tools/_stamps/$t && tools/_stamps/$t > gpurun_out/$t.log; done
+python tools/step_stress.py 2000 2                > gpurun_out/step_stress.log      # bit-reproducibility beside a second process on the GPU
+python tools/dp_repeat.py 4                       > gpurun_out/dp_repeat.log        # two-rank runs, bit for bit
 echo "done: see gpurun_out/"
