@@ -60,6 +60,10 @@ class FusedAdamEMA:
         self._gammas = [std_to_gamma(s) for s in self.ema_stds]
         self.shards = [(0, flat.numel())]            # element ranges of the flat buffers this rank updates
         self.after_step = None
+        # Data parallel with replicated parameters: every rank must run Adam on every parameter, but nothing in a step READS the EMA
+        # copies - each rank keeps them current for its own range only (16 of the kernel's 44 bytes per parameter) and the ranges
+        # are gathered when a snapshot or checkpoint needs them (parallel.OverlappedGradReducer.attach / gather_state).
+        self.ema_ranges = None                       # [(lo, hi), ...] ascending: update the EMA copies only there; None = everywhere
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
@@ -82,15 +86,29 @@ class FusedAdamEMA:
         betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
         # the per-step values travel as kernel arguments: nothing is uploaded in the training loop
         hyper = L.AdamScalars(lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale)
+        segs = []                                    # (lo, hi, with_ema)
         for lo, hi in self.shards:                   # the whole flat buffer unless a ZeRO-1 reducer handed over its partition
+            if self.ema_ranges is None or not self.ema:
+                segs.append((lo, hi, True))
+                continue
+            pos = lo
+            for a, b in self.ema_ranges:
+                a, b = max(a, lo), min(b, hi)
+                if a >= b:
+                    continue
+                segs += [(pos, a, False), (a, b, True)]
+                pos = b
+            segs.append((pos, hi, False))
+        for lo, hi, with_ema in segs:
             if hi <= lo:
                 continue
             off = lo * 4
+            ema = self.ema if with_ema else None
             with torch.cuda.device(m._pflat.device):
                 L.lib().adam_ema_step_scalars(m._pflat.data_ptr() + off, m._gflat.data_ptr() + off, self.exp_avg.data_ptr() + off,
                                               self.exp_avg_sq.data_ptr() + off,
-                                              self.ema[0].data_ptr() + off if self.ema else None,
-                                              self.ema[1].data_ptr() + off if self.ema else None,
+                                              ema[0].data_ptr() + off if ema else None,
+                                              ema[1].data_ptr() + off if ema else None,
                                               hi - lo, C.byref(hyper), b1, b2, self.eps, L.cur_stream())
         if self.after_step is not None:
             self.after_step()                        # ZeRO-1: all-gather of the updated parameter shards

@@ -161,6 +161,39 @@ class OverlappedGradReducer:
     def reduce(self, flat=None):          # same call site as GradReducer
         self.finish()
 
+    # The parameters and Adam moments are replicated (every rank steps all of them from the same reduced gradients); the two EMA
+    # copies, which no step reads, are kept current by one rank each: rank r owns elements [r * per, (r + 1) * per) (the < 4 * world
+    # elements behind the last range stay replicated).  16 of the optimiser kernel's 44 bytes per parameter on (world - 1) / world
+    # of the model drop out of every step; gather_state() completes the copies before a snapshot or checkpoint reads them.
+    def attach(self, opt):
+        self.opt = opt
+        if self.world > 1 and opt.ema:
+            n = self.model._pflat.numel()
+            self.per = (n // (4 * self.world)) * 4
+            rank = dist.get_rank(self.group)
+            opt.ema_ranges = [(rank * self.per, (rank + 1) * self.per)]
+            if self.world * self.per < n:                  # the tail behind the last equal range: every rank keeps it current
+                opt.ema_ranges.append((self.world * self.per, n))
+            self.name = type(self).name + ", EMA copies sharded"
+
+    def gather_state(self):
+        opt = getattr(self, "opt", None)
+        if opt is None or self.world == 1 or not opt.ema or opt.ema_ranges is None:
+            return
+        rank = dist.get_rank(self.group)
+        for buf in opt.ema:
+            mine = buf[rank * self.per:(rank + 1) * self.per]
+            whole = buf[:self.world * self.per]
+            if _host_staged(self.group, buf):
+                parts = [torch.empty(self.per, dtype=buf.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, mine.detach().cpu(), group=self.group)
+                whole.copy_(torch.cat(parts))
+                torch.cuda.synchronize(buf.device)
+            elif dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(whole, mine, group=self.group)          # in place: `mine` is part `rank` of `whole`
+            else:
+                dist.all_gather(list(whole.chunk(self.world)), mine.clone(), group=self.group)
+
 
 class _ReducerBase:
     name = "none"
@@ -173,8 +206,6 @@ class _ReducerBase:
 
 
 OverlappedGradReducer.name = "allreduce-fp32-per-stage-overlapped"
-OverlappedGradReducer.attach = _ReducerBase.attach
-OverlappedGradReducer.gather_state = _ReducerBase.gather_state
 GradReducer.gather_state = _ReducerBase.gather_state
 GradReducer.name = "allreduce-fp32-after-backward"
 GradReducer.attach = _ReducerBase.attach
