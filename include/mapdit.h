@@ -177,6 +177,9 @@ typedef struct {
     float* part_scratch;
     size_t part_scratch_bytes;
     int* gain_partials_out;
+    /* optional: the scalar gain gradient itself - the partials are then summed here (in partial order, as mapdit_reduce_partials
+     * does; inside the row-split form's second kernel when that form is taken) and *gain_partials_out receives 0 */
+    float* dgain_out;
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
 

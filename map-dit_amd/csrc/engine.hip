@@ -434,7 +434,9 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     } else {
         TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
         a.dxm = e->dxm;
-        TRY(mapdit_resid_mod_bwd(&a, st));              // sets npart
+        a.dgain_out = dgain;                            // the gain partials are summed by the pass itself (npart = 0 then)
+        TRY(mapdit_resid_mod_bwd(&a, st));
+        if (npart == 0) return MAPDIT_OK;
     }
     return mapdit_reduce_partials(e->gain_part, npart, dgain, 0, st);
 }

@@ -139,8 +139,18 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
 }
 
 // Second stage of the row-split form: out[n, d] = sum_z part[z][n][which][d], z in order (deterministic).
+// The extra last block (gain_part != null) sums the scalar-gain partials exactly as reduce_partials_kernel does - one launch less.
 __global__ void rmb_finish_kernel(const float* __restrict__ part, int Z, int N, int D, float* __restrict__ dscale,
-                                  float* __restrict__ dshift, int ldd, float* __restrict__ dg_up, int ldd_up) {
+                                  float* __restrict__ dshift, int ldd, float* __restrict__ dg_up, int ldd_up,
+                                  const float* __restrict__ gain_part, int gain_count, float* __restrict__ dgain_out) {
+    if (gain_part && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x >= 64) return;
+        float a = 0.f;
+        for (int i = threadIdx.x; i < gain_count; i += 64) a += gain_part[i];
+        a = wave_sum(a);
+        if (threadIdx.x == 0) *dgain_out = a;
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * D) return;
     const int n = i / D, d = i % D;
@@ -384,12 +394,18 @@ extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* strea
     p.part = Z > 1 ? a->part_scratch : nullptr;
     hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
     MD_LAUNCH_CHECK();
+    const int npart = a->n_samples * (a->D / 128) * Z;
+    const bool own_gain = a->dgain_out != nullptr && a->dxm != nullptr;
     if (Z > 1) {
-        hipLaunchKernelGGL(rmb_finish_kernel, dim3(cdiv((long)a->n_samples * a->D, 256)), dim3(256), 0, (hipStream_t)stream, p.part, Z,
-                           a->n_samples, a->D, a->dxm ? a->dscale : nullptr, a->dshift, a->ldd, a->y_up ? a->dg_up : nullptr, a->ldd_up);
+        hipLaunchKernelGGL(rmb_finish_kernel, dim3(cdiv((long)a->n_samples * a->D, 256) + (own_gain ? 1 : 0)), dim3(256), 0,
+                           (hipStream_t)stream, p.part, Z, a->n_samples, a->D, a->dxm ? a->dscale : nullptr, a->dshift, a->ldd,
+                           a->y_up ? a->dg_up : nullptr, a->ldd_up, own_gain ? a->dgain_part : nullptr, npart, a->dgain_out);
+        MD_LAUNCH_CHECK();
+    } else if (own_gain) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->dgain_part, npart, a->dgain_out, 0);
         MD_LAUNCH_CHECK();
     }
-    if (a->gain_partials_out) *a->gain_partials_out = a->n_samples * (a->D / 128) * Z;
+    if (a->gain_partials_out) *a->gain_partials_out = own_gain ? 0 : npart;
     return MAPDIT_OK;
 }
 
