@@ -100,12 +100,29 @@ def cpu_steps(model_name: str, batch: int, steps: int):
     return batch * steps / dt, dt / steps
 
 
+def pick_cpu_threads(logical):
+    """torch's default (one thread per logical CPU: 128 on the GPU box) is ~5x slower than the best setting for a batch of 8 -
+    the eager oracle's small ops drown in synchronisation.  One short sweep on DiT-S/4 (batch 8, 2 steps each) picks the count
+    the baseline then runs with; the sweep is reported."""
+    sweep = {}
+    for n in (8, 16, 32, 64):
+        if logical and n > logical:
+            break
+        torch.set_num_threads(n)
+        sweep[n] = cpu_steps("DiT-S/4", 8, 2)[1]
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    return best, {str(k): round(v, 3) for k, v in sweep.items()}
+
+
 def cpu_baseline(model_name: str, batch: int, steps: int, c1_steps: int):
     phys, logical = physical_cores()
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
+    threads, sweep = pick_cpu_threads(logical)
     val, sps = cpu_steps(model_name, batch, steps)
     out = {"value": val, "unit": "latent-img/s", "cores": threads, "kind": "port",
-           "host": {"physical_cores": phys, "logical_cpus": logical, "torch_threads": threads, "torch": torch.__version__},
+           "host": {"physical_cores": phys, "logical_cpus": logical, "torch_threads": threads, "torch_default_threads": default_threads,
+                    "thread_sweep_s_per_step_S4_batch8": sweep, "torch": torch.__version__},
            "sample": f"{model_name}, batch {batch}, {steps} full steps (fwd+loss+bwd+Adam+2 EMA), fp32 eager oracle, "
                      f"{sps:.2f} s/step"}
     if c1_steps > 0:        # BASELINE.json configs[0]: the reference's own CPU-runnable case (SURVEY.md §8d "C1")
@@ -212,8 +229,10 @@ def main():
                     help="strong: --global-batch per node, sharded over the GPUs (BASELINE.json); weak: --global-batch per GPU")
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="override the per-GPU batch directly")
-    ap.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
-                    help="bf16x3: the fp32-accurate parity engine (informational; the headline metric is bf16)")
+    ap.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="bf16",
+                    help="bf16: BASELINE.json's metric (the headline).  f16: the same engine with IEEE fp16 operands (also timed as the "
+                         "`f16` object of the default run).  bf16x3: the fp32-accurate parity engine (informational)")
+    ap.add_argument("--no-f16-leg", action="store_true", help="default bf16 run: skip the extra timed fp16 leg")
     ap.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
                     help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce)")
     ap.add_argument("--rotation-modulation", action="store_true",
@@ -250,70 +269,80 @@ def main():
         B = args.global_batch
     global_batch = B * world
 
-    parity = None
-    if rank == 0 and not args.no_parity and not args.rotation_modulation:
-        parity = parity_leg(args.model, args.precision, dev)
+    def timed_run(precision, steps, warmup):
+        """Builds the model in `precision`, runs `warmup` untimed + `steps` timed training steps; returns the measurements."""
+        parity = None
+        if rank == 0 and not args.no_parity and not args.rotation_modulation:
+            parity = parity_leg(args.model, precision, dev)
+        torch.manual_seed(0)                               # model seed 0 on every rank: identical replicas, no broadcast needed
+        mkw = dict(rotation_modulation=True) if args.rotation_modulation else {}
+        model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000, **mkw).to(dev).train()
+        model.gemm_precision = precision
+        torch.manual_seed(1000 + rank)                     # from here on every rank draws its OWN timesteps, noise and label drops
+        diffusion = create_diffusion(timestep_respacing="")
+        num_steps = 400_000                                # train.py defaults -> warm-up / decay points
+        reducer = parallel.make_reducer(model, args.grad_comm)
+        opt = FusedAdamEMA(model, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
+                           lr_lambda=create_lr_lambda(num_steps // 150, num_steps // 10), grad_scale=reducer.grad_scale)
+        reducer.attach(opt)
+        g = torch.Generator(device=dev).manual_seed(1 + rank)  # data seed 1 + rank
 
-    torch.manual_seed(0)                                   # model seed 0 on every rank: identical replicas, no broadcast needed
-    mkw = dict(rotation_modulation=True) if args.rotation_modulation else {}
-    model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000, **mkw).to(dev).train()
-    model.gemm_precision = args.precision
-    torch.manual_seed(1000 + rank)                         # from here on every rank draws its OWN timesteps, noise and label drops
-    diffusion = create_diffusion(timestep_respacing="")
-    num_steps = 400_000                                    # train.py defaults -> warm-up / decay points
-    reducer = parallel.make_reducer(model, args.grad_comm)
-    opt = FusedAdamEMA(model, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
-                       lr_lambda=create_lr_lambda(num_steps // 150, num_steps // 10), grad_scale=reducer.grad_scale)
-    reducer.attach(opt)
-    g = torch.Generator(device=dev).manual_seed(1 + rank)  # data seed 1 + rank
+        def step():
+            x = torch.randn(B, 4, 32, 32, device=dev, generator=g)              # a fresh batch every step
+            y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+            t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
+            loss = diffusion.training_losses(model, x, t, dict(y=y))["loss"].mean()
+            opt.zero_grad()
+            loss.backward()
+            reducer.finish()
+            opt.step()
+            return loss
 
-    def step():
-        x = torch.randn(B, 4, 32, 32, device=dev, generator=g)              # a fresh batch every step
-        y = torch.randint(0, 1000, (B,), device=dev, generator=g)
-        t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
-        loss = diffusion.training_losses(model, x, t, dict(y=y))["loss"].mean()
-        opt.zero_grad()
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def fence():
+        for _ in range(warmup):
+            step()
+        fence()
+        rt = model._rt[True if precision == "bf16" else (precision, True)]
+        L.lib().engine_profile_begin(rt.handle, L.PROF_FC1_FWD, model.depth * steps)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            loss = step()
+            marks[i + 1].record()                          # on the compute stream; no host synchronisation inside the region
+        fence()
+        elapsed = time.perf_counter() - t0
+        cnt, tot_ms = C.c_int(0), C.c_double(0.0)
+        L.lib().engine_profile_end(rt.handle, C.byref(cnt), C.byref(tot_ms))
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        final_loss = float(loss.item())
+        model.check_device_errors()
+        geo = dict(T=(model.input_size // model.patch_size) ** 2, D=model.hidden_size, Hm=model.blocks[0].mlp.hidden_dim,
+                   P=model.patch_size ** 2 * model.in_channels, depth=model.depth)
+        res = dict(parity=parity, elapsed=elapsed, per_step=per_step, fc1_count=cnt.value, fc1_ms=tot_ms.value, final_loss=final_loss,
+                   grad_comm=reducer.name, geo=geo)
+        del model, opt, reducer, rt
+        torch.cuda.empty_cache()
+        return res
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    rt = model._rt[True if args.precision == "bf16" else (args.precision, True)]
-    L.lib().engine_profile_begin(rt.handle, L.PROF_FC1_FWD, model.depth * args.steps)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = step()
-        marks[i + 1].record()                              # on the compute stream; no host synchronisation inside the region
-    fence()
-    elapsed = time.perf_counter() - t0
-    cnt, tot_ms = C.c_int(0), C.c_double(0.0)
-    L.lib().engine_profile_end(rt.handle, C.byref(cnt), C.byref(tot_ms))
-    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    final_loss = float(loss.item())
-    model.check_device_errors()
+    r = timed_run(args.precision, args.steps, args.warmup)
+    parity, elapsed, per_step, final_loss = r["parity"], r["elapsed"], r["per_step"], r["final_loss"]
+    geo = r["geo"]
 
-    T = (model.input_size // model.patch_size) ** 2
-    D, Hm = model.hidden_size, model.blocks[0].mlp.hidden_dim
-    P = model.patch_size ** 2 * model.in_channels
-    f_fwd = fwd_flops_per_sample(model.depth, D, T, P)
+    T, D, Hm, P = geo["T"], geo["D"], geo["Hm"], geo["P"]
+    f_fwd = fwd_flops_per_sample(geo["depth"], D, T, P)
     value = world * B * args.steps / elapsed
     fc1_flops = 2.0 * (B * T) * Hm * D
-    fc1_ms = tot_ms.value / max(cnt.value, 1)
-    achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if cnt.value else None
+    fc1_ms = r["fc1_ms"] / max(r["fc1_count"], 1)
+    achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if r["fc1_count"] else None
     at = f"@{global_batch}" if args.scaling == "strong" else f"@{B}/GPU"
     out = {
         "metric": f"latent-images/sec training step, {args.model} {args.precision}{' rotation-modulation' if args.rotation_modulation else ''} {at}",
@@ -321,12 +350,13 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": statistics.median(per_step),
         "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (two-term split bf16 operands, fp32 accumulate and storage)", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3 (two-term split bf16 operands, fp32 accumulate and storage)"}[args.precision],
+        "data": "synthetic",
         "config": {"workload": f"{args.model} full training step on 32x32x4 latents (fresh batch+fwd+loss+bwd+grad reduction+Adam+"
-                               "2xEMA), all magnitude-preserving features on, bf16 GEMM operands / fp32 accumulate, master and "
-                               "residual fp32",
+                               f"2xEMA), all magnitude-preserving features on, {'fp16' if args.precision == 'f16' else 'bf16'} GEMM operands / "
+                               "fp32 accumulate, master and residual fp32",
                    "global_batch": global_batch, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
-                   "grad_comm": reducer.name,
+                   "grad_comm": r["grad_comm"],
                    "seeds": {"model": 0, "data": "1+rank", "t/noise/drop": "1000+rank"}, "final_loss": final_loss},
         "step_mfma_frac": value * 3 * f_fwd / (world * PEAK_BF16_DENSE_TFLOPS * 1e12),
         "parity": parity,
@@ -334,8 +364,18 @@ def main():
                                                   f"[{B * T},{D}]x[{Hm},{D}]^T)",
                      "achieved": achieved, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_BF16_DENSE_TFLOPS) if achieved else None, **pmc_traffic(args.model, B),
-                     "launches_timed": cnt.value, "avg_launch_ms": fc1_ms, "flops_per_launch": fc1_flops},
+                     "launches_timed": r["fc1_count"], "avg_launch_ms": fc1_ms, "flops_per_launch": fc1_flops},
     }
+    # The same step with IEEE fp16 operands (gemm_precision = "f16": same kernels, same MFMA rate, 10 mantissa bits): the path
+    # whose forward logits are inside north_star's 1e-3 of the reference.  The headline above stays BASELINE.json's bf16.
+    if args.precision == "bf16" and world == 1 and not args.no_f16_leg and not args.rotation_modulation:
+        h = timed_run("f16", args.steps, max(3, args.warmup // 2))
+        h_ms = h["fc1_ms"] / max(h["fc1_count"], 1)
+        out["f16"] = {"value": world * B * args.steps / h["elapsed"], "unit": "latent-img/s", "ms_per_step": 1e3 * h["elapsed"] / args.steps,
+                      "ms_per_step_median": statistics.median(h["per_step"]), "steps": args.steps, "parity": h["parity"],
+                      "final_loss": h["final_loss"], "fc1_avg_launch_ms": h_ms,
+                      "fc1_tflops": fc1_flops / (h_ms * 1e-3) / 1e12 if h["fc1_count"] else None,
+                      "note": "same engine, IEEE fp16 GEMM / attention operands, static power-of-two loss scale"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.rotation_modulation:
             out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps, args.cpu_c1_steps)

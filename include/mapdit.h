@@ -9,6 +9,12 @@
  *
  * All pointers are DEVICE pointers unless a name ends in _host.  bf16 tensors are raw uint16_t bits.
  * Every kernel entry point is asynchronous on `stream` and safe to capture into a hipGraph.
+ *
+ * 16-bit operand format.  Every entry point that reads or writes 16-bit GEMM / attention operands exists twice: under its
+ * plain name with bfloat16 operands, and with the suffix _f16 (mapdit_gemm_f16, mapdit_f32_to_f16, ...) with IEEE fp16 operands
+ * - same arguments, same arithmetic, fp32 accumulation either way (the library builds each kernel file once per format).  fp16
+ * issues on the MFMA pipe at the bf16 rate and keeps 10 mantissa bits, the precision of the TF32 products the reference trains
+ * with (train.py:222-223): it is the engine's MAPDIT_PREC_F16 mode.  The _f16 forms are listed at the end of this header.
  */
 #ifndef MAPDIT_H
 #define MAPDIT_H
@@ -26,7 +32,8 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 2: cond_combine_* take table_rows; adam_ema_step_scalars; device_error_poll; comm_* */
+int mapdit_abi_version(void);   /* 3: _f16 twins; grad scale arguments (final_out_bwd, rotate_bwd, resid_mod_bwd_t.dgain_scale);
+                                 * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM on bf16 MFMA with fused epilogues — F.linear and its autograd (src/basic/mp_linear.py:46,75).
@@ -53,8 +60,8 @@ enum {
                                 * it (utils.py:11-16 backward): dx' = ca*dxo + k*scale*acc, the per-sample column sums dshift /
                                 * dscale / dgate and the gain partials (one per output tile), and dy_up = cb*gate_up*dx'.  `rmb`
                                 * holds the operands (its dxm field is ignored: the accumulator takes its place).  Needs
-                                * T = rmb->T with T % 64 == 0, M >= 512, N = D >= 256 (256x256 tiles: a tile holds whole 64-row
-                                * blocks of one sample each).  dgain_part receives ceil(M/256) * ceil(D/256) partials.          */
+                                * T = rmb->T in {64, 128, 256} (256 % T == 0: a sample's rows lie in ONE 256-row tile, whose
+                                * 64-row blocks belong to one sample each), M >= 512, N = D >= 256.  dgain_part receives ceil(M/256) * ceil(D/256) partials.          */
     MAPDIT_EPI_QKV_HEADS = 6   /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
                                 * is (which, head, d) = (n / D, n % D / 64, n % 64); q and k rows are cosine-normalised per
                                 * head, x * s with s = 8 / (|x| + 1e-4) from the fp32 accumulators, and everything is written
@@ -180,16 +187,20 @@ typedef struct {
     /* optional: the scalar gain gradient itself - the partials are then summed here (in partial order, as mapdit_reduce_partials
      * does; inside the row-split form's second kernel when that form is taken) and *gain_partials_out receives 0 */
     float* dgain_out;
+    /* optional (0 = 1): factor on the scalar gain gradient (its partials).  An fp16 engine runs its backward on gradients
+     * multiplied by a power-of-two loss scale and passes 1/scale here: parameter gradients leave the library unscaled. */
+    float dgain_scale;
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
 
 /* Rotation modulation (the reference's README.md:1-3; NOT in its snapshot - parity unpinned, semantics: oracle.modulate_rot):
  * in place on the bf16 operand u [n_samples*T, D] = x * scale: (u[2i], u[2i+1]) <- R(*gain * theta[n, i]) (u[2i], u[2i+1]);
  * theta fp32 rows of D/2 angles, stride ldt.  The backward rotates the gradient back in place (dy <- R^T dy), writes
- * dtheta[n, i] = *gain * sum_t (dy1 y0 - dy0 y1) (y = the saved rotated operand) and n_samples * D/128 partial sums of dgain. */
+ * dtheta[n, i] = *gain * sum_t (dy1 y0 - dy0 y1) (y = the saved rotated operand) and n_samples * D/128 partial sums of dgain,
+ * each multiplied by dgain_scale (1 unless the gradients carry a loss scale, see mapdit_resid_mod_bwd_t.dgain_scale). */
 int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D, void* stream);
 int mapdit_rotate_bwd(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta, int ldd,
-                      float* dgain_part, int n_samples, int T, int D, void* stream);
+                      float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream);
 int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream);
 
 int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream);          /* mp_silu.py:7 */
@@ -253,10 +264,12 @@ int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, 
 int mapdit_device_error_poll(void* stream);
 int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
                          const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream);
+/* grad_scale multiplies the two 16-bit outputs (dlin, da_bf) only: the loss scale of an fp16 backward (1 otherwise); the
+ * MPScale reference gradients are written unscaled. */
 int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
                          const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
                          float* dref_part /* scratch [N][2][8] */, float* dref_mean /* [8], += */, float* dref_sigma,
-                         int N, int C, int S, int p, void* stream);
+                         float grad_scale, int N, int C, int S, int p, void* stream);
 /* DiT.forward_with_cfg tail (src/dit.py:113-118). */
 int mapdit_cfg_combine(const float* model_out, float* out, int n_total, int C, int HW, float cfg_scale, void* stream);
 
@@ -295,9 +308,18 @@ typedef struct {
                      * split into hi+lo bf16 terms along the reduction index (3x the GEMM work, unfused fp32 pointwise and
                      * attention kernels); logits, losses and parameter gradients agree with the fp32 reference to ~1e-5. */
     int rotation;   /* != 0: rotation modulation (README.md:1-3; parity unpinned): a block's modulation linear has 5*hidden rows
-                     * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m).  MAPDIT_PREC_BF16 only. */
+                     * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m).  Not with MAPDIT_PREC_BF16X3. */
+    float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
+                       * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
+                       * divided by it again before it is written.  0 = chosen per backward from the batch:
+                       * 2^(floor(log2(N * C * S * S)) - 5), i.e. |dout| ~ 1/(N C S S) of a mean-reduced loss becomes ~1/32. */
 } mapdit_config_t;
-enum { MAPDIT_PREC_BF16 = 0, MAPDIT_PREC_BF16X3 = 1 };
+/* MAPDIT_PREC_F16: the MAPDIT_PREC_BF16 engine with IEEE fp16 in place of bf16 for every GEMM / attention operand (weight images,
+ * activations, activation gradients): same kernels, same MFMA rate, fp32 accumulation, fp32 residual stream and master weights,
+ * fp32-accurate conditioning path.  10 mantissa bits instead of 7: forward logits within 1e-3 of the fp32 reference on every named
+ * model (bf16: 6e-3 ... 8e-3).  Unit-scale magnitude-preserving activations and bounded cosine logits (exp <= e^8.5) fit fp16's
+ * range; the backward carries a static loss scale (loss_scale above). */
+enum { MAPDIT_PREC_BF16 = 0, MAPDIT_PREC_BF16X3 = 1, MAPDIT_PREC_F16 = 2 };
 
 /* Parameter pointer table: MAPDIT_NUM_GLOBAL global entries followed by MAPDIT_NUM_BLOCK entries per block. */
 enum {
@@ -337,7 +359,7 @@ int mapdit_engine_profile_end(mapdit_engine_t* e, int* count, double* total_ms);
 
 /* Diagnostics: device address of an intermediate of the LAST forward that ran with save=1 (training engines keep every
  * block's activations for backward).  Lets tests compare the engine stage by stage with the oracle instead of only at
- * the logits.  *dtype: 0 = fp32, 1 = bf16.  `block` is ignored for the MAPDIT_PEEK_G_* ids.  Layouts:
+ * the logits.  *dtype: 0 = fp32, 1 = bf16, 2 = fp16 (MAPDIT_PREC_F16 engines).  `block` is ignored for the MAPDIT_PEEK_G_* ids.  Layouts:
  *   G_FOUR [N,256] bf16 | G_TEMB [N,D] f32 | G_C [N,D] f32 | G_MOD_ALL [N, depth*6D] f32 | G_X0 [N*T,D] f32 (embedded tokens)
  *   G_XMODF [N*T,D] bf16 (final modulate) | G_LIN [N*T, ldl] f32 (final linear, ldl = *ld)
  *   B_XM / B_XM2 [N*T,D] bf16 (modulated inputs of the two branches) | B_QKV [N*T,3D] bf16 | B_QN / B_KN / B_V / B_O
@@ -364,6 +386,57 @@ void mapdit_comm_destroy(mapdit_comm_t* comm);
 int mapdit_allreduce_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
 int mapdit_reduce_scatter_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
 int mapdit_allgather_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * IEEE fp16 operand forms (see "16-bit operand format" at the top): identical signatures and semantics, every uint16_t tensor
+ * holds fp16 bits instead of bf16 bits.  (mapdit_weightnorm_fwd*_f16: w_bf16 receives fp16; the w_split3 image stays a bf16
+ * split - the fp32-accurate conditioning GEMMs run on bf16 terms in every engine.)
+ * ------------------------------------------------------------------------------------------------------------ */
+int mapdit_gemm_f16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
+                    const mapdit_epilogue_t* epi, void* stream);
+int mapdit_weightnorm_fwd_f16(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_f16, float* w_f32,
+                              float* inv, void* stream);
+int mapdit_weightnorm_fwd_batch_f16(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream);
+int mapdit_modulate_fwd_f16(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
+                            uint16_t* out, int n_samples, int T, int D, void* stream);
+int mapdit_resid_mod_bwd_f16(const mapdit_resid_mod_bwd_t* args, void* stream);
+int mapdit_rotate_fwd_f16(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D, void* stream);
+int mapdit_rotate_bwd_f16(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta, int ldd,
+                          float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream);
+int mapdit_mpsilu_to_f16(const float* x, uint16_t* out, long n, void* stream);
+int mapdit_f32_to_f16(const float* x, uint16_t* out, long n, float alpha, void* stream);
+int mapdit_f32_to_f16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream);
+int mapdit_qkv_split_f16(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
+                         void* stream);
+int mapdit_qkv_merge_bwd_f16(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+                             const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
+int mapdit_attn_cos_fwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
+                            int T, int H, int head_dim, void* stream);
+int mapdit_attn_cos_bwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                            const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+                            int head_dim, void* stream);
+int mapdit_attn_cos_bwd_fused_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                                  const float* lse, float* delta, const float* scales, uint16_t* dqkv, int B, int T, int H,
+                                  int head_dim, void* stream);
+int mapdit_qkv_split_generic_f16(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
+                                 void* stream);
+int mapdit_qkv_merge_bwd_generic_f16(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+                                     const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
+int mapdit_attn_generic_fwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T,
+                                int H, int head_dim, void* stream);
+int mapdit_attn_generic_bwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                                const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
+                                int head_dim, void* stream);
+int mapdit_patch_embed_fwd_f16(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
+                               int ldp, int N, int C, int S, int p, int D, void* stream);
+int mapdit_cond_combine_fwd_f16(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
+                                uint16_t* c_f16, int n, int D, int table_rows, void* stream);
+int mapdit_cond_combine_bwd_f16(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
+                                float* dtable, int n, int D, int table_rows, void* stream);
+int mapdit_final_out_bwd_f16(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
+                             const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_f16,
+                             float* dref_part, float* dref_mean, float* dref_sigma, float grad_scale, int N, int C, int S, int p,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ class ResidModBwd(C.Structure):
                 ("g_up", vp), ("dx", vp), ("dx_bf", vp), ("dshift", vp), ("dscale", vp), ("dgain_part", vp),
                 ("dy_up", vp), ("dg_up", vp), ("ldmod", ci), ("ldg_up", ci), ("ldd", ci), ("ldd_up", ci),
                 ("n_samples", ci), ("T", ci), ("D", ci), ("ca", cf), ("cb", cf), ("part_scratch", vp), ("part_scratch_bytes", C.c_size_t),
-                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp)]
+                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("dgain_scale", cf)]
 
 
 class WnJob(C.Structure):          # mapdit_wn_job_t
@@ -46,10 +46,13 @@ class AdamScalars(C.Structure):    # mapdit_adam_scalars_t
 
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
-                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci), ("rotation", ci)]
+                ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci), ("rotation", ci),
+                ("loss_scale", cf)]
 
 
-PRECISIONS = {"bf16": 0, "bf16x3": 1}
+# engine precisions (mapdit.h MAPDIT_PREC_*).  "f16": the bf16 engine with IEEE fp16 operands - same speed, 10 mantissa bits
+# (forward logits within 1e-3 of the fp32 reference); "bf16x3": the fp32-accurate parity instrument.
+PRECISIONS = {"bf16": 0, "bf16x3": 1, "f16": 2}
 
 
 NT, NN, TN = 0, 1, 2
@@ -75,7 +78,7 @@ _SIGS = {
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
     "mapdit_rotate_fwd": [vp, vp, ci, vp, ci, ci, ci, vp],
-    "mapdit_rotate_bwd": [vp, vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp],
+    "mapdit_rotate_bwd": [vp, vp, vp, ci, vp, vp, ci, vp, cf, ci, ci, ci, vp],
     "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
@@ -100,7 +103,7 @@ _SIGS = {
     "mapdit_reduce_scatter_bucket": [vp, vp, cl, vp],
     "mapdit_allgather_bucket": [vp, vp, cl, vp],
     "mapdit_final_out_fwd": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_final_out_bwd": [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp],
     "mapdit_cfg_combine": [vp, vp, ci, ci, ci, cf, vp],
     "mapdit_q_sample": [vp, vp, vp, vp, ci, vp, ci, ci, vp],
     "mapdit_loss_fwd": [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp],
@@ -117,6 +120,14 @@ _SIGS = {
     "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
     "mapdit_engine_peek": [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(ci), C.POINTER(ci)],
 }
+# IEEE fp16 operand forms: same signatures (mapdit.h, "16-bit operand format")
+for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rotate_fwd", "rotate_bwd", "qkv_split",
+           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
+           "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
+    _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]
+for _b, _h in (("gemm_bf16", "gemm_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),
+               ("mpsilu_to_bf16", "mpsilu_to_f16")):
+    _SIGS[f"mapdit_{_h}"] = _SIGS[f"mapdit_{_b}"]
 # entry points that do not return a status
 _OTHER = {
     "mapdit_last_error": (C.c_char_p, []),

@@ -20,14 +20,14 @@
 
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
     union { uint32_t u[4]; bf16x8_t v; } r;
-    r.u[0] = pack2bf(a[base + 0], a[base + 1]);
-    r.u[1] = pack2bf(a[base + 2], a[base + 3]);
-    r.u[2] = pack2bf(a[base + 4], a[base + 5]);
-    r.u[3] = pack2bf(a[base + 6], a[base + 7]);
+    r.u[0] = pack16(a[base + 0], a[base + 1]);
+    r.u[1] = pack16(a[base + 2], a[base + 3]);
+    r.u[2] = pack16(a[base + 4], a[base + 5]);
+    r.u[3] = pack16(a[base + 6], a[base + 7]);
     return r.v;
 }
 
@@ -106,8 +106,8 @@ __device__ __forceinline__ void store_wave_tile(char* wbuf, const float (&c0)[16
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         char* row = wbuf + acc_row(i, lane) * WT_LD;
-        *(bf16_t*)(row + 2 * r) = f2bf(c0[i]);
-        *(bf16_t*)(row + 64 + 2 * r) = f2bf(c1[i]);
+        *(bf16_t*)(row + 2 * r) = cvt16(c0[i]);
+        *(bf16_t*)(row + 64 + 2 * r) = cvt16(c1[i]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -145,7 +145,7 @@ __device__ __forceinline__ void store_wave_tile_jac(float* wbuf, const f32x16_t&
         float x[8], dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            x[e] = __uint_as_float((e & 1) ? (xw[e >> 1] & 0xffff0000u) : (xw[e >> 1] << 16));
+            x[e] = (e & 1) ? hi16(xw[e >> 1]) : lo16(xw[e >> 1]);
             dot += g[e] * x[e];
         }
         dot += __shfl_xor(dot, 1, 64);
@@ -154,10 +154,10 @@ __device__ __forceinline__ void store_wave_tile_jac(float* wbuf, const f32x16_t&
         const float sc = srow[row], n = 8.f / sc - NORM_EPS;
         const float cc = dot / (8.f * fmaxf(n, 1e-30f));
         uint4 out;
-        out.x = pack2bf(sc * g[0] - x[0] * cc, sc * g[1] - x[1] * cc);
-        out.y = pack2bf(sc * g[2] - x[2] * cc, sc * g[3] - x[3] * cc);
-        out.z = pack2bf(sc * g[4] - x[4] * cc, sc * g[5] - x[5] * cc);
-        out.w = pack2bf(sc * g[6] - x[6] * cc, sc * g[7] - x[7] * cc);
+        out.x = pack16(sc * g[0] - x[0] * cc, sc * g[1] - x[1] * cc);
+        out.y = pack16(sc * g[2] - x[2] * cc, sc * g[3] - x[3] * cc);
+        out.z = pack16(sc * g[4] - x[4] * cc, sc * g[5] - x[5] * cc);
+        out.w = pack16(sc * g[6] - x[6] * cc, sc * g[7] - x[7] * cc);
         *(uint4*)(gdst + (size_t)row * ld + c * 8) = out;
     }
     __builtin_amdgcn_wave_barrier();
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) a = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
             const bf16x8_t pa = pack8(a, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_rows(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
+                oa[dt] = MFMA32(pa, frag_tr_rows(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt]);
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
         dof[ks] = *(const bf16x8_t*)(dO + mo);
         const bf16x8_t of = *(const bf16x8_t*)(O + mo);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+        for (int e = 0; e < 8; ++e) del_p += up16((bf16_t)dof[ks][e]) * up16((bf16_t)of[e]);
     }
     const float lse_q = lse[bh * T + q0 + r];
     sk_.store(ks_, nullptr, tid);
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
         f32x16_t st = {}, dp = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+            st = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st);
+            dp = MFMA32(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
             const bf16x8_t a = pack8(st, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr_rows(ks_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
+                dq[dt] = MFMA32(a, frag_tr_rows(ks_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt]);
         }
     }
     __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
         f32x16_t s = {}, dp = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+            s = MFMA32(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s);
+            dp = MFMA32(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
             const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dvv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(dots_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<T>(qts_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt], 0, 0, 0);
+                dvv[dt] = MFMA32(pa, frag_tr<T>(dots_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt]);
+                dk[dt] = MFMA32(da, frag_tr<T>(qts_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt]);
             }
         }
     }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     store_wave_tile(wbuf, c0, c1, dv + (bh * T + k0) * 64, 64, lane);
 }
 
-}  // namespace
+MD_NS_CLOSE
 
 #define ATTN_DISPATCH(T_, CALL)                                                         \
     switch (T_) {                                                                       \
@@ -401,14 +401,14 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     }
 
 // Generic-shape path (attention_generic.hip): any head_dim <= 96, any T <= 256.
-extern "C" int mapdit_attn_generic_fwd(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, int, void*);
-extern "C" int mapdit_attn_generic_bwd(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*,
+extern "C" int MD_SYM(attn_generic_fwd)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, int, void*);
+extern "C" int MD_SYM(attn_generic_bwd)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*,
                                        const float*, float*, uint16_t*, uint16_t*, uint16_t*, int, int, int, int, void*);
 
 static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 || T == 128 || T == 256); }
 // head_dim 72 (DiT-XL): MFMA kernels of attention72.hip; an escape hatch keeps the generic path reachable for A/B runs
-int mapdit_attn72_fwd(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
-int mapdit_attn72_bwd(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
+int MD_SYM(attn72_fwd)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
+int MD_SYM(attn72_bwd)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
                       uint16_t*, uint16_t*, uint16_t*, int, int, int, void*);
 static bool mfma72_shape(int T, int head_dim) {
     if (head_dim != 72 || !(T == 64 || T == 128 || T == 256)) return false;
@@ -416,11 +416,11 @@ static bool mfma72_shape(int T, int head_dim) {
     return enabled;
 }
 
-extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse,
+extern "C" int MD_SYM(attn_cos_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse,
                                    int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && o && lse, "attn_cos_fwd: null argument");
-    if (mfma72_shape(T, head_dim)) return mapdit_attn72_fwd(qn, kn, v, o, lse, B, T, H, stream);
-    if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_fwd(qn, kn, v, o, lse, B, T, H, head_dim, stream);
+    if (mfma72_shape(T, head_dim)) return MD_SYM(attn72_fwd)(qn, kn, v, o, lse, B, T, H, stream);
+    if (!mfma_shape(T, head_dim)) return MD_SYM(attn_generic_fwd)(qn, kn, v, o, lse, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
@@ -429,12 +429,12 @@ extern "C" int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
+extern "C" int MD_SYM(attn_cos_bwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
                                    const uint16_t* O, const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn,
                                    uint16_t* dv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && dqn && dkn && dv, "attn_cos_bwd: null argument");
-    if (mfma72_shape(T, head_dim)) return mapdit_attn72_bwd(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, stream);
-    if (!mfma_shape(T, head_dim)) return mapdit_attn_generic_bwd(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, head_dim, stream);
+    if (mfma72_shape(T, head_dim)) return MD_SYM(attn72_bwd)(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, stream);
+    if (!mfma_shape(T, head_dim)) return MD_SYM(attn_generic_bwd)(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
@@ -446,7 +446,7 @@ extern "C" int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_attn_cos_bwd_fused(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
+extern "C" int MD_SYM(attn_cos_bwd_fused)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
                                          const uint16_t* O, const float* lse, float* delta, const float* scales,
                                          uint16_t* dqkv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && scales && dqkv, "attn_cos_bwd_fused: null argument");

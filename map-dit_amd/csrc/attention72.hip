@@ -12,7 +12,7 @@
 // Layouts: qn, kn, v, dqn, dkn, dv [B*H][T][72] bf16; o, dO [B*T][H*72] bf16; lse, delta [B*H][T] fp32.
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 constexpr int HD = 72, CH = 9;                 // valid columns, 16-byte chunks per row
 constexpr int KS = 5, DT = 3;                  // k-steps over the head dim (80), 32-column output tiles (96)
@@ -21,10 +21,10 @@ constexpr int IMG_ROWS = 96;                   // rows a transposed image is rea
 
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
     union { uint32_t u[4]; bf16x8_t v; } r;
-    r.u[0] = pack2bf(a[base + 0], a[base + 1]);
-    r.u[1] = pack2bf(a[base + 2], a[base + 3]);
-    r.u[2] = pack2bf(a[base + 4], a[base + 5]);
-    r.u[3] = pack2bf(a[base + 6], a[base + 7]);
+    r.u[0] = pack16(a[base + 0], a[base + 1]);
+    r.u[1] = pack16(a[base + 2], a[base + 3]);
+    r.u[2] = pack16(a[base + 4], a[base + 5]);
+    r.u[3] = pack16(a[base + 6], a[base + 7]);
     return r.v;
 }
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
@@ -112,9 +112,9 @@ __device__ __forceinline__ void store_wave_tile(char* wbuf, const f32x16_t (&acc
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         char* row = wbuf + acc_row(i, lane) * WT_LD;
-        *(bf16_t*)(row + 2 * r) = f2bf(acc[0][i] * rs[i]);
-        *(bf16_t*)(row + 64 + 2 * r) = f2bf(acc[1][i] * rs[i]);
-        if (r < HD - 64) *(bf16_t*)(row + 128 + 2 * r) = f2bf(acc[2][i] * rs[i]);
+        *(bf16_t*)(row + 2 * r) = cvt16(acc[0][i] * rs[i]);
+        *(bf16_t*)(row + 64 + 2 * r) = cvt16(acc[1][i] * rs[i]);
+        if (r < HD - 64) *(bf16_t*)(row + 128 + 2 * r) = cvt16(acc[2][i] * rs[i]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) a = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
             const bf16x8_t pa = pack8(a, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<T>(vts_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt], 0, 0, 0);
+                oa[dt] = MFMA32(pa, frag_tr<T>(vts_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt]);
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t
         dof[ks] = frag_global(dorow, ks, h2);
         const bf16x8_t of = frag_global(orow, ks, h2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) del_p += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+        for (int e = 0; e < 8; ++e) del_p += up16((bf16_t)dof[ks][e]) * up16((bf16_t)of[e]);
     }
     const float lse_q = lse[bh * T + q0 + r];
     sk_.template store<T>(ks_, kts_, 0, tid);
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t
         f32x16_t st = {}, dp = {};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+            st = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], st);
+            dp = MFMA32(frag_rows(vs_, 32 * kt, ks, lane), dof[ks], dp);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t
             const bf16x8_t a = pack8(st, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt], 0, 0, 0);
+                dq[dt] = MFMA32(a, frag_tr<T>(kts_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt]);
         }
     }
     float one[16];
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dkv_kernel(const bf16_
             f32x16_t s = {}, dp = {};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+                s = MFMA32(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s);
+                dp = MFMA32(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dkv_kernel(const bf16_
                 const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    dvv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<G::TH>(dots_, 32 * dt, 32 * qh + 16 * s2, lane), dvv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<G::TH>(qts_, 32 * dt, 32 * qh + 16 * s2, lane), dk[dt], 0, 0, 0);
+                    dvv[dt] = MFMA32(pa, frag_tr<G::TH>(dots_, 32 * dt, 32 * qh + 16 * s2, lane), dvv[dt]);
+                    dk[dt] = MFMA32(da, frag_tr<G::TH>(qts_, 32 * dt, 32 * qh + 16 * s2, lane), dk[dt]);
                 }
             }
         }
@@ -350,10 +350,10 @@ constexpr int TOK = 8;
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { f[2 * i] = lo16(w[i]); f[2 * i + 1] = hi16(w[i]); }
 }
 __device__ __forceinline__ uint4 pack8f(const float* f) {
-    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+    return make_uint4(pack16(f[0], f[1]), pack16(f[2], f[3]), pack16(f[4], f[5]), pack16(f[6], f[7]));
 }
 
 __global__ void qkv_split72_kernel(const bf16_t* __restrict__ qkv, int M, int T, int H, bf16_t* __restrict__ qn,
@@ -437,9 +437,9 @@ __global__ void qkv_merge72_kernel(const bf16_t* __restrict__ qkv, int M, int T,
     }
 }
 
-}  // namespace
+MD_NS_CLOSE
 
-int mapdit_qkv_split72(const uint16_t* qkv, int B, int T, int H, uint16_t* qn, uint16_t* kn, uint16_t* v, void* stream) {
+int MD_SYM(qkv_split72)(const uint16_t* qkv, int B, int T, int H, uint16_t* qn, uint16_t* kn, uint16_t* v, void* stream) {
     const int threads = (3 * H * CH + 63) / 64 * 64, M = B * T;
     MD_CHECK(threads <= 1024, "qkv_split (head_dim 72): %d heads unsupported (<= 37)", H);
     hipLaunchKernelGGL(qkv_split72_kernel, dim3((M + TOK - 1) / TOK), dim3(threads), 3 * H * CH * sizeof(float), (hipStream_t)stream, qkv,
@@ -448,7 +448,7 @@ int mapdit_qkv_split72(const uint16_t* qkv, int B, int T, int H, uint16_t* qn, u
     return MAPDIT_OK;
 }
 
-int mapdit_qkv_merge_bwd72(const uint16_t* qkv, int B, int T, int H, const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv,
+int MD_SYM(qkv_merge_bwd72)(const uint16_t* qkv, int B, int T, int H, const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv,
                            uint16_t* dqkv, void* stream) {
     const int threads = (3 * H * CH + 63) / 64 * 64, M = B * T;
     MD_CHECK(threads <= 1024, "qkv_merge_bwd (head_dim 72): %d heads unsupported (<= 37)", H);
@@ -467,7 +467,7 @@ int mapdit_qkv_merge_bwd72(const uint16_t* qkv, int B, int T, int H, const uint1
     }
 
 // Internal entry points (dispatched to from mapdit_attn_cos_fwd / _bwd for head_dim 72).
-int mapdit_attn72_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+int MD_SYM(attn72_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
                       void* stream) {
     const float scale = 1.f / sqrtf((float)HD);
     hipStream_t st = (hipStream_t)stream;
@@ -476,7 +476,7 @@ int mapdit_attn72_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v,
     return MAPDIT_OK;
 }
 
-int mapdit_attn72_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+int MD_SYM(attn72_bwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                       const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H, void* stream) {
     const float scale = 1.f / sqrtf((float)HD);
     hipStream_t st = (hipStream_t)stream;

@@ -5,7 +5,7 @@
 // Layout: qn, kn, v, dqn, dkn, dv  [B*H][T][hd] bf16 (no padding); o, dO [B*T][H*hd] bf16; lse, delta [B*H][T] fp32.
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 constexpr int GEN_MAX_HD = 96;
 constexpr int GEN_MAX_T = 256;
@@ -26,10 +26,10 @@ __global__ void qkv_split_generic_kernel(const bf16_t* __restrict__ qkv, int B, 
         float s = 1.f;
         if (which < 2) {
             float ss = 0.f;
-            for (int d = 0; d < hd; ++d) { const float x = bf2f(src[d]); ss += x * x; }
+            for (int d = 0; d < hd; ++d) { const float x = up16(src[d]); ss += x * x; }
             s = rt / (sqrtf(ss) + NORM_EPS);
         }
-        for (int d = 0; d < hd; ++d) dst[d] = which < 2 ? f2bf(bf2f(src[d]) * s) : src[d];
+        for (int d = 0; d < hd; ++d) dst[d] = which < 2 ? cvt16(up16(src[d]) * s) : src[d];
     }
 }
 
@@ -53,12 +53,12 @@ __global__ void qkv_merge_bwd_generic_kernel(const bf16_t* __restrict__ qkv, int
         }
         float ss = 0.f, dot = 0.f;
         for (int d = 0; d < hd; ++d) {
-            const float x = bf2f(qkv[moff + d]);
+            const float x = up16(qkv[moff + d]);
             ss += x * x;
-            dot += x * bf2f(g[d]);
+            dot += x * up16(g[d]);
         }
         const float n = sqrtf(ss), s = rt / (n + NORM_EPS), c = dot / (fmaxf(n, 1e-30f) * (n + NORM_EPS));
-        for (int d = 0; d < hd; ++d) dqkv[moff + d] = f2bf(s * (bf2f(g[d]) - bf2f(qkv[moff + d]) * c));
+        for (int d = 0; d < hd; ++d) dqkv[moff + d] = cvt16(s * (up16(g[d]) - up16(qkv[moff + d]) * c));
     }
 }
 
@@ -68,7 +68,7 @@ template <int HD>
 __device__ __forceinline__ void stage_f32(float* dst, const bf16_t* __restrict__ src, long ld, int rows, int hd, int tid, int nth) {
     for (int i = tid; i < rows * HD; i += nth) {
         const int r = i / HD, d = i % HD;
-        dst[i] = d < hd ? bf2f(src[(size_t)r * ld + d]) : 0.f;
+        dst[i] = d < hd ? up16(src[(size_t)r * ld + d]) : 0.f;
     }
 }
 template <int HD> __device__ __forceinline__ float dot_row(const float (&a)[HD], const float* __restrict__ row) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __r
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
         float q[HD], acc[HD];
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { q[d] = d < hd ? bf2f(qn[(bh * T + i) * hd + d]) : 0.f; acc[d] = 0.f; }
+        for (int d = 0; d < HD; ++d) { q[d] = d < hd ? up16(qn[(bh * T + i) * hd + d]) : 0.f; acc[d] = 0.f; }
         float l = 0.f;
         for (int j = 0; j < T; ++j) {
             const float p = __expf(dot_row<HD>(q, ks + j * HD) * scale);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __r
         }
         const float il = 1.f / l;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) if (d < hd) o[((size_t)b * T + i) * D + hh * hd + d] = f2bf(acc[d] * il);
+        for (int d = 0; d < HD; ++d) if (d < hd) o[((size_t)b * T + i) * D + hh * hd + d] = cvt16(acc[d] * il);
         lse[bh * T + i] = __logf(l);
     }
 }
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const bf16_t* __re
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
             const size_t mo = ((size_t)b * T + i) * D + hh * hd + d;
-            q[d] = d < hd ? bf2f(qn[(bh * T + i) * hd + d]) : 0.f;
-            g[d] = d < hd ? bf2f(dO[mo]) : 0.f;
-            if (d < hd) del += g[d] * bf2f(O[mo]);
+            q[d] = d < hd ? up16(qn[(bh * T + i) * hd + d]) : 0.f;
+            g[d] = d < hd ? up16(dO[mo]) : 0.f;
+            if (d < hd) del += g[d] * up16(O[mo]);
             acc[d] = 0.f;
         }
         const float ls = lse[bh * T + i];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const bf16_t* __re
             axpy_row<HD>(acc, __expf(s * scale - ls) * (dp - del) * scale, ks + j * HD);
         }
 #pragma unroll
-        for (int d = 0; d < HD; ++d) if (d < hd) dqn[(bh * T + i) * hd + d] = f2bf(acc[d]);
+        for (int d = 0; d < HD; ++d) if (d < hd) dqn[(bh * T + i) * hd + d] = cvt16(acc[d]);
         delta[bh * T + i] = del;
     }
 }
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const bf16_t* __r
         float k[HD], vv[HD], ak[HD], av[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
-            k[d] = d < hd ? bf2f(kn[(bh * T + j) * hd + d]) : 0.f;
-            vv[d] = d < hd ? bf2f(v[(bh * T + j) * hd + d]) : 0.f;
+            k[d] = d < hd ? up16(kn[(bh * T + j) * hd + d]) : 0.f;
+            vv[d] = d < hd ? up16(v[(bh * T + j) * hd + d]) : 0.f;
             ak[d] = 0.f; av[d] = 0.f;
         }
         for (int i = 0; i < T; ++i) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const bf16_t* __r
             axpy_row<HD>(ak, p * (dp - dl[i]) * scale, qs + i * HD);
         }
 #pragma unroll
-        for (int d = 0; d < HD; ++d) if (d < hd) { dkn[(bh * T + j) * hd + d] = f2bf(ak[d]); dv[(bh * T + j) * hd + d] = f2bf(av[d]); }
+        for (int d = 0; d < HD; ++d) if (d < hd) { dkn[(bh * T + j) * hd + d] = cvt16(ak[d]); dv[(bh * T + j) * hd + d] = cvt16(av[d]); }
     }
 }
 
@@ -198,7 +198,7 @@ int check(int T, int hd) {
     return MAPDIT_OK;
 }
 
-}  // namespace
+MD_NS_CLOSE
 
 #define GEN_DISPATCH(hd_, CALL)                                            \
     if (hd_ <= 32) { constexpr int HDT = 32; CALL; }                        \
@@ -206,7 +206,7 @@ int check(int T, int hd) {
     else if (hd_ <= 72) { constexpr int HDT = 72; CALL; }                   \
     else { constexpr int HDT = 96; CALL; }
 
-extern "C" int mapdit_qkv_split_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
+extern "C" int MD_SYM(qkv_split_generic)(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
                                         uint16_t* v, void* stream) {
     MD_CHECK(qkv && qn && kn && v, "qkv_split_generic: null argument");
     const long n = (long)B * T * H;
@@ -215,7 +215,7 @@ extern "C" int mapdit_qkv_split_generic(const uint16_t* qkv, int B, int T, int H
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_qkv_merge_bwd_generic(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+extern "C" int MD_SYM(qkv_merge_bwd_generic)(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
                                             const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream) {
     MD_CHECK(qkv && dqn && dkn && dv && dqkv, "qkv_merge_bwd_generic: null argument");
     const long n = (long)B * T * H;
@@ -225,7 +225,7 @@ extern "C" int mapdit_qkv_merge_bwd_generic(const uint16_t* qkv, int B, int T, i
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_attn_generic_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
+extern "C" int MD_SYM(attn_generic_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
                                        int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && o && lse, "attn_generic_fwd: null argument");
     if (check(T, head_dim) != MAPDIT_OK) return MAPDIT_ERR_ARG;
@@ -241,7 +241,7 @@ extern "C" int mapdit_attn_generic_fwd(const uint16_t* qn, const uint16_t* kn, c
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_attn_generic_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
+extern "C" int MD_SYM(attn_generic_bwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO,
                                        const uint16_t* O, const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn,
                                        uint16_t* dv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && dqn && dkn && dv, "attn_generic_bwd: null argument");

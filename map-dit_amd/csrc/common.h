@@ -22,6 +22,62 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// ---- the 16-bit operand format of a translation unit ---------------------------------------------------------------------
+// Every kernel file that reads or writes 16-bit GEMM / attention operands is compiled TWICE (csrc/Makefile): MAPDIT_DT = 0 with
+// bf16 operands (entry points mapdit_<name>) and MAPDIT_DT = 1 with IEEE fp16 operands (mapdit_<name>_f16), the same source
+// otherwise.  fp16 issues on the MFMA pipe at the bf16 rate and carries TF32's 10-bit mantissa: it is what puts the fast engine
+// inside the reference's fp32/TF32 tolerance (mapdit.h, MAPDIT_PREC_F16).  In the shared code a 16-bit element is a `bf16_t`
+// (raw bits) whatever the format; conversions go through cvt16 / up16 / pack16 / lo16 / hi16 and products through MFMA16 / MFMA32.
+// f2bf / bf2f / pack2bf above stay bf16 in both builds: the two-term split operands of the fp32-accurate GEMMs are always bf16.
+#ifndef MAPDIT_DT
+#define MAPDIT_DT 0
+#endif
+#if MAPDIT_DT == 1
+#define MD_SYM(name) mapdit_##name##_f16
+#define MD_TU(name) name##_f16
+#define MD_SYM_GEMM mapdit_gemm_f16
+#define MD_SYM_F32_TO_16 mapdit_f32_to_f16
+#define MD_SYM_F32_TO_16_2D mapdit_f32_to_f16_2d
+#define MD_SYM_MPSILU_TO_16 mapdit_mpsilu_to_f16
+#else
+#define MD_SYM(name) mapdit_##name
+#define MD_TU(name) name
+#define MD_SYM_GEMM mapdit_gemm_bf16
+#define MD_SYM_F32_TO_16 mapdit_f32_to_bf16
+#define MD_SYM_F32_TO_16_2D mapdit_f32_to_bf16_2d
+#define MD_SYM_MPSILU_TO_16 mapdit_mpsilu_to_bf16
+#endif
+// kernels live in an anonymous namespace; the fp16 build adds a named level so that profiles tell the two builds' kernels apart
+#if MAPDIT_DT == 1
+#define MD_NS_OPEN namespace { namespace f16 {
+#define MD_NS_CLOSE } using namespace f16; }
+#else
+#define MD_NS_OPEN namespace {
+#define MD_NS_CLOSE }
+#endif
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+#if MAPDIT_DT == 1
+__device__ __forceinline__ bf16_t cvt16(float x) { return __builtin_bit_cast(bf16_t, (_Float16)x); }        // v_cvt_f16_f32, RNE
+__device__ __forceinline__ float up16(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint32_t pack16(float lo, float hi) {                                             // v_cvt_pk_f16_f32
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w).x; }
+__device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w).y; }       // v_cvt_f32_f16 sdwa WORD_1
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0)
+#else
+__device__ __forceinline__ bf16_t cvt16(float x) { return f2bf(x); }
+__device__ __forceinline__ float up16(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ uint32_t pack16(float lo, float hi) { return pack2bf(lo, hi); }
+__device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -65,6 +121,7 @@ __device__ __forceinline__ float dmpsilu_f(float x) {
         return v_;                                                                                     \
     }())
 int mapdit_dev_error_take_embed(hipStream_t st, int* out);
+int mapdit_dev_error_take_embed_f16(hipStream_t st, int* out);
 int mapdit_dev_error_take_diffusion(hipStream_t st, int* out);
 int mapdit_dev_error_take_precise(hipStream_t st, int* out);
 

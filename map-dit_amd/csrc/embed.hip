@@ -2,9 +2,14 @@
 // All are small or HBM-bound; the FLOP-carrying parts go through mapdit_gemm_bf16.
 #include "common.h"
 
+#if MAPDIT_DT == 1
+MAPDIT_DEFINE_DEV_ERROR(embed_f16)
+#define g_dev_error_embed g_dev_error_embed_f16
+#else
 MAPDIT_DEFINE_DEV_ERROR(embed)
+#endif
 
-namespace {
+MD_NS_OPEN
 
 #define C5 0.70710678118654752f   // mp_sum(a, b, 0.5) = (a + b) * 0.5 / sqrt(0.5)   (src/utils.py:15-16, dit.py:84,88)
 
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
     if (patches && blockIdx.y == 0) {
         for (int i = threadIdx.x; i < 64 * ldp; i += 256) {
             const int tok = i / ldp, j = i % ldp;
-            if (m0 + tok < M) patches[(m0 + tok) * ldp + j] = f2bf(j < P1 ? ps[tok * P1 + j] : 0.f);
+            if (m0 + tok < M) patches[(m0 + tok) * ldp + j] = cvt16(j < P1 ? ps[tok * P1 + j] : 0.f);
         }
     }
     const int d = threadIdx.x % DT;
@@ -68,7 +73,7 @@ __global__ void fourier_kernel(const long* __restrict__ t, const float* __restri
     float prod = (float)t[b] * scale[f];
     asm volatile("" : "+v"(prod));     // opaque to the optimiser: no contraction into v_fma (build uses -ffp-contract=fast)
     const float arg = prod + shift[f];
-    out[i] = f2bf(1.41421356237309515f * cosf(arg));
+    out[i] = cvt16(1.41421356237309515f * cosf(arg));
 }
 
 // ---- c = mp_sum(t_emb, y_emb, 0.5); also MPSiLU(c) and c as bf16 GEMM operands (dit.py:86-88) ------------------------
@@ -81,8 +86,8 @@ __global__ void cond_combine_kernel(const float* __restrict__ temb, const float*
     const long label = MAPDIT_CHECKED_INDEX(embed, y[b], table_rows, MAPDIT_DEVERR_LABEL);
     const float v = (temb[i] + table[(size_t)label * D + d]) * C5;
     c[i] = v;
-    c_silu[i] = f2bf(silu_f(v) * (1.f / MP_SILU_DIV));
-    c_bf[i] = f2bf(v);
+    c_silu[i] = cvt16(silu_f(v) * (1.f / MP_SILU_DIV));
+    c_bf[i] = cvt16(v);
 }
 
 // Backward of the above: dc = dcs * dmpsilu(c) + dc_direct;  dtemb = C5*dc (bf16 operand);  dtable[y] += C5*dc.
@@ -95,7 +100,7 @@ __global__ void cond_combine_bwd_kernel(const float* __restrict__ c, const float
     if (d >= D) return;
     const int i = b * D + d;
     const float dc = (dcs[i] * dmpsilu_f(c[i]) + dcd[i]) * C5;
-    dtemb[i] = f2bf(dc);
+    dtemb[i] = cvt16(dc);
     const long label = y[b];
     if (label < 0 || label >= table_rows) {              // the forward clamped it and flagged the call; never write out of bounds
         g_dev_error_embed = MAPDIT_DEVERR_LABEL;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restr
                                                           const float* __restrict__ a_mean, const float* __restrict__ a_sigma,
                                                           const float* __restrict__ ref_mean, const float* __restrict__ ref_sigma,
                                                           bf16_t* __restrict__ dlin, int ldd, bf16_t* __restrict__ da_bf,
-                                                          float* __restrict__ dref_part, int C, int S, int p) {
+                                                          float* __restrict__ dref_part, int C, int S, int p, float gscale) {
     __shared__ float red[2][4];
     const int n = blockIdx.x;
     const int grid = S / p, P = p * p * C, T = grid * grid;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restr
         const float go = dout[(size_t)n * per + e];
         const float l = lin[((size_t)n * T + t) * ldl + chunk * P + j];
         if (chunk == 0) sm += go * l; else ss += go * l;
-        dlin[((size_t)n * T + t) * ldd + chunk * P + j] = f2bf(go * (chunk == 0 ? gm : gs));
+        dlin[((size_t)n * T + t) * ldd + chunk * P + j] = cvt16(gscale * go * (chunk == 0 ? gm : gs));
     }
     sm = wave_sum(sm);
     ss = wave_sum(ss);
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void final_out_bwd_kernel(const float* __restr
         const float dang = dg * g * (1.f - g) * 0.35355339059327379f;
         const float* ref = which == 0 ? ref_mean : ref_sigma;
         const float* a = (which == 0 ? a_mean : a_sigma) + n * 8;
-        da_bf[((size_t)which * gridDim.x + n) * 8 + j] = f2bf(dang * ref[j]);
+        da_bf[((size_t)which * gridDim.x + n) * 8 + j] = cvt16(gscale * dang * ref[j]);
         dref_part[((size_t)n * 2 + which) * 8 + j] = dang * a[j];
     }
 }
@@ -195,9 +200,9 @@ __global__ void cfg_combine_kernel(const float* __restrict__ in, float* __restri
     out[i] = unc + s * (cond - unc);
 }
 
-}  // namespace
+MD_NS_CLOSE
 
-extern "C" int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
+extern "C" int MD_SYM(patch_embed_fwd)(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
                                       int ldp, int N, int C, int S, int p, int D, void* stream) {
     MD_CHECK(x && w_eff && pos && out, "patch_embed_fwd: null argument");
     MD_CHECK(S % p == 0 && D % 128 == 0, "patch_embed_fwd: S=%d p=%d D=%d unsupported", S, p, D);
@@ -219,6 +224,7 @@ extern "C" int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const 
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift, uint16_t* out, int n, int F,
                                   void* stream) {
     MD_CHECK(t && scale && shift && out && n > 0, "fourier_fwd: null/empty argument");
@@ -227,8 +233,9 @@ extern "C" int mapdit_fourier_fwd(const int64_t* t, const float* scale, const fl
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
-extern "C" int mapdit_cond_combine_fwd(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
+extern "C" int MD_SYM(cond_combine_fwd)(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
                                        uint16_t* c_bf, int n, int D, int table_rows, void* stream) {
     MD_CHECK(temb && table && y && c && c_silu && c_bf && n > 0 && table_rows > 0, "cond_combine_fwd: null/empty argument");
     hipLaunchKernelGGL(cond_combine_kernel, dim3(cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, temb, table,
@@ -237,7 +244,7 @@ extern "C" int mapdit_cond_combine_fwd(const float* temb, const float* table, co
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_cond_combine_bwd(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
+extern "C" int MD_SYM(cond_combine_bwd)(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,
                                        float* dtable, int n, int D, int table_rows, void* stream) {
     MD_CHECK(c && dcs && dcd && y && dtemb && dtable && n > 0 && table_rows > 0, "cond_combine_bwd: null/empty argument");
     hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, (hipStream_t)stream, c, dcs, dcd,
@@ -246,6 +253,7 @@ extern "C" int mapdit_cond_combine_bwd(const float* c, const float* dcs, const f
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_mean, const float* a_sigma, const float* ref_mean,
                                     const float* ref_sigma, float* out, int N, int C, int S, int p, void* stream) {
     MD_CHECK(lin && a_mean && a_sigma && ref_mean && ref_sigma && out, "final_out_fwd: null argument");
@@ -255,21 +263,23 @@ extern "C" int mapdit_final_out_fwd(const float* lin, int ldl, const float* a_me
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
-extern "C" int mapdit_final_out_bwd(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
+extern "C" int MD_SYM(final_out_bwd)(const float* dout, const float* lin, int ldl, const float* a_mean, const float* a_sigma,
                                     const float* ref_mean, const float* ref_sigma, uint16_t* dlin, int ldd, uint16_t* da_bf,
-                                    float* dref_part, float* dref_mean, float* dref_sigma, int N, int C, int S, int p,
-                                    void* stream) {
+                                    float* dref_part, float* dref_mean, float* dref_sigma, float grad_scale, int N, int C, int S,
+                                    int p, void* stream) {
     MD_CHECK(dout && lin && a_mean && a_sigma && ref_mean && ref_sigma && dlin && da_bf && dref_part && dref_mean && dref_sigma,
              "final_out_bwd: null argument");
     hipLaunchKernelGGL(final_out_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dout, lin, ldl, a_mean, a_sigma,
-                       ref_mean, ref_sigma, dlin, ldd, da_bf, dref_part, C, S, p);
+                       ref_mean, ref_sigma, dlin, ldd, da_bf, dref_part, C, S, p, grad_scale);
     MD_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_dref_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dref_part, N, dref_mean, dref_sigma);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_cfg_combine(const float* model_out, float* out, int n_total, int C, int HW, float cfg_scale, void* stream) {
     MD_CHECK(model_out && out && n_total > 0 && n_total % 2 == 0, "cfg_combine: batch must be even and non-empty");
     const long total = (long)n_total * 2 * C * HW;
@@ -278,3 +288,4 @@ extern "C" int mapdit_cfg_combine(const float* model_out, float* out, int n_tota
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif

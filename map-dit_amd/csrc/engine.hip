@@ -54,6 +54,8 @@ struct mapdit_engine {
     int MW = 0, o_sha = 0, o_sca = 0, o_ga = 0, o_shm = 0, o_scm = 0, o_gm = 0;
     float *zero_rows = nullptr, *sink_rows = nullptr, *zero_gain = nullptr, *sink_gain = nullptr;   // rotation mode: see engine_create
     bool generic_attn = false;
+    bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
+    float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
     int last_N = 0;
     int next_stage = 0;                   // backward stage expected next (stages run in order)
     bool have_saved = false;
@@ -300,9 +302,11 @@ size_t carve(mapdit_engine* e, void* base) {
 int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c, "engine: null config");
     MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
-    MD_CHECK(c->precision == MAPDIT_PREC_BF16 || c->precision == MAPDIT_PREC_BF16X3, "engine: unknown precision %d", c->precision);
+    MD_CHECK(c->precision == MAPDIT_PREC_BF16 || c->precision == MAPDIT_PREC_BF16X3 || c->precision == MAPDIT_PREC_F16,
+             "engine: unknown precision %d", c->precision);
+    MD_CHECK(c->loss_scale >= 0.f && (c->loss_scale == 0.f || c->precision == MAPDIT_PREC_F16), "engine: loss_scale is an fp16 setting (>= 0)");
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
-    MD_CHECK(!c->rotation || c->precision == MAPDIT_PREC_BF16, "engine: rotation modulation is built for the bf16 engine only");
+    MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
              "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
     MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
@@ -332,6 +336,7 @@ void init_dims(mapdit_engine* e) {
     e->M_max = c.max_batch * e->T;
     const int D = c.hidden;
     e->rot = c.rotation != 0;
+    e->f16 = c.precision == MAPDIT_PREC_F16;
     e->MW = (e->rot ? 5 : 6) * D;
     if (e->rot) { e->o_sha = 0; e->o_sca = D / 2; e->o_ga = D / 2 + D; e->o_shm = D / 2 + 2 * D; e->o_scm = 3 * D; e->o_gm = 4 * D; }
     else { e->o_sha = 0; e->o_sca = D; e->o_ga = 2 * D; e->o_shm = 3 * D; e->o_scm = 4 * D; e->o_gm = 5 * D; }
@@ -345,6 +350,22 @@ void init_dims(mapdit_engine* e) {
 
 int gemm(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, const mapdit_epilogue_t& ep, void* st) {
     return mapdit_gemm_bf16(layout, M, N, K, A, lda, B, ldb, &ep, st);
+}
+// The 16-bit operands of a bf16 / fp16 engine (activations, activation gradients, weight images): the entry point of its format.
+// (The two-term split operands of the fp32-accurate products are bf16 in every engine: those go through gemm() above.)
+#define DT_FN(e, name) ((e)->f16 ? name##_f16 : name)
+int gemm16(const mapdit_engine* e, int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb,
+           const mapdit_epilogue_t& ep, void* st) {
+    return (e->f16 ? mapdit_gemm_f16 : mapdit_gemm_bf16)(layout, M, N, K, A, lda, B, ldb, &ep, st);
+}
+int to16(const mapdit_engine* e, const float* x, bf16_t* out, long n, float alpha, void* st) {
+    return (e->f16 ? mapdit_f32_to_f16 : mapdit_f32_to_bf16)(x, out, n, alpha, st);
+}
+int to16_2d(const mapdit_engine* e, const float* x, int ldx, bf16_t* out, int ldo, int rows, int cols, float alpha, void* st) {
+    return (e->f16 ? mapdit_f32_to_f16_2d : mapdit_f32_to_bf16_2d)(x, ldx, out, ldo, rows, cols, alpha, st);
+}
+int mpsilu16(const mapdit_engine* e, const float* x, bf16_t* out, long n, void* st) {
+    return (e->f16 ? mapdit_mpsilu_to_f16 : mapdit_mpsilu_to_bf16)(x, out, n, st);
 }
 mapdit_epilogue_t epi_bf16(bf16_t* out, int ldo) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
@@ -417,25 +438,27 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     a.part_scratch = e->rmb_part;                       // lets small batches take the row-split form (more blocks)
     a.part_scratch_bytes = (size_t)8 * e->cfg.max_batch * 3 * D * sizeof(float);
     a.gain_partials_out = &npart;
+    a.dgain_scale = e->ginv;                            // fp16: the gradients carry the loss scale, the gain gradient must not
     if (rot) {
-        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
-        TRY(mapdit_rotate_bwd(e->dxm, rot->y, rot->theta, e->ldm, rot->gain, rot->dtheta, e->ldm, e->gain_part, a.n_samples, a.T, D, st));
+        TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
+        TRY(DT_FN(e, mapdit_rotate_bwd)(e->dxm, rot->y, rot->theta, e->ldm, rot->gain, rot->dtheta, e->ldm, e->gain_part, e->ginv,
+                                        a.n_samples, a.T, D, st));
         TRY(mapdit_reduce_partials(e->gain_part, a.n_samples * (D / 128), dgain, 0, st));
         a.dxm = e->dxm;
-        TRY(mapdit_resid_mod_bwd(&a, st));              // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
+        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&a, st));    // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
         return MAPDIT_OK;
     }
-    if (!no_fuse && e->T % 64 == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
+    if (!no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
         a.dxm = nullptr;
-        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, ep, st));
+        TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, ep, st));
         npart = cdiv(M, 256) * cdiv(D, 256);
     } else {
-        TRY(gemm(MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
+        TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
         a.dxm = e->dxm;
         a.dgain_out = dgain;                            // the gain partials are summed by the pass itself (npart = 0 then)
-        TRY(mapdit_resid_mod_bwd(&a, st));
+        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&a, st));
         if (npart == 0) return MAPDIT_OK;
     }
     return mapdit_reduce_partials(e->gain_part, npart, dgain, 0, st);
@@ -448,10 +471,10 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
     // in a fixed order, by the weight-norm backward that consumes G anyway.
     const long slab = (long)w.rows * w.cols;
     const int split = pick_split_k(w.rows, w.cols, K, e->G_cap / slab);
-    mapdit_epilogue_t ep = epi_f32(e->G, w.cols, alpha);
+    mapdit_epilogue_t ep = epi_f32(e->G, w.cols, alpha * e->ginv);      // (fp16: dy carries the loss scale, the weight gradient does not)
     ep.split_k = split;
     ep.slab_stride = slab;
-    TRY(gemm(MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
+    TRY(gemm16(e, MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
     if (e->grads[pidx])
         TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
     return MAPDIT_OK;
@@ -460,14 +483,14 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
 }  // namespace
 
 extern "C" int mapdit_device_error_poll(void* stream) {
-    int a = 0, b = 0, c = 0;
-    const int rc = mapdit_dev_error_take_embed((hipStream_t)stream, &a) | mapdit_dev_error_take_diffusion((hipStream_t)stream, &b) |
-                   mapdit_dev_error_take_precise((hipStream_t)stream, &c);
+    int a = 0, a2 = 0, b = 0, c = 0;
+    const int rc = mapdit_dev_error_take_embed((hipStream_t)stream, &a) | mapdit_dev_error_take_embed_f16((hipStream_t)stream, &a2) |
+                   mapdit_dev_error_take_diffusion((hipStream_t)stream, &b) | mapdit_dev_error_take_precise((hipStream_t)stream, &c);
     if (rc) {
         mapdit_set_error("device_error_poll: reading the device error words failed");
         return MAPDIT_ERR_HIP;
     }
-    const int code = a | b | c;
+    const int code = a | a2 | b | c;
     if (code & MAPDIT_DEVERR_LABEL) {
         mapdit_set_error("index out of range: a class label outside [0, embedding rows) reached the label embedding (the kernels "
                          "clamped it; results of that call are invalid)");
@@ -590,7 +613,7 @@ extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host,
         e->wn_jobs.push_back(j);
         e->wn_blocks += (rows + 3) / 4;
     };
-    if (e->cfg.precision == MAPDIT_PREC_BF16) {
+    if (e->cfg.precision != MAPDIT_PREC_BF16X3) {
         for (size_t i = 0; i < e->wimg.size(); ++i)
             if (e->wimg[i].img)                 // (+ the split image of a conditioning weight: fp32-accurate conditioning forward)
                 job(e->params[i], e->wimg[i].rows, e->wimg[i].cols, 1.f, e->wimg[i].img, nullptr,
@@ -611,7 +634,7 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
             MD_CHECK(he == hipSuccess, "engine_prepare_weights: job table upload failed: %s", hipGetErrorString(he));
             e->wn_table_ready = true;
         }
-        TRY(mapdit_weightnorm_fwd_batch(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st));
+        TRY(DT_FN(e, mapdit_weightnorm_fwd_batch)(e->wn_jobs_dev, (int)e->wn_jobs.size(), e->wn_blocks, forced, st));
         // (the same launch writes the split images of the conditioning weights, cp.img3, for the fp32-accurate conditioning forward)
         return MAPDIT_OK;
     }
@@ -849,17 +872,17 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     TRY(cond_linear(e->cp.four32, FOURIER, MAPDIT_SPLIT_OP_NONE, MAPDIT_P_T0, D, e->cp.h1, D));
     TRY(cond_linear(e->cp.h1, D, MAPDIT_SPLIT_OP_MPSILU, MAPDIT_P_T2, D, e->temb, D));
     if (save) {
-        TRY(mapdit_f32_to_bf16(e->cp.four32, e->four, (long)N * FOURIER, 1.f, st));
-        TRY(mapdit_f32_to_bf16(e->cp.h1, e->h1_pre, (long)N * D, 1.f, st));
-        TRY(mapdit_mpsilu_to_bf16(e->cp.h1, e->h1_act, (long)N * D, st));
+        TRY(to16(e, e->cp.four32, e->four, (long)N * FOURIER, 1.f, st));
+        TRY(to16(e, e->cp.h1, e->h1_pre, (long)N * D, 1.f, st));
+        TRY(mpsilu16(e, e->cp.h1, e->h1_act, (long)N * D, st));
     }
-    TRY(mapdit_cond_combine_fwd(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));
+    TRY(DT_FN(e, mapdit_cond_combine_fwd)(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));
     if (save) {
         hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
         MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
     }
     // patch embedding                                                  (dit.py:81-84)
-    TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], save ? e->patches : nullptr, e->ldp, N,
+    TRY(DT_FN(e, mapdit_patch_embed_fwd)(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], save ? e->patches : nullptr, e->ldp, N,
                                c.in_channels, c.input_size, c.patch, D, st));
     // (shift, scale, gate) x 2 of EVERY block = MPLinearChunk(MPSiLU(c)) (dit_block.py:33) as ONE GEMM against the
     // contiguous [L*6D, D] weight image, plus the final layer's (shift, scale); all later modulate()s are fused into
@@ -871,7 +894,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // rotation modulation: the fused modulates run with shift = 0, gain = 0 (u = x * scale) and mapdit_rotate_fwd turns u in place
     const float* sh_base = e->rot ? e->zero_rows : e->mod_all;            // where the "shift" chunks are read from
     auto gain_of = [&](int pidx) -> const float* { return e->rot ? e->zero_gain : e->params[pidx]; };
-    TRY(mapdit_modulate_fwd(e->X[0], sh_base + e->o_sha, e->mod_all + e->o_sca, ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)),
+    TRY(DT_FN(e, mapdit_modulate_fwd)(e->X[0], sh_base + e->o_sha, e->mod_all + e->o_sca, ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)),
                             e->blk[0].xm, N, T, D, st));
     for (int i = 0; i < L; ++i) {
         BlockBufs& b = e->blk[save ? i : 0];
@@ -881,11 +904,11 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         float* xmid = e->X[save ? 2 * i + 1 : (2 * i + 1) % 3];
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
         const float* gmlp = gain_of(pidx_block(i, MAPDIT_B_GAIN_MLP));
-        if (e->rot) TRY(mapdit_rotate_fwd(b.xm, mod + e->o_sha, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], N, T, D, st));
+        if (e->rot) TRY(DT_FN(e, mapdit_rotate_fwd)(b.xm, mod + e->o_sha, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], N, T, D, st));
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         if (e->generic_attn) {
-            TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
-            TRY(mapdit_qkv_split(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
+            TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
+            TRY(DT_FN(e, mapdit_qkv_split)(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
         } else {   // head split + cosine normalisation of q, k in the GEMM epilogue (attention.py:38-43)
             mapdit_epilogue_t ep;
             memset(&ep, 0, sizeof(ep));
@@ -893,18 +916,18 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
             ep.out = b.qn; ep.out2 = b.kn; ep.out3 = b.v; ep.out4 = b.qks;
             ep.rows_per_sample = T;
             ep.alpha = 1.f;
-            TRY(gemm(MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
+            TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
         }
-        TRY(mapdit_attn_cos_fwd(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
-        TRY(gemm(MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
+        TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, shm + e->o_shm, mod + e->o_scm, ldm, gmlp), st));
-        if (e->rot) TRY(mapdit_rotate_fwd(b.xm2, mod + e->o_shm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], N, T, D, st));
+        if (e->rot) TRY(DT_FN(e, mapdit_rotate_fwd)(b.xm2, mod + e->o_shm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], N, T, D, st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
-        TRY(gemm(MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
+        TRY(gemm16(e, MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
-        TRY(gemm(MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
+        TRY(gemm16(e, MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
                  i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
                                        shm + e->MW + e->o_sha, mod + e->MW + e->o_sca, ldm, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)))
                            : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
@@ -913,7 +936,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     float* xL = e->X[save ? 2 * L : (2 * L) % 3];
     // final layer                                                       (final_layer.py:53-59, dit.py:96-101)
     (void)xL;   // xmodf = modulate(xL, ...) was written by the last block's fc2 epilogue
-    TRY(gemm(MAPDIT_NT, M, 2 * e->P, D, e->xmodf, D, W(MAPDIT_P_F_LIN), D, epi_f32(e->lin, 2 * e->P), st));
+    TRY(gemm16(e, MAPDIT_NT, M, 2 * e->P, D, e->xmodf, D, W(MAPDIT_P_F_LIN), D, epi_f32(e->lin, 2 * e->P), st));
     TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_NONE, st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_MS_LIN], 3 * D, epi_f32(e->a_mean, NSCALE), st));
     TRY(gemm(MAPDIT_NT, N, NSCALE, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_SS_LIN], 3 * D, epi_f32(e->a_sigma, NSCALE), st));
@@ -928,7 +951,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
 extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long* elems, int* ld, int* dtype) {
     MD_CHECK(e && ptr && elems && ld && dtype, "engine_peek: null argument");
     MD_CHECK(e->have_saved && e->last_N > 0, "engine_peek: needs a forward with save=1 first");
-    MD_CHECK(e->cfg.precision == MAPDIT_PREC_BF16, "engine_peek: the intermediates listed are those of the bf16 engine");
+    MD_CHECK(e->cfg.precision != MAPDIT_PREC_BF16X3, "engine_peek: the intermediates listed are those of the bf16 / fp16 engines");
     MD_CHECK(what >= 0 && what < MAPDIT_PEEK_COUNT, "engine_peek: unknown id %d", what);
     const bool per_block = what >= MAPDIT_PEEK_B_XM;
     MD_CHECK(!per_block || (block >= 0 && block < e->cfg.depth), "engine_peek: block %d outside 0..%d", block, e->cfg.depth - 1);
@@ -958,6 +981,7 @@ extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void*
         case MAPDIT_PEEK_B_XMID: p = e->X[2 * block + 1]; n = M * D; dt = 0; break;
         case MAPDIT_PEEK_B_XOUT: p = e->X[2 * block + 2]; n = M * D; dt = 0; break;
     }
+    if (dt == 1 && e->f16) dt = 2;
     *ptr = p; *elems = n; *ld = l; *dtype = dt;
     return MAPDIT_OK;
 }
@@ -983,6 +1007,15 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     auto W = [&](int idx) { return e->wimg[idx].img; };
     auto G = [&](int idx) { return e->grads[idx]; };
     if (stage_from == 0) {
+    // fp16: the whole backward runs on gradients multiplied by a power of two (mapdit_config_t.loss_scale) so that the 16-bit
+    // activation gradients sit in fp16's normal range; each parameter gradient is divided by it where it is written (the dW GEMMs'
+    // alpha, the weight-norm Jacobian's scale, the gain partials).  bf16 has fp32's exponent range: scale 1.
+    e->lscale = 1.f;
+    if (e->f16) {
+        e->lscale = c.loss_scale > 0.f ? c.loss_scale
+                                       : exp2f(floorf(log2f((float)N * c.in_channels * c.input_size * c.input_size)) - 5.f);
+    }
+    e->ginv = 1.f / e->lscale;
     hipError_t he = hipMemsetAsync(e->dcs, 0, (size_t)N * D * 4, hs);
     if (he == hipSuccess) he = hipMemsetAsync(e->dcd, 0, (size_t)N * D * 4, hs);
     if (he == hipSuccess) he = hipMemsetAsync(e->dtable, 0, (size_t)c.table_rows * D * 4, hs);
@@ -992,13 +1025,13 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     MD_CHECK(G(MAPDIT_P_MS_REF) && G(MAPDIT_P_SS_REF), "engine_backward: gradient buffers not bound");
 
     // ---- final layer ---------------------------------------------------------------------------------------
-    TRY(mapdit_final_out_bwd(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF], e->dlin,
-                             e->ldl, e->da_bf, e->dref_part, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), N, c.in_channels, c.input_size,
-                             c.patch, st));
+    TRY(DT_FN(e, mapdit_final_out_bwd)(dout, e->lin, P2, e->a_mean, e->a_sigma, e->params[MAPDIT_P_MS_REF], e->params[MAPDIT_P_SS_REF],
+                                        e->dlin, e->ldl, e->da_bf, e->dref_part, G(MAPDIT_P_MS_REF), G(MAPDIT_P_SS_REF), e->lscale, N,
+                                        c.in_channels, c.input_size, c.patch, st));
     for (int w = 0; w < 2; ++w) {
         const int pi = w == 0 ? MAPDIT_P_MS_LIN : MAPDIT_P_SS_LIN;
         const bf16_t* da = e->da_bf + (size_t)w * N * NSCALE;
-        TRY(gemm(MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
+        TRY(gemm16(e, MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
         TRY(linear_dw(e, pi, da, NSCALE, e->c_bf, D, N, 1.f, st));
     }
     TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, e->ldl, e->xmodf, D, M, 1.f, st));
@@ -1012,8 +1045,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
         TRY(dx_resid_mod_bwd(e, M, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), a, G(MAPDIT_P_F_GAIN), st));
     }
-    TRY(mapdit_f32_to_bf16(e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
-    TRY(gemm(MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
+    TRY(to16(e, e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
+    TRY(gemm16(e, MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
     TRY(linear_dw(e, MAPDIT_P_F_MOD, e->dmod_bf, 2 * D, e->c_silu, D, N, 1.f, st));
     }   // stage 0
 
@@ -1029,7 +1062,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         const float* shm = (e->rot ? e->zero_rows : e->mod_all) + (size_t)i * e->MW;
         float* dshm = (e->rot ? e->sink_rows : e->dmod) + (size_t)i * e->MW;
         // MLP branch
-        TRY(gemm(MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
+        TRY(gemm16(e, MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
@@ -1044,13 +1077,13 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
                                  e->rot ? &rb : nullptr));
         }
         // attention branch: dy now holds the grad of the attention branch output y_i
-        TRY(gemm(MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
+        TRY(gemm16(e, MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
         if (e->generic_attn) {
-            TRY(mapdit_attn_cos_bwd(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
-            TRY(mapdit_qkv_merge_bwd(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
+            TRY(DT_FN(e, mapdit_attn_cos_bwd)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
+            TRY(DT_FN(e, mapdit_qkv_merge_bwd)(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
         } else {   // normalisation Jacobian + head merge inside the attention backward passes
-            TRY(mapdit_attn_cos_bwd_fused(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, b.qks, e->dqkv, N, T, H, e->hd, st));
+            TRY(DT_FN(e, mapdit_attn_cos_bwd_fused)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, b.qks, e->dqkv, N, T, H, e->hd, st));
         }
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
@@ -1073,7 +1106,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         }
         // modulation linear of this block (its six gradient chunks are complete now): dW here, so the block's gradient
         // slice is final when its stage ends (the DP reducer relies on that); d c_silu for all blocks in one GEMM below
-        TRY(mapdit_f32_to_bf16_2d(dmod, ldm, e->dmod_bf + (size_t)i * e->MW, ldm, N, e->MW, 1.f, st));
+        TRY(to16_2d(e, dmod, ldm, e->dmod_bf + (size_t)i * e->MW, ldm, N, e->MW, 1.f, st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * e->MW, ldm, e->c_silu, D, N, 1.f, st));
         if (i == 0) {
             // d c_silu += dmod_all W_mod_all: ONE split-K GEMM over K = L*6D, slabs summed into dcs
@@ -1081,7 +1114,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
             const long slab = (long)N * D;
             ep.split_k = pick_split_k(N, D, ldm, e->G_cap / slab);
             ep.slab_stride = slab;
-            TRY(gemm(MAPDIT_NN, N, D, ldm, e->dmod_bf, ldm, W(pidx_block(0, MAPDIT_B_MOD)), D, ep, st));
+            TRY(gemm16(e, MAPDIT_NN, N, D, ldm, e->dmod_bf, ldm, W(pidx_block(0, MAPDIT_B_MOD)), D, ep, st));
             TRY(mapdit_sum_slabs(e->dcs, e->G, ep.split_k, slab, slab, st));
         }
     }
@@ -1092,16 +1125,17 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     {
         const float c5 = 0.70710678118654752f;
         const long slab = (long)D * e->ldp;
-        mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5);
+        mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5 * e->ginv);
         ep.split_k = pick_split_k(D, e->ldp, M, e->G_cap / slab);
         ep.slab_stride = slab;
-        TRY(gemm(MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, ep, st));
+        TRY(gemm16(e, MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, ep, st));
         TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
     }
     // ---- conditioning path ------------------------------------------------------------------------------------------
-    TRY(mapdit_cond_combine_bwd(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, c.table_rows, st));
-    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D), 0, st));
-    TRY(gemm(MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
+    TRY(DT_FN(e, mapdit_cond_combine_bwd)(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, c.table_rows, st));
+    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D) * e->ginv, 0,
+                              st));
+    TRY(gemm16(e, MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
     TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));
     TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));
     e->have_saved = false;

@@ -25,7 +25,7 @@
 
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 constexpr int BM = 128, BN = 128, BKT = 64;
 constexpr int TILE_BYTES = 16384;           // one operand tile, either layout
@@ -155,15 +155,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ __forceinline__ void store16_stream(void* p, u32x4_t v) { __builtin_nontemporal_store(v, (u32x4_t*)p); }
 __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
     u32x4_t u;
-    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    u.x = pack16(v[0], v[1]); u.y = pack16(v[2], v[3]); u.z = pack16(v[4], v[5]); u.w = pack16(v[6], v[7]);
     store16_stream(p, u);
 }
 __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // read-once stream (epilogue operand): nt
     const u32x4_t u = __builtin_nontemporal_load((const u32x4_t*)p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    v[0] = lo16(u.x); v[1] = hi16(u.x);
+    v[2] = lo16(u.y); v[3] = hi16(u.y);
+    v[4] = lo16(u.z); v[5] = hi16(u.z);
+    v[6] = lo16(u.w); v[7] = hi16(u.w);
 }
 
 #define EPI_TRIVIAL_STEPS                                                                                      \
@@ -178,7 +178,7 @@ struct EpiStoreBf16 {
     __device__ __forceinline__ int n_direct() const { return 1; }
     __device__ __forceinline__ bf16_t* dst(int) const { return out; }
     __device__ __forceinline__ void pw(const f32x4_t& v, u32x2_t* o, int) const {
-        o[0] = u32x2_t{pack2bf(alpha * v[0], alpha * v[1]), pack2bf(alpha * v[2], alpha * v[3])};
+        o[0] = u32x2_t{pack16(alpha * v[0], alpha * v[1]), pack16(alpha * v[2], alpha * v[3])};
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         float w[8];
@@ -230,8 +230,8 @@ struct EpiSilu2Grad {
             a[i] = v[i] * s * (1.f / MP_SILU_DIV);
             d[i] = s * (1.f + v[i] * (1.f - s)) * (1.f / MP_SILU_DIV);
         }
-        o[0] = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
-        if (nout > 1) o[1] = u32x2_t{pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+        o[0] = u32x2_t{pack16(a[0], a[1]), pack16(a[2], a[3])};
+        if (nout > 1) o[1] = u32x2_t{pack16(d[0], d[1]), pack16(d[2], d[3])};
     }
     // One v_exp + one v_rcp per element serve both outputs; everything else runs on two elements per instruction (v_pk_mul /
     // v_pk_add / v_pk_fma_f32 from the float2 arithmetic below): this epilogue is VALU-issue-bound - the matrix pipe idles while it
@@ -276,10 +276,10 @@ struct EpiMulAux {
     __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile&) const {
         const u32x4_t u = a.h;
         float w[8];
-        w[0] = v[0] * __uint_as_float(u.x << 16); w[1] = v[1] * __uint_as_float(u.x & 0xffff0000u);
-        w[2] = v[2] * __uint_as_float(u.y << 16); w[3] = v[3] * __uint_as_float(u.y & 0xffff0000u);
-        w[4] = v[4] * __uint_as_float(u.z << 16); w[5] = v[5] * __uint_as_float(u.z & 0xffff0000u);
-        w[6] = v[6] * __uint_as_float(u.w << 16); w[7] = v[7] * __uint_as_float(u.w & 0xffff0000u);
+        w[0] = v[0] * lo16(u.x); w[1] = v[1] * hi16(u.x);
+        w[2] = v[2] * lo16(u.y); w[3] = v[3] * hi16(u.y);
+        w[4] = v[4] * lo16(u.z); w[5] = v[5] * hi16(u.z);
+        w[6] = v[6] * lo16(u.w); w[7] = v[7] * hi16(u.w);
         store8_bf16(out + (size_t)m * ldo + n, w);
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const { apply(m, n, v, 0, load(m, n), Tile()); }
@@ -355,10 +355,10 @@ struct EpiDSilu {
     __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile&) const {
         const u32x4_t u = a.h;
         float h[8], w[8];
-        h[0] = __uint_as_float(u.x << 16); h[1] = __uint_as_float(u.x & 0xffff0000u);
-        h[2] = __uint_as_float(u.y << 16); h[3] = __uint_as_float(u.y & 0xffff0000u);
-        h[4] = __uint_as_float(u.z << 16); h[5] = __uint_as_float(u.z & 0xffff0000u);
-        h[6] = __uint_as_float(u.w << 16); h[7] = __uint_as_float(u.w & 0xffff0000u);
+        h[0] = lo16(u.x); h[1] = hi16(u.x);
+        h[2] = lo16(u.y); h[3] = hi16(u.y);
+        h[4] = lo16(u.z); h[5] = hi16(u.z);
+        h[6] = lo16(u.w); h[7] = hi16(u.w);
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = v[i] * dmpsilu_f(h[i]);
         store8_bf16(out + (size_t)m * ldo + n, w);
@@ -385,7 +385,7 @@ struct EpiRmb {
     const float* dxo; const float* x; const float* shift; const float* scale; const float* gain;
     const bf16_t* y_up; const float* g_up;
     float* dx; bf16_t* dx_bf; bf16_t* dy_up; float* dshift; float* dscale; float* dg_up; float* dgain_part;
-    int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb;
+    int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb, gscale;
     struct Aux { float4 x0, x1, d0, d1; u32x4_t y; };
     struct Tile { float4 sc0, sc1, sh0, sh1, gu0, gu1; };
     struct Acc { float sc[8], sh[8], g[8], gain; };    // running sums of the current 64-row block (gain: of the whole tile)
@@ -430,7 +430,7 @@ struct EpiRmb {
         for (int i = 0; i < 8; ++i) {
             // the unfused path sees this gradient as a bf16 tensor: round it the same way, so that a sample's gradients do not
             // depend on which path its batch size selects
-            const float vi = bf2f(f2bf(v[i]));
+            const float vi = up16(cvt16(v[i]));
             o[i] = ca * dd[i] + k * sc[i] * vi;
             r.sc[i] += k * xx[i] * vi;
             r.sh[i] += kb * vi;
@@ -445,9 +445,9 @@ struct EpiRmb {
         if (y_up) {
             const float gu[8] = {t.gu0.x, t.gu0.y, t.gu0.z, t.gu0.w, t.gu1.x, t.gu1.y, t.gu1.z, t.gu1.w};
             const u32x4_t u = a.y;
-            const float yy[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                                 __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
-                                 __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+            const float yy[8] = {lo16(u.x), hi16(u.x), lo16(u.y),
+                                 hi16(u.y), lo16(u.z), hi16(u.z),
+                                 lo16(u.w), hi16(u.w)};
             float w[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA16(fb[j], fa[i], acc[i][j]);
         }
     }
     __syncthreads();       // all fragment reads done: the staging buffers may be overwritten
@@ -847,7 +847,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+                        acc[i][j] = MFMA16(fb[j][ks], fa[i][ks], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             G256_STAMP(4);
             if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -893,7 +893,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
         __builtin_amdgcn_s_setprio(1);                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);                      \
+            acc[i][j] = MFMA16(FB[j], FA[i], acc[i][j]);                      \
         __builtin_amdgcn_s_setprio(0)
         stage_a(0, 0);
         stage_b(0);
@@ -917,7 +917,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             // finished, reads outstanding; placed after the new reads it would wait for them too
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0b[0], f0a[0], acc[0][0], 0, 0, 0);
+            acc[0][0] = MFMA16(f0b[0], f0a[0], acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
             G256_SP_READ(f1a, f1b, a_cur, t, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -926,7 +926,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0b[j], f0a[i], acc[i][j], 0, 0, 0);
+                    if (i + j > 0) acc[i][j] = MFMA16(f0b[j], f0a[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (has1) {
@@ -936,7 +936,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             G256_END_LOAD();                                   // lgkmcnt(0) + barrier
             if (has2) stage_b(t + 2);
             if (has3) stage_a(t + 3, a_cur);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[0], f1a[0], acc[0][0], 0, 0, 0);
+            acc[0][0] = MFMA16(f1b[0], f1a[0], acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
             G256_SP_READ(f0a, f0b, a_nxt, t + 1, 0);           // (after the last tile: a harmless read of stale LDS, no branch)
             __builtin_amdgcn_sched_barrier(0);
@@ -945,7 +945,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[j], f1a[i], acc[i][j], 0, 0, 0);
+                    if (i + j > 0) acc[i][j] = MFMA16(f1b[j], f1a[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             a_cur = a_nxt;
@@ -971,7 +971,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
         acc[(MQ) * 4 + i][(NQ) * 2 + j] =                                                                      \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][ks], fa[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j], 0, 0, 0); \
+            MFMA16(FB[j][ks], fa[i][ks], acc[(MQ) * 4 + i][(NQ) * 2 + j]); \
     __builtin_amdgcn_s_setprio(0)
 #define G256_WAIT_DMA(has2)                                                  \
     if (has2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              \
@@ -1270,7 +1270,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) a += gred[w];
-            epi.dgain_part[z * p.tiles + tile] = a;
+            epi.dgain_part[z * p.tiles + tile] = a * epi.gscale;
         }
         G256_STAMPS_OUT();
         return;
@@ -1348,14 +1348,14 @@ __global__ void gemm_simple_kernel(const bf16_t* __restrict__ A, long sam, long 
     const int m = (int)(id / chunks), n = (int)(id % chunks) * 8;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < K; ++k) {
-        const float a = bf2f(A[m * sam + k * sak]);
+        const float a = up16(A[m * sam + k * sak]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += a * bf2f(B[(n + i) * sbn + k * sbk]);
+        for (int i = 0; i < 8; ++i) v[i] += a * up16(B[(n + i) * sbn + k * sbk]);
     }
     epi(m, n, v);
 }
 
-}  // namespace
+MD_NS_CLOSE
 
 // Output tile edge the dispatcher uses for an [M, N] result: 256 (8-wave staggered kernel, one workgroup per CU) for
 // token-sized problems, 128 for small ones (conditioning path, final linear).  Exposed so callers can size split-K.
@@ -1375,6 +1375,7 @@ extern "C" void mapdit_debug_set_stamps_block(long long* p, int block) {      //
 #endif
 
 // A/B switches for benchmarking, read from the environment ONCE (the first launch): the launch path makes no getenv calls.
+// (One instance in the library: the bf16 build of this file owns it, the fp16 build refers to it.)
 struct GemmEnv {
     int tile = 0;        // MAPDIT_GEMM_TILE   = 128 | 256: force the tile edge
     int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule
@@ -1389,7 +1390,10 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
-static GemmEnv& gemm_env() {
+GemmEnv& mapdit_gemm_env_ref();
+static GemmEnv& gemm_env() { return mapdit_gemm_env_ref(); }
+#if MAPDIT_DT == 0
+GemmEnv& mapdit_gemm_env_ref() {
     static GemmEnv env;
     return env;
 }
@@ -1431,8 +1435,9 @@ extern "C" int mapdit_gemm_tile_size_k(int M, int N, int K, int split_k_launch) 
 }
 extern "C" int mapdit_gemm_tile_size_ex(int M, int N, int split_k_launch) { return mapdit_gemm_tile_size_k(M, N, 0, split_k_launch); }
 extern "C" int mapdit_gemm_tile_size(int M, int N) { return mapdit_gemm_tile_size_ex(M, N, 0); }
+#endif   // MAPDIT_DT == 0
 
-namespace {
+MD_NS_OPEN
 
 template <class Epi> constexpr bool kHasTail = false;
 template <> constexpr bool kHasTail<EpiStoreF32> = true;
@@ -1532,8 +1537,9 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
     return MAPDIT_OK;
 }
 
-}  // namespace
+MD_NS_CLOSE
 
+#if MAPDIT_DT == 0
 // ---- error plumbing (shared) ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 void mapdit_set_error(const char* fmt, ...) {
@@ -1543,9 +1549,10 @@ void mapdit_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mapdit_last_error(void) { return g_err; }
-extern "C" int mapdit_abi_version(void) { return 2; }
+extern "C" int mapdit_abi_version(void) { return 3; }
+#endif
 
-extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
+extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {
     MD_CHECK(layout >= MAPDIT_NT && layout <= MAPDIT_TN, "gemm: bad layout %d", layout);
     MD_CHECK(M > 0 && N > 0 && K > 0 && A && B && e, "gemm: null/empty argument (M=%d N=%d K=%d)", M, N, K);
@@ -1593,13 +1600,15 @@ extern "C" int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t*
             MD_CHECK(a->x && a->shift && a->scale && a->gain && a->dshift && a->dscale && a->dgain_part && (a->dx || a->dx_bf),
                      "gemm: RMB needs x, shift, scale, gain, dshift, dscale, dgain_part and dx or dx_bf");
             MD_CHECK(!a->y_up || (a->g_up && a->dy_up && a->dg_up), "gemm: RMB residual backward needs g_up, dy_up, dg_up");
-            MD_CHECK(a->T > 0 && a->T % 64 == 0 && M % a->T == 0 && N == a->D,
-                     "gemm: RMB needs T %% 64 == 0, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
+            // a sample's rows must lie inside ONE 256-row tile: the per-sample column sums are stored once per tile (T = 192, 512, ...
+            // would have two tiles overwrite each other's partial sums)
+            MD_CHECK(a->T > 0 && a->T % 64 == 0 && 256 % a->T == 0 && M % a->T == 0 && N == a->D,
+                     "gemm: RMB needs T in {64, 128, 256}, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
             MD_CHECK(a->ldmod % 4 == 0 && a->ldg_up % 4 == 0 && e->ldo % 8 == 0, "gemm: RMB row strides must be multiples of 4 / 8");
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiRmb{a->dxo, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx, (bf16_t*)a->dx_bf,
                                  (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod, a->ldg_up, a->ldd,
-                                 a->ldd_up, a->T, a->ca, a->cb}, st);
+                                 a->ldd_up, a->T, a->ca, a->cb, a->dgain_scale != 0.f ? a->dgain_scale : 1.f}, st);
         }
         case MAPDIT_EPI_QKV_HEADS: {
             MD_CHECK(e->out2 && e->out3 && e->out4 && e->rows_per_sample > 0, "gemm: QKV_HEADS needs out2, out3, out4, rows_per_sample");

@@ -4,7 +4,7 @@
 // Residual stream is fp32 [M, D]; GEMM operands are bf16; per-sample conditioning vectors are fp32.
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 __device__ __forceinline__ float mp_den(float t) { return sqrtf((1.f - t) * (1.f - t) + t * t); }
 
@@ -26,10 +26,10 @@ __global__ __launch_bounds__(256) void modulate_fwd_kernel(const float* __restri
         const float4* sh = (const float4*)(shift + (size_t)n * ldmod + d);
         float4 x0 = xp[0], x1 = xp[1], c0 = sc[0], c1 = sc[1], h0 = sh[0], h1 = sh[1];
         uint4 u;
-        u.x = pack2bf(ka * x0.x * c0.x + kb * h0.x, ka * x0.y * c0.y + kb * h0.y);
-        u.y = pack2bf(ka * x0.z * c0.z + kb * h0.z, ka * x0.w * c0.w + kb * h0.w);
-        u.z = pack2bf(ka * x1.x * c1.x + kb * h1.x, ka * x1.y * c1.y + kb * h1.y);
-        u.w = pack2bf(ka * x1.z * c1.z + kb * h1.z, ka * x1.w * c1.w + kb * h1.w);
+        u.x = pack16(ka * x0.x * c0.x + kb * h0.x, ka * x0.y * c0.y + kb * h0.y);
+        u.y = pack16(ka * x0.z * c0.z + kb * h0.z, ka * x0.w * c0.w + kb * h0.w);
+        u.z = pack16(ka * x1.x * c1.x + kb * h1.x, ka * x1.y * c1.y + kb * h1.y);
+        u.w = pack16(ka * x1.z * c1.z + kb * h1.z, ka * x1.w * c1.w + kb * h1.w);
         *(uint4*)(out + m * D + d) = u;
     }
 }
@@ -49,6 +49,7 @@ struct RmbP {
     float* dx; bf16_t* dx_bf; float* dshift; float* dscale; float* dgain_part; bf16_t* dy_up; float* dg_up;
     int ldmod, ldg_up, ldd, ldd_up;   // row strides of (shift,scale), g_up, dshift/dscale and dg_up
     int T, D; float ca, cb;
+    float gscale;                     // factor on the scalar gain partials (1 / loss scale of an fp16 engine; 1 otherwise)
     // gridDim.z > 1: each block handles T / gridDim.z rows and parks its column sums in `part` ([z][sample][3][D]) and its gain
     // partial in dgain_part[(z * samples + n) * D/128 + column block]; rmb_finish_kernel adds the z slices in order
     float* part;
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
         }
         if (p.dxm) {
             uint2 u = *(const uint2*)(p.dxm + off);
-            const float dm[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            const float dm[4] = {lo16(u.x), hi16(u.x),
+                                 lo16(u.y), hi16(u.y)};
             float4 xv = *(const float4*)(p.x + off);
             const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
@@ -94,20 +95,20 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
         }
         if (p.dx) *(float4*)(p.dx + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
         if (p.dx_bf) {
-            uint2 u; u.x = pack2bf(dx[0], dx[1]); u.y = pack2bf(dx[2], dx[3]);
+            uint2 u; u.x = pack16(dx[0], dx[1]); u.y = pack16(dx[2], dx[3]);
             *(uint2*)(p.dx_bf + off) = u;
         }
         if (p.y_up) {
             uint2 u = *(const uint2*)(p.y_up + off);
-            const float yy[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            const float yy[4] = {lo16(u.x), hi16(u.x),
+                                 lo16(u.y), hi16(u.y)};
             float dy[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 dy[i] = p.cb * guv[i] * dx[i];
                 a_g[i] += p.cb * yy[i] * dx[i];
             }
-            uint2 w; w.x = pack2bf(dy[0], dy[1]); w.y = pack2bf(dy[2], dy[3]);
+            uint2 w; w.x = pack16(dy[0], dy[1]); w.y = pack16(dy[2], dy[3]);
             *(uint2*)(p.dy_up + off) = w;
         }
     }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
             float gsum = s[12];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
-            if (cl == 0) p.dgain_part[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y] = gsum;
+            if (cl == 0) p.dgain_part[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y] = gsum * p.gscale;
         }
         if (p.y_up) *(float4*)(split ? pz + 2 * p.D + d : p.dg_up + (size_t)n * p.ldd_up + d) = make_float4(s[8], s[9], s[10], s[11]);
     }
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(256) void rot_fwd_kernel(bf16_t* __restrict__ u, co
         for (int j = 0; j < 4; ++j) {
             float sn, cs;
             sincosf(ang[j], &sn, &cs);
-            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
-            w[j] = pack2bf(cs * a - sn * b, sn * a + cs * b);
+            const float a = lo16(w[j]), b = hi16(w[j]);
+            w[j] = pack16(cs * a - sn * b, sn * a + cs * b);
         }
         *(uint4*)(u + m * D + d) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void rot_fwd_kernel(bf16_t* __restrict__ u, co
 // groups; LDS reduce over the row groups (no atomics).
 __global__ __launch_bounds__(256) void rot_bwd_kernel(bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                     const float* __restrict__ theta, int ldt, const float* __restrict__ gain,
-                                                    float* __restrict__ dtheta, int ldd, float* __restrict__ dgain_part, int T, int D) {
+                                                    float* __restrict__ dtheta, int ldd, float* __restrict__ dgain_part, int T, int D, float gscale) {
     __shared__ float red[8][32][2];
     const int n = blockIdx.x, cb0 = blockIdx.y * 128;
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -213,10 +214,10 @@ __global__ __launch_bounds__(256) void rot_bwd_kernel(bf16_t* __restrict__ dy, c
         uint32_t o[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
-            const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+            const float g0 = lo16(gw[j]), g1 = hi16(gw[j]);
+            const float y0 = lo16(yw[j]), y1 = hi16(yw[j]);
             acc[j] += g1 * y0 - g0 * y1;
-            o[j] = pack2bf(cs[j] * g0 + sn[j] * g1, cs[j] * g1 - sn[j] * g0);
+            o[j] = pack16(cs[j] * g0 + sn[j] * g1, cs[j] * g1 - sn[j] * g0);
         }
         *(uint2*)(dy + off) = make_uint2(o[0], o[1]);
     }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void rot_bwd_kernel(bf16_t* __restrict__ dy, c
         float gs = th.x * s0 + th.y * s1;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
-        if (cl == 0) dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gs;
+        if (cl == 0) dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gs * gscale;
     }
 }
 
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
         if (which < 2) {
             float f[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+            for (int i = 0; i < 8; ++i) { f[2 * i] = lo16(w[i]); f[2 * i + 1] = hi16(w[i]); }
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ss += f[i] * f[i];
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
             ss += __shfl_xor(ss, 2, 64);
             const float sc = 8.f / (sqrtf(ss) + NORM_EPS);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = pack2bf(f[2 * i] * sc, f[2 * i + 1] * sc);
+            for (int i = 0; i < 8; ++i) w[i] = pack16(f[2 * i] * sc, f[2 * i + 1] * sc);
         }
         bf16_t* dst = (which == 0 ? qn : which == 1 ? kn : v) + (bh * T + t0 + row) * 64 + qd * 16;
         ((uint4*)dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256) void qkv_merge_bwd_kernel(const bf16_t* __rest
             float f[16], gf[16];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-                gf[2 * i] = __uint_as_float(gw[i] << 16); gf[2 * i + 1] = __uint_as_float(gw[i] & 0xffff0000u);
+                f[2 * i] = lo16(w[i]); f[2 * i + 1] = hi16(w[i]);
+                gf[2 * i] = lo16(gw[i]); gf[2 * i + 1] = hi16(gw[i]);
             }
             float ss = 0.f, dot = 0.f;
 #pragma unroll
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void qkv_merge_bwd_kernel(const bf16_t* __rest
 #pragma unroll
             for (int i = 0; i < 16; ++i) gf[i] = s * (gf[i] - f[i] * c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gw[i] = pack2bf(gf[2 * i], gf[2 * i + 1]);
+            for (int i = 0; i < 8; ++i) gw[i] = pack16(gf[2 * i], gf[2 * i + 1]);
         }
         ((uint4*)(dqkv + moff))[0] = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         ((uint4*)(dqkv + moff))[1] = make_uint4(gw[4], gw[5], gw[6], gw[7]);
@@ -318,11 +319,11 @@ __global__ __launch_bounds__(256) void qkv_merge_bwd_kernel(const bf16_t* __rest
 // mp_silu on a small fp32 matrix -> bf16 GEMM operand (conditioning path: MPSiLU(c), dit_block.py:24-25).
 __global__ void mpsilu_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f2bf(silu_f(x[i]) * (1.f / MP_SILU_DIV));
+    if (i < n) out[i] = cvt16(silu_f(x[i]) * (1.f / MP_SILU_DIV));
 }
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n, float alpha) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f2bf(alpha * x[i]);
+    if (i < n) out[i] = cvt16(alpha * x[i]);
 }
 
 __global__ void f32_to_bf16_2d_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ out, int ldo, int rows, int cols,
@@ -330,7 +331,7 @@ __global__ void f32_to_bf16_2d_kernel(const float* __restrict__ x, int ldx, bf16
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * cols) return;
     const int r = (int)(i / cols), c = (int)(i % cols);
-    out[(size_t)r * ldo + c] = f2bf(alpha * x[(size_t)r * ldx + c]);
+    out[(size_t)r * ldo + c] = cvt16(alpha * x[(size_t)r * ldx + c]);
 }
 // acc[i] += sum_s slabs[s*stride + i]   (fixed order: deterministic split-K reduction)
 __global__ void sum_slabs_kernel(float* __restrict__ acc, const float* __restrict__ slabs, int nslabs, long stride, long n) {
@@ -341,9 +342,9 @@ __global__ void sum_slabs_kernel(float* __restrict__ acc, const float* __restric
     acc[i] = a;
 }
 
-}  // namespace
+MD_NS_CLOSE
 
-extern "C" int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream) {
+extern "C" int MD_SYM_F32_TO_16_2D(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream) {
     MD_CHECK(x && out && rows > 0 && cols > 0 && ldx >= cols && ldo >= cols, "f32_to_bf16_2d: bad argument");
     hipLaunchKernelGGL(f32_to_bf16_2d_kernel, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
                        rows, cols, alpha);
@@ -351,14 +352,16 @@ extern "C" int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0          // no 16-bit operand: one copy in the library
 extern "C" int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream) {
     MD_CHECK(acc && slabs && nslabs >= 1 && n > 0, "sum_slabs: bad argument");
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, acc, slabs, nslabs, slab_stride, n);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
-extern "C" int mapdit_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
+extern "C" int MD_SYM(modulate_fwd)(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
                                    uint16_t* out, int n_samples, int T, int D, void* stream) {
     MD_CHECK(x && shift && scale && gain && out, "modulate_fwd: null argument");
     MD_CHECK(D % 8 == 0 && ldmod % 4 == 0, "modulate_fwd: D=%d must be a multiple of 8, ldmod=%d of 4", D, ldmod);
@@ -370,7 +373,7 @@ extern "C" int mapdit_modulate_fwd(const float* x, const float* shift, const flo
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* stream) {
+extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stream) {
     MD_CHECK(a, "resid_mod_bwd: null argument");
     MD_CHECK(a->D % 128 == 0, "resid_mod_bwd: D=%d must be a multiple of 128", a->D);
     MD_CHECK(a->dxo || a->dxm, "resid_mod_bwd: need dxo and/or dxm");
@@ -382,6 +385,7 @@ extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* strea
     p.y_up = a->y_up; p.g_up = a->g_up; p.dx = a->dx; p.dx_bf = a->dx_bf; p.dshift = a->dshift; p.dscale = a->dscale;
     p.dgain_part = a->dgain_part; p.dy_up = a->dy_up; p.dg_up = a->dg_up;
     p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
+    p.gscale = a->dgain_scale != 0.f ? a->dgain_scale : 1.f;
     // Small batches: one block per (sample, 128 columns) is too few blocks to stream at the HBM rate (32 samples x 6 = 192 blocks:
     // 60 us for 25 us of traffic).  With scratch given, the rows of a sample are cut into Z pieces (grid z), the column sums
     // parked per piece and added in order by a second small kernel; the gain partials simply become Z times as many.
@@ -409,7 +413,7 @@ extern "C" int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* a, void* strea
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D,
+extern "C" int MD_SYM(rotate_fwd)(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D,
                                  void* stream) {
     MD_CHECK(u && theta && gain && n_samples > 0, "rotate_fwd: null/empty argument");
     MD_CHECK(D % 8 == 0 && ldt % 4 == 0 && ((uintptr_t)theta & 15) == 0, "rotate_fwd: D %% 8, ldt %% 4 and a 16-byte aligned theta");
@@ -420,59 +424,61 @@ extern "C" int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_rotate_bwd(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta,
-                                 int ldd, float* dgain_part, int n_samples, int T, int D, void* stream) {
+extern "C" int MD_SYM(rotate_bwd)(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta,
+                                 int ldd, float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream) {
     MD_CHECK(dy && y && theta && gain && dtheta && dgain_part && n_samples > 0, "rotate_bwd: null/empty argument");
     MD_CHECK(D % 128 == 0 && ldt % 2 == 0 && ldd % 2 == 0, "rotate_bwd: D=%d must be a multiple of 128, even row strides", D);
     hipLaunchKernelGGL(rot_bwd_kernel, dim3(n_samples, D / 128), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, (const bf16_t*)y,
-                       theta, ldt, gain, dtheta, ldd, dgain_part, T, D);
+                       theta, ldt, gain, dtheta, ldd, dgain_part, T, D, dgain_scale);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream) {
     MD_CHECK(part && out && count > 0, "reduce_partials: null/empty argument");
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, count, out, accumulate);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
-extern "C" int mapdit_qkv_split_generic(const uint16_t*, int, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
-extern "C" int mapdit_qkv_merge_bwd_generic(const uint16_t*, int, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*,
+extern "C" int MD_SYM(qkv_split_generic)(const uint16_t*, int, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
+extern "C" int MD_SYM(qkv_merge_bwd_generic)(const uint16_t*, int, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*,
                                             uint16_t*, void*);
 
 // head_dim 72 (DiT-XL): coalesced chunk-per-thread kernels of attention72.hip
-int mapdit_qkv_split72(const uint16_t*, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
-int mapdit_qkv_merge_bwd72(const uint16_t*, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, void*);
+int MD_SYM(qkv_split72)(const uint16_t*, int, int, int, uint16_t*, uint16_t*, uint16_t*, void*);
+int MD_SYM(qkv_merge_bwd72)(const uint16_t*, int, int, int, const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, void*);
 
-extern "C" int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
+extern "C" int MD_SYM(qkv_split)(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn,
                                 uint16_t* v, void* stream) {
     MD_CHECK(qkv && qn && kn && v, "qkv_split: null argument");
-    if (head_dim == 72 && H <= 37) return mapdit_qkv_split72(qkv, B, T, H, qn, kn, v, stream);
-    if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_split_generic(qkv, B, T, H, head_dim, qn, kn, v, stream);
+    if (head_dim == 72 && H <= 37) return MD_SYM(qkv_split72)(qkv, B, T, H, qn, kn, v, stream);
+    if (head_dim != 64 || T % 64 != 0) return MD_SYM(qkv_split_generic)(qkv, B, T, H, head_dim, qn, kn, v, stream);
     hipLaunchKernelGGL(qkv_split_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, qn, kn, v);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
+extern "C" int MD_SYM(qkv_merge_bwd)(const uint16_t* qkv, int B, int T, int H, int head_dim, const uint16_t* dqn,
                                     const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream) {
     MD_CHECK(qkv && dqn && dkn && dv && dqkv, "qkv_merge_bwd: null argument");
-    if (head_dim == 72 && H <= 37) return mapdit_qkv_merge_bwd72(qkv, B, T, H, dqn, dkn, dv, dqkv, stream);
-    if (head_dim != 64 || T % 64 != 0) return mapdit_qkv_merge_bwd_generic(qkv, B, T, H, head_dim, dqn, dkn, dv, dqkv, stream);
+    if (head_dim == 72 && H <= 37) return MD_SYM(qkv_merge_bwd72)(qkv, B, T, H, dqn, dkn, dv, dqkv, stream);
+    if (head_dim != 64 || T % 64 != 0) return MD_SYM(qkv_merge_bwd_generic)(qkv, B, T, H, head_dim, dqn, dkn, dv, dqkv, stream);
     hipLaunchKernelGGL(qkv_merge_bwd_kernel, dim3(T / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, T, H, dqn, dkn, dv, dqkv);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream) {
+extern "C" int MD_SYM_MPSILU_TO_16(const float* x, uint16_t* out, long n, void* stream) {
     MD_CHECK(x && out && n > 0, "mpsilu_to_bf16: null/empty argument");
     hipLaunchKernelGGL(mpsilu_f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void* stream) {
+extern "C" int MD_SYM_F32_TO_16(const float* x, uint16_t* out, long n, float alpha, void* stream) {
     MD_CHECK(x && out && n > 0, "f32_to_bf16: null/empty argument");
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n, alpha);
     MD_LAUNCH_CHECK();

@@ -3,7 +3,7 @@
 // 16-byte accesses, fp32 arithmetic.
 #include "common.h"
 
-namespace {
+MD_NS_OPEN
 
 // One wave per row.  Pass 1: sum of squares.  Pass 2 (row is L1/L2-hot): rewrite the master weight
 // (forced weight norm, reference mp_linear.py:38-40 / mp_embedding.py:17-19) and emit the effective
@@ -46,8 +46,8 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
             if (wf) *(float4*)(wf + (size_t)row * cols + c) = o;
             if (wb) {
                 uint2 u;
-                u.x = pack2bf(o.x, o.y);
-                u.y = pack2bf(o.z, o.w);
+                u.x = pack16(o.x, o.y);
+                u.y = pack16(o.z, o.w);
                 *(uint2*)(wb + (size_t)row * cols + c) = u;
             }
             if (w3) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
             const float v = w[c];
             if (forced) w[c] = v * f;
             if (wf) wf[(size_t)row * cols + c] = v * e;
-            if (wb) wb[(size_t)row * cols + c] = f2bf(v * e);
+            if (wb) wb[(size_t)row * cols + c] = cvt16(v * e);
             if (w3) {
                 const bf16_t hi = f2bf(v * e), lo = f2bf(v * e - bf2f(hi));
                 bf16_t* d = w3 + (size_t)row * 3 * cols + c;
@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
     }
 }
 
-}  // namespace
+MD_NS_CLOSE
 
-extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16,
+extern "C" int MD_SYM(weightnorm_fwd)(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16,
                                      float* w_f32, float* inv, void* stream) {
     MD_CHECK(W && rows > 0 && cols > 0, "weightnorm_fwd: null/empty argument");
     MD_CHECK((cols & 3) != 0 || (((uintptr_t)W | (uintptr_t)w_f32) & 15) == 0, "weightnorm_fwd: unaligned pointer");
@@ -248,13 +248,14 @@ extern "C" int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, f
     return MAPDIT_OK;
 }
 
-extern "C" int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream) {
+extern "C" int MD_SYM(weightnorm_fwd_batch)(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream) {
     MD_CHECK(jobs_dev && njobs > 0 && total_blocks > 0, "weightnorm_fwd_batch: null/empty argument");
     hipLaunchKernelGGL(weightnorm_fwd_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs, forced);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW,
                                      int rows, int cols, float out_scale, int accumulate, void* stream) {
     MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols && nslabs >= 1, "weightnorm_bwd: null/empty argument");
@@ -269,7 +270,9 @@ extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nsla
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
                                     float* ema_b, long n, const float* hyper, float beta1, float beta2, float eps,
                                     void* stream) {
@@ -282,7 +285,9 @@ extern "C" int mapdit_adam_ema_step(float* params, const float* grads, float* ex
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif
 
+#if MAPDIT_DT == 0
 extern "C" int mapdit_adam_ema_step_scalars(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
                                             float* ema_b, long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2,
                                             float eps, void* stream) {
@@ -294,3 +299,4 @@ extern "C" int mapdit_adam_ema_step_scalars(float* params, const float* grads, f
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+#endif

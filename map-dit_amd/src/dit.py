@@ -191,7 +191,8 @@ class _Runtime:
         self.cfg = L.Config(depth=len(model.blocks), hidden=model.hidden_size, patch=model.patch_size,
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
                             mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
-                            precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)))
+                            precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)),
+                            loss_scale=float(getattr(model, "loss_scale", 0.0)) if precision == "f16" else 0.0)
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
             raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
@@ -307,8 +308,11 @@ class DiT(nn.Module):
                                      for _ in range(depth)])
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
 
-        self._rt = {}                 # {train (bool) | ("bf16x3", train): _Runtime}
-        self.gemm_precision = "bf16"  # "bf16x3": fp32-accurate forward and backward (several times slower), see mapdit.h
+        self._rt = {}                 # {train (bool) | (precision, train): _Runtime}
+        # "bf16" (default) | "f16": the same engine with IEEE fp16 operands - same speed, forward logits within 1e-3 of the fp32
+        # reference (bf16: ~6e-3) | "bf16x3": fp32-accurate forward and backward (several times slower).  See mapdit.h.
+        self.gemm_precision = "bf16"
+        self.loss_scale = 0.0         # "f16" only: static power-of-two loss scale of the backward (0 = chosen from the batch size)
         self._pflat = None            # flat fp32 storage behind every parameter (views)
         self._gflat = None            # flat gradient buffer, p.grad are views of it
         self._gviews = None
@@ -394,7 +398,7 @@ class DiT(nn.Module):
         if self._pflat is None or not self._pflat.is_cuda:
             raise L.MapditError("MaP-DiT runs on the MI355X only: move the module to a cuda device (there is no CPU path)")
         if self._pflat.dtype != torch.float32:
-            raise L.MapditError("master parameters must be fp32 (bf16 is the engine's internal GEMM operand type)")
+            raise L.MapditError("master parameters must be fp32 (bf16 / fp16 are the engine's internal GEMM operand types)")
         precision = getattr(self, "gemm_precision", "bf16")
         if precision not in L.PRECISIONS:
             raise L.MapditError(f"gemm_precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
@@ -411,7 +415,8 @@ class DiT(nn.Module):
     def _peek(self, what: str, block: int = 0) -> torch.Tensor:
         """Diagnostics (mapdit_engine_peek): a copy of an intermediate of the last training-mode forward, as a 2-d
         [rows, ld] tensor (fp32 or bf16).  Names: _lib.PEEK_IDS."""
-        rt = self._rt.get(True)
+        precision = getattr(self, "gemm_precision", "bf16")
+        rt = self._rt.get(True if precision == "bf16" else (precision, True))
         if rt is None:
             raise L.MapditError("_peek needs a training-mode forward first")
         ptr, n, ld, dt = C.c_void_p(), C.c_long(), C.c_int(), C.c_int()
@@ -419,7 +424,7 @@ class DiT(nn.Module):
         off = ptr.value - rt.workspace.data_ptr()
         size = 2 if dt.value else 4
         assert 0 <= off and off + n.value * size <= rt.workspace.numel()
-        flat = rt.workspace[off: off + n.value * size].view(torch.bfloat16 if dt.value else torch.float32)
+        flat = rt.workspace[off: off + n.value * size].view({0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt.value])
         return flat.view(-1, ld.value).clone()
 
     def _weights_key(self):

@@ -87,8 +87,9 @@ def build_parser():
     p.add_argument("--num-lin-warmup", type=int, default=None)
     p.add_argument("--start-decay", type=int, default=None)
     p.add_argument("--ema-snapshot-every", type=int, default=None)
-    p.add_argument("--precision", choices=["bf16", "bf16x3"], default="bf16",
-                   help="GEMM operand precision: bf16 (fast path) or bf16x3 (fp32-accurate forward and backward, the reference's "
+    p.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="bf16",
+                   help="GEMM operand precision: bf16 (fast path), f16 (the same engine with IEEE fp16 operands: same speed, logits within "
+                        "1e-3 of the fp32 reference; static loss scale) or bf16x3 (fp32-accurate forward and backward, the reference's "
                         "numerics to ~1e-5, several times slower)")
     p.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
                    help="data-parallel gradient exchange: per-stage all-reduce overlapped with backward (default), or "
@@ -97,7 +98,7 @@ def build_parser():
         p.add_argument(f"--use-{f}", dest="use_" + f.replace("-", "_"), action=argparse.BooleanOptionalAction, default=True)
     p.add_argument("--use-rotation-modulation", action=argparse.BooleanOptionalAction, default=False,
                    help="block conditioning by rotation modulation (reference README.md:1-3; not in its code snapshot: this build's "
-                        "own restatement, parity unpinned): ~5.4 %% fewer parameters; bf16 precision only")
+                        "own restatement, parity unpinned): ~5.4 %% fewer parameters; bf16 and f16 precisions")
     return p
 
 

@@ -157,17 +157,26 @@ def bf16_round(x: Tensor) -> Tensor:
     return x.bfloat16().to(x.dtype)
 
 
+def f16_round(x: Tensor) -> Tensor:
+    """Round-to-nearest-even to IEEE fp16 and back: the storage rounding of the fp16 engine (gemm_precision = "f16")."""
+    return x.half().to(x.dtype)
+
+
 class EnginePlan:
     """The bf16 engine's precision plan as a per-site rounding policy: bf16 GEMM / attention operands on the token path, an
     fp32-accurate conditioning path (timestep MLP, modulation linears, MPScale linears: the engine runs those [samples, D]
-    products on two-term split operands)."""
+    products on two-term split operands).  ``EnginePlan(f16_round)``: the same plan for the fp16 engine."""
     COND = ("t0", "t2", "mod", "fmod", "scale")
 
+    def __init__(self, rnd=bf16_round):
+        self.rnd = rnd
+
     def at(self, site: str):
-        return _ident if site[:2] in ("x:", "w:") and site[2:] in self.COND else bf16_round
+        return _ident if site[:2] in ("x:", "w:") and site[2:] in self.COND else self.rnd
 
 
 engine_plan = EnginePlan()
+engine_plan_f16 = EnginePlan(f16_round)
 
 
 def _at(rnd, site: str):

@@ -19,19 +19,50 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(scope="module")
-def L():
+# Every test of this file runs twice: on the bf16 entry points and on their IEEE fp16 twins (mapdit.h, "16-bit operand format").
+# MODE["dt"] is the torch dtype of the 16-bit tensors of the current pass; the library view maps a call to its _f16 form.
+MODE = {"dt": torch.bfloat16, "f16": False}
+_F16_NAMES = {"gemm_bf16": "gemm_f16", "f32_to_bf16": "f32_to_f16", "f32_to_bf16_2d": "f32_to_f16_2d", "mpsilu_to_bf16": "mpsilu_to_f16"}
+
+
+class _F16Calls:
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        twin = _F16_NAMES.get(name, name + "_f16")
+        return getattr(self._real, twin if hasattr(self._real, twin) else name)
+
+
+class _LibView:
+    def __init__(self, mod, f16):
+        self._mod, self._f16 = mod, f16
+
+    def __getattr__(self, name):
+        return getattr(self._mod, name)
+
+    def lib(self):
+        real = self._mod.lib()
+        return _F16Calls(real) if self._f16 else real
+
+
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def L(request):
     import mapdit_amd
-    return mapdit_amd._lib
+    MODE["f16"] = request.param == "f16"
+    MODE["dt"] = torch.float16 if MODE["f16"] else torch.bfloat16
+    yield _LibView(mapdit_amd._lib, MODE["f16"])
+    MODE["f16"], MODE["dt"] = False, torch.bfloat16
 
 
 def bf16_exact(*shape, seed=0, scale=1.0):
+    """Values exact in bf16 - and in fp16 too (8 significant bits, exponents far inside fp16's range at these scales)."""
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
 
 
 def to_bf(x):
-    return x.to(DEV).bfloat16().contiguous()
+    return x.to(DEV).to(MODE["dt"]).contiguous()
 
 
 def p(t):
@@ -129,7 +160,7 @@ def test_gemm_epilogues(L):
     acc = (A.double() @ B.double().t()).float()
     a, b = to_bf(A), to_bf(B)
     # bf16 store with alpha
-    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
     run_gemm(L, 0, a, b, L.EPI_STORE_BF16, M, N, K, out=p(out), ldo=N, alpha=0.5)
     assert rel_err(out.float().cpu().numpy(), (0.5 * acc).numpy()) < 3e-3
     # accumulate fp32
@@ -138,7 +169,7 @@ def test_gemm_epilogues(L):
     run_gemm(L, 0, a, b, L.EPI_STORE_F32, M, N, K, out=p(o2), ldo=N, alpha=2.0, accumulate=1)
     assert rel_err(o2.cpu().numpy(), (base + 2 * acc).numpy()) < 2e-6
     # silu2
-    pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    pre = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
     act = torch.zeros_like(pre)
     run_gemm(L, 0, a, b, L.EPI_SILU2, M, N, K, out=p(pre), out2=p(act), ldo=N)
     assert rel_err(pre.float().cpu().numpy(), acc.numpy()) < 3e-3
@@ -161,7 +192,7 @@ def test_gemm_epilogues(L):
     x = torch.randn(M, N)
     gate = torch.randn(M // T, 3 * N)
     xo = torch.zeros(M, N, device=DEV)
-    y = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    y = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
     xd, gd = x.to(DEV), gate.to(DEV)
     run_gemm(L, 0, a, b, L.EPI_RESID, M, N, K, out=p(y), out2=p(xo), aux=p(xd), gate=gd.data_ptr() + 4 * N, ldg=3 * N,
              rows_per_sample=T, ldo=N, alpha=0.7, beta=0.3)
@@ -170,7 +201,7 @@ def test_gemm_epilogues(L):
     assert rel_err(y.float().cpu().numpy(), acc.numpy()) < 3e-3
     # dsilu
     h = bf16_exact(M, N, seed=9)
-    o3 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o3 = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
     hd = to_bf(h)
     run_gemm(L, 0, a, b, L.EPI_DSILU, M, N, K, out=p(o3), aux=p(hd), ldo=N)
     hh = h.clone().requires_grad_(True)
@@ -179,7 +210,7 @@ def test_gemm_epilogues(L):
 
 
 def test_gemm_rejects_bad_args(L):
-    a = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    a = torch.zeros(64, 64, device=DEV, dtype=MODE["dt"])
     ep = L.Epilogue()
     ep.kind = L.EPI_STORE_F32
     ep.out = None
@@ -201,7 +232,7 @@ def test_weightnorm(L, rows, cols, forced):
     g = torch.Generator().manual_seed(5)
     W = torch.randn(rows, cols, generator=g) * 1.7
     Wd = W.to(DEV).clone()
-    wb = torch.zeros(rows, cols, device=DEV, dtype=torch.bfloat16)
+    wb = torch.zeros(rows, cols, device=DEV, dtype=MODE["dt"])
     wf = torch.zeros(rows, cols, device=DEV)
     inv = torch.zeros(rows, device=DEV)
     L.lib().weightnorm_fwd(p(Wd), rows, cols, forced, 1.0, p(wb), p(wf), p(inv), st())
@@ -234,7 +265,7 @@ def test_weightnorm_batch_equals_single_launches(L):
         singles, batch = [], []
         for which in ("single", "batch"):
             Ws = [m.clone().to(DEV) for m in masters]
-            outs = [torch.zeros(r, c, device=DEV, dtype=torch.bfloat16 if kind == "bf" else torch.float32) for r, c, _, kind in shapes]
+            outs = [torch.zeros(r, c, device=DEV, dtype=MODE["dt"] if kind == "bf" else torch.float32) for r, c, _, kind in shapes]
             if which == "single":
                 for W, o, (r, c, sc, kind) in zip(Ws, outs, shapes):
                     L.lib().weightnorm_fwd(p(W), r, c, forced, sc, p(o) if kind == "bf" else None, p(o) if kind == "f32" else None, None, st())
@@ -255,7 +286,7 @@ def test_weightnorm_batch_equals_single_launches(L):
     # hi = the bf16 image, hi + lo = the fp32 effective weight to 2^-16 relative, for a vector-width and a ragged column count
     for r, c in ((96, 256), (10, 257)):
         W = torch.randn(r, c, generator=g).to(DEV)
-        wb = torch.zeros(r, c, device=DEV, dtype=torch.bfloat16)
+        wb = torch.zeros(r, c, device=DEV, dtype=MODE["dt"])
         wf = torch.zeros(r, c, device=DEV)
         w3 = torch.zeros(r, 3 * c, device=DEV, dtype=torch.bfloat16)
         jobs = (L.WnJob * 1)()
@@ -315,7 +346,7 @@ def test_modulate_and_fused_backward(L):
     xpd = xp.detach().to(DEV).contiguous()
     modd = mod.to(DEV)
     gd = gain.to(DEV)
-    out = torch.zeros(N * T, D, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(N * T, D, device=DEV, dtype=MODE["dt"])
     L.lib().modulate_fwd(p(xpd), modd.data_ptr() + 4 * 3 * D, modd.data_ptr() + 4 * 4 * D, 6 * D, p(gd), p(out), N, T, D, st())
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu().numpy().reshape(N, T, D), u.detach().numpy()) < 3e-3
@@ -323,11 +354,11 @@ def test_modulate_and_fused_backward(L):
     a = L.ResidModBwd()
     dxod, dxmd, yud, mud = dxo.to(DEV).contiguous(), to_bf(dxm), to_bf(y_up), mod_up.to(DEV)
     dx = torch.zeros(N, T, D, device=DEV)
-    dxbf = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    dxbf = torch.zeros(N, T, D, device=DEV, dtype=MODE["dt"])
     dmod = torch.zeros(N, 6 * D, device=DEV)
     dmod_up = torch.zeros(N, 6 * D, device=DEV)
     part = torch.zeros(N * (D // 128), device=DEV)
-    dy = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    dy = torch.zeros(N, T, D, device=DEV, dtype=MODE["dt"])
     a.dxo, a.dxm, a.x = p(dxod), p(dxmd), p(xpd)
     a.shift, a.scale, a.gain, a.ldmod = modd.data_ptr() + 4 * 3 * D, modd.data_ptr() + 4 * 4 * D, p(gd), 6 * D
     a.y_up, a.g_up, a.ldg_up = p(yud), mud.data_ptr() + 4 * 5 * D, 6 * D
@@ -383,7 +414,7 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     gain = torch.tensor(0.37)
     dyo = bf16_exact(M, K, seed=9)                                    # gradient entering the dX GEMM
     w = bf16_exact(K, D, seed=10) * 0.25 if layout == 1 else bf16_exact(D, K, seed=10) * 0.25
-    dxm = (dyo @ (w if layout == 1 else w.t())).bfloat16().float()    # the GEMM result as the backward sees it: bf16
+    dxm = (dyo @ (w if layout == 1 else w.t())).to(MODE["dt"]).float()    # the GEMM result as the backward sees it: bf16
     dxo = torch.randn(N, T, D, generator=g)
     ca, cb = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58)
     leaves = [t.clone().requires_grad_(True) for t in (x_up, y_up, mod_up, mod, gain)]
@@ -398,12 +429,12 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     modd, gd, mud = mod.to(DEV), gain.to(DEV), mod_up.to(DEV)
     dxod, yud = dxo.to(DEV).contiguous(), to_bf(y_up)
     dx = torch.zeros(N, T, D, device=DEV)
-    dxbf = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    dxbf = torch.zeros(N, T, D, device=DEV, dtype=MODE["dt"])
     dmod = torch.zeros(N, 6 * D, device=DEV)
     dmod_up = torch.zeros(N, 6 * D, device=DEV)
     tiles = ((M + 255) // 256) * (D // 256)
     part = torch.full((tiles + 4,), float("nan"), device=DEV)
-    dy = torch.zeros(N, T, D, device=DEV, dtype=torch.bfloat16)
+    dy = torch.zeros(N, T, D, device=DEV, dtype=MODE["dt"])
     a = L.ResidModBwd()
     a.dxo, a.dxm, a.x = (p(dxod) if with_dxo else None), None, p(xpd)
     a.shift, a.scale, a.gain, a.ldmod = modd.data_ptr() + 4 * 3 * D, modd.data_ptr() + 4 * 4 * D, p(gd), 6 * D
@@ -418,29 +449,42 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     e.kind, e.ldo, e.rmb = L.EPI_RMB, D, C.addressof(a)
     ad, bd = to_bf(dyo), to_bf(w)
     L.lib().gemm_tuning(256, 2, 0)            # these small results would take the 128^2 kernel by themselves (too few 256^2 tiles)
-    L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
-    dgain = torch.zeros((), device=DEV)
-    L.lib().reduce_partials(p(part), tiles, p(dgain), 0, st())
-    torch.cuda.synchronize()
-    assert torch.isnan(part[tiles:]).all() and torch.isfinite(part[:tiles]).all()          # exactly one partial per tile
-    want_dxp = xu.grad / ca if with_up else xu.grad            # d x' (autograd: xu.grad = ca * d x' through the mp_sum)
-    # (the reference rounds a CPU fp32 product to bf16, the kernel its own fp32 accumulation: a few roundings flip -> ~2e-5)
-    assert rel_err(dx.cpu().numpy(), want_dxp.numpy()) < 1e-4
-    assert rel_err(dxbf.float().cpu().numpy(), dx.cpu().numpy()) < 3e-3
-    assert rel_err(dmod[:, 3 * D:5 * D].cpu().numpy(), mm.grad[:, 3 * D:5 * D].numpy()) < 1e-4
-    assert abs(dgain.item() - gg.grad.item()) < 1e-4 * (dxm.abs().sum().item() ** 0.5 + 1) + 1e-3 * abs(gg.grad.item())
-    if with_up:
-        assert rel_err(dy.float().cpu().numpy(), yu.grad.numpy()) < 3e-3
-        assert rel_err(dmod_up[:, 5 * D:].cpu().numpy(), mu.grad[:, 5 * D:].numpy()) < 1e-4
-    # bit-reproducible (no atomics): a second launch gives the same bits
-    dx2, dmod2 = dx.clone(), dmod.clone()
-    L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
-    torch.cuda.synchronize()
-    assert torch.equal(dx, dx2) and torch.equal(dmod, dmod2)
+    try:                                        # (the tile override is process-global state: always undone)
+        L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
+        dgain = torch.zeros((), device=DEV)
+        L.lib().reduce_partials(p(part), tiles, p(dgain), 0, st())
+        torch.cuda.synchronize()
+        assert torch.isnan(part[tiles:]).all() and torch.isfinite(part[:tiles]).all()          # exactly one partial per tile
+        want_dxp = xu.grad / ca if with_up else xu.grad            # d x' (autograd: xu.grad = ca * d x' through the mp_sum)
+        # (the reference rounds a CPU fp32 product to bf16, the kernel its own fp32 accumulation: a few roundings flip -> ~2e-5)
+        assert rel_err(dx.cpu().numpy(), want_dxp.numpy()) < 1e-4
+        assert rel_err(dxbf.float().cpu().numpy(), dx.cpu().numpy()) < 3e-3
+        assert rel_err(dmod[:, 3 * D:5 * D].cpu().numpy(), mm.grad[:, 3 * D:5 * D].numpy()) < 1e-4
+        assert abs(dgain.item() - gg.grad.item()) < 1e-4 * (dxm.abs().sum().item() ** 0.5 + 1) + 1e-3 * abs(gg.grad.item())
+        if with_up:
+            assert rel_err(dy.float().cpu().numpy(), yu.grad.numpy()) < 3e-3
+            assert rel_err(dmod_up[:, 5 * D:].cpu().numpy(), mu.grad[:, 5 * D:].numpy()) < 1e-4
+        # bit-reproducible (no atomics): a second launch gives the same bits
+        dx2, dmod2 = dx.clone(), dmod.clone()
+        L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dx2) and torch.equal(dmod, dmod2)
+    finally:
+        L.lib().gemm_tuning(0, 2, 0)
     # shapes the 256x256 path does not take are refused, not mis-computed
-    L.lib().gemm_tuning(0, 2, 0)
     with pytest.raises(L.MapditError):
         L.lib().gemm_bf16(layout, 256, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
+    # a sample whose rows would cross a 256-row tile (T = 192, 512: the per-sample sums are stored once per tile) is refused too
+    for bad_t in (192, 512):
+        if M % bad_t == 0:
+            a.T = bad_t
+            L.lib().gemm_tuning(256, 2, 0)
+            try:
+                with pytest.raises(L.MapditError, match="RMB needs T"):
+                    L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
+            finally:
+                L.lib().gemm_tuning(0, 2, 0)
+    a.T = T
 
 
 @pytest.mark.parametrize("B,T,H", [(2, 64, 2), (1, 256, 3), (3, 128, 1)])
@@ -459,7 +503,7 @@ def test_attention_fwd_bwd(L, B, T, H):
     o_ref.backward(dO)
 
     qkvd = to_bf(qkv)
-    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
     qn_d, kn_d, v_d = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
     lib = L.lib()
     lib.qkv_split(p(qkvd), B, T, H, 64, p(qn_d), p(kn_d), p(v_d), st())
@@ -507,7 +551,7 @@ def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
     o_ref = att.transpose(1, 2).reshape(M, D)
     o_ref.backward(dO)
 
-    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
     xd, wd = to_bf(x), to_bf(w)
     qn_d, kn_d, v_d = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
     scales = torch.zeros(2, B * H, T, device=DEV)
@@ -562,7 +606,7 @@ def test_generic_attention_fwd_bwd(L, B, T, H, hd):
     att = torch.softmax(qn @ kn.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ sp(v)
     o_ref = att.transpose(1, 2).reshape(B * T, D)
     o_ref.backward(dO)
-    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
     qkvd, dOd = to_bf(qkv), to_bf(dO)
     qn_d, kn_d, v_d = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
     lib = L.lib()
@@ -598,7 +642,7 @@ def test_attention_head_dim_72_mfma(L, B, T, H):
     att = torch.softmax(qn @ kn.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ sp(v)
     o_ref = att.transpose(1, 2).reshape(B * T, D)
     o_ref.backward(dO)
-    mk = lambda *s: torch.full(s, float("nan"), device=DEV, dtype=torch.bfloat16)      # NaN-filled: every element must be written
+    mk = lambda *s: torch.full(s, float("nan"), device=DEV, dtype=MODE["dt"])      # NaN-filled: every element must be written
     qkvd, dOd = to_bf(qkv), to_bf(dO)
     qn_d, kn_d, v_d = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
     lib = L.lib()
@@ -637,7 +681,7 @@ def test_attention_head_dim_72_mfma(L, B, T, H):
 def test_attention_exact_small_integers(L):
     """Uniform attention (all logits equal) with integer V: O must be the exact key-mean of V."""
     B, T, H = 1, 64, 1
-    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.bfloat16)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
     qn = mk(1, T, 64)          # zero queries -> all logits 0 -> uniform softmax
     kn = to_bf(bf16_exact(1, T, 64, seed=12))
     V = (torch.arange(T * 64).reshape(1, T, 64) % 7).float()
@@ -669,7 +713,7 @@ def test_patch_embed(L, p_, S):
     ref = mp_sum(h @ w.t(), pos.unsqueeze(0), 0.5)
     ldp = (P + 1 + 7) // 8 * 8
     out = torch.zeros(N * T, D, device=DEV)
-    patches = torch.full((N * T, ldp), 7.0, device=DEV, dtype=torch.bfloat16)
+    patches = torch.full((N * T, ldp), 7.0, device=DEV, dtype=MODE["dt"])
     xd, wd, pd = x.to(DEV), w.to(DEV), pos.to(DEV)
     L.lib().patch_embed_fwd(p(xd), p(wd), p(pd), p(out), p(patches), ldp, N, C_, S, p_, D, st())
     torch.cuda.synchronize()
@@ -697,7 +741,7 @@ def test_conditioning_kernels(L):
     y = torch.randint(0, 11, (N,), generator=g)
     cref = (temb + table[y]) * 0.5 / math.sqrt(0.5)
     c = torch.zeros(N, D, device=DEV)
-    cs = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, D, device=DEV, dtype=MODE["dt"])
     cb = torch.zeros_like(cs)
     tb, tab, yd = temb.to(DEV), table.to(DEV), y.to(DEV)
     L.lib().cond_combine_fwd(p(tb), p(tab), p(yd), p(c), p(cs), p(cb), N, D, tab.shape[0], st())
@@ -709,7 +753,7 @@ def test_conditioning_kernels(L):
     leaf_t, leaf_tab = temb.clone().requires_grad_(True), table.clone().requires_grad_(True)
     cc = (leaf_t + leaf_tab[y]) * 0.5 / math.sqrt(0.5)
     ((torch.nn.functional.silu(cc) / 0.596 * dcs).sum() + (cc * dcd).sum()).backward()
-    dtemb = torch.zeros(N, D, device=DEV, dtype=torch.bfloat16)
+    dtemb = torch.zeros(N, D, device=DEV, dtype=MODE["dt"])
     dtable = torch.zeros(11, D, device=DEV)
     a, b = dcs.to(DEV), dcd.to(DEV)
     L.lib().cond_combine_bwd(p(c), p(a), p(b), p(yd), p(dtemb), p(dtable), N, D, dtable.shape[0], st())
@@ -742,13 +786,13 @@ def test_final_out(L, p_, S):
     torch.cuda.synchronize()
     assert rel_err(out.cpu().numpy(), ref.detach().numpy()) < 1e-6
     ldd = 2 * P if 2 * P > 64 else 64
-    dlin = torch.zeros(N * T, ldd, device=DEV, dtype=torch.bfloat16)
-    da = torch.zeros(2, N, 8, device=DEV, dtype=torch.bfloat16)
+    dlin = torch.zeros(N * T, ldd, device=DEV, dtype=MODE["dt"])
+    da = torch.zeros(2, N, 8, device=DEV, dtype=MODE["dt"])
     drm, drs = torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
     part = torch.zeros(N, 2, 8, device=DEV)
     dd = dout.to(DEV).contiguous()
     L.lib().final_out_bwd(p(dd), p(d[0]), 2 * P, p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(dlin), ldd, p(da), p(part), p(drm),
-                          p(drs), N, C_, S, p_, st())
+                          p(drs), 1.0, N, C_, S, p_, st())
     torch.cuda.synchronize()
     assert rel_err(dlin[:, :2 * P].float().cpu().numpy(), l_.grad.numpy()) < 3e-3
     assert rel_err(da[0].float().cpu().numpy(), a1.grad.numpy()) < 4e-3
@@ -850,10 +894,10 @@ def test_c_abi_collectives_single_rank(L):
         lib.allreduce_bucket(comm, p(buf), buf.numel(), st())
         lib.reduce_scatter_bucket(comm, p(buf), buf.numel(), st())
         lib.allgather_bucket(comm, p(buf), buf.numel(), st())
-        out = torch.empty(buf.numel(), device=DEV, dtype=torch.bfloat16)
+        out = torch.empty(buf.numel(), device=DEV, dtype=MODE["dt"])
         lib.f32_to_bf16(p(buf), p(out), buf.numel(), 1.0, st())          # an engine kernel queued behind the collectives
         torch.cuda.synchronize()
-        assert torch.equal(buf, want) and torch.equal(out, want.bfloat16())
+        assert torch.equal(buf, want) and torch.equal(out, want.to(MODE["dt"]))
         with pytest.raises(L.MapditError):
             lib.reduce_scatter_bucket(comm, p(buf), 0, st())
     finally:

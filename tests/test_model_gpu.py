@@ -266,7 +266,7 @@ def test_gradient_accumulation_and_zero_grad():
     assert rel_err(m.blocks[0].attn.qkv_proj.weight.grad.cpu().numpy(), g1.cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16", LOGIT_TOL), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("bf16", LOGIT_TOL), ("f16", 2e-3), ("bf16x3", 1e-4)])
 def test_sampler_matches_reference(precision, tol):
     """One p_sample step with classifier-free guidance and a 3-step loop prefix with injected noise against the
     reference's outputs; in bf16x3 precision the agreement is 1e-4 or better."""

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("precision,wtol,ltol", [("bf16", 5e-3, 2e-2), ("bf16x3", 2e-4, 1e-4)])
+@pytest.mark.parametrize("precision,wtol,ltol", [("bf16", 5e-3, 2e-2), ("f16", 1e-3, 2e-3), ("bf16x3", 2e-4, 1e-4)])
 def test_three_optimizer_steps_match_reference(precision, wtol, ltol):
     """forward + backward + Adam(lr 1e-2, betas (0.9, 0.99)) + 2 power-EMA copies, three steps, vs the reference's
     weights after each step.  bf16 gradients feed Adam's sign-like early updates, so weights are compared at 5e-3
@@ -108,7 +108,7 @@ def test_train_harness_synthetic(tmp_path):
     assert "(step=0000002) train loss:" in open(os.path.join(exp2, "log.txt")).read()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "bf16x3"])
 def test_staged_backward_equals_monolithic(monkeypatch, precision):
     """The data-parallel path runs backward stage by stage (hooking the all-reduce in between); with one rank the
     gradients must be bit-identical to the single-call backward, and the stage slices must tile the flat buffer."""
@@ -143,7 +143,7 @@ def test_staged_backward_equals_monolithic(monkeypatch, precision):
     assert torch.equal(grads[1], grads[0])         # no atomics anywhere in the step: bit-identical
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "bf16x3"])
 def test_training_is_bit_reproducible(precision):
     """Same seeds -> same bits: five optimiser steps (label drops, repeated labels in the batch, split-K weight gradients, scalar
     gain reductions, fused Adam/EMA) run twice give identical losses and identical weights.  Nothing in the step uses atomics."""
