@@ -184,7 +184,8 @@ def test_gemm_epilogues(L):
     assert rel_err(act2.float().cpu().numpy(), (torch.nn.functional.silu(acc) / 0.596).numpy()) < 3e-3
     act3 = torch.zeros_like(pre)
     run_gemm(L, 0, a, b, L.EPI_SILU2_GRAD, M, N, K, out=None, out2=p(act3), ldo=N)          # inference form: no factor
-    assert rel_err(act3.float().cpu().numpy(), act2.float().cpu().numpy()) < 1e-6
+    # (two instruction sequences for the same sigmoid: an output now and then rounds the other way - 2^-9 in bf16, 2^-12 in fp16)
+    assert rel_err(act3.float().cpu().numpy(), act2.float().cpu().numpy()) < 1e-5
     prod = torch.zeros_like(pre)
     run_gemm(L, 0, a, b, L.EPI_MUL_AUX, M, N, K, out=p(prod), aux=p(dfac), ldo=N)
     assert rel_err(prod.float().cpu().numpy(), (acc * dfac.float().cpu()).numpy()) < 3e-3
@@ -294,7 +295,10 @@ def test_weightnorm_batch_equals_single_launches(L):
         raw = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(DEV)
         L.lib().weightnorm_fwd_batch(p(raw), 1, (r + 3) // 4, 1, st())
         torch.cuda.synchronize()
-        assert torch.equal(w3[:, :c], wb) and torch.equal(w3[:, 2 * c:], wb)
+        # (the split image is bf16 in both builds; the plain image next to it is bf16 or fp16)
+        hi = wb if not MODE["f16"] else wf.bfloat16()
+        assert torch.equal(w3[:, :c], hi) and torch.equal(w3[:, 2 * c:], hi)
+        assert float((wb.float() - wf).abs().max()) <= float(wf.abs().max()) * 2.0 ** (-11 if MODE["f16"] else -8)
         assert float(((w3[:, :c].float() + w3[:, c:2 * c].float()) - wf).abs().max()) <= float(wf.abs().max()) * 2.0 ** -16
 
 
