@@ -236,12 +236,13 @@ def test_training_losses_and_gradients(name):
     # the scalar gain gradients are sums of ~1e5 signed terms (heavy cancellation): judge them on the scale of the
     # largest gain gradient of the model, not on their own (possibly tiny) magnitude
     gain_scale = max(float(np.abs(g["grad/" + k]).max()) for k, p in m.named_parameters() if p.dim() == 0)
+    worst_gain = 0.0
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         gref = g["grad/" + k]
         if p.dim() == 0:
             gain_dev = abs(float(p.grad) - float(gref)) / (gain_scale + 1e-30)
-            worst_gain = max(locals().get("worst_gain", 0.0), gain_dev)
+            worst_gain = max(worst_gain, gain_dev)
             assert gain_dev < GAIN_TOL, (k, float(p.grad), float(gref))
             continue
         e = rel_err(sub(p.grad), gref)
@@ -252,7 +253,7 @@ def test_training_losses_and_gradients(name):
         # forced weight normalisation rewrote the weights in place, on the fp32 path
         if "postw/" + k in g:
             assert rel_err(sub(p.detach()), g["postw/" + k]) < 2e-6, k
-    print(f"{name}: worst gradient rel err {worst:.3e} ({worst_k}); worst gain deviation {locals().get('worst_gain', 0.0):.3e}")
+    print(f"{name}: worst gradient rel err {worst:.3e} ({worst_k}); worst gain deviation {worst_gain:.3e}")
 
 
 def test_gradient_accumulation_and_zero_grad():
@@ -341,11 +342,12 @@ def test_named_models_match_reference(name):
     assert e < 6e-3                   # measured: <= 2.9e-3 (s2_n4)
     worst = worst_e = 0.0
     gain_scale = max(float(g["gradnorm/" + k]) for k, p in m.named_parameters() if p.dim() == 0)
+    worst_gain = 0.0
     for k, p in m.named_parameters():
         gn = float(g["gradnorm/" + k])
         if p.dim() == 0:     # cancellation-heavy scalar sums: see test_training_losses_and_gradients
             gain_dev = abs(float(p.grad) - float(g["grad/" + k])) / (gain_scale + 1e-30)
-            worst_gain = max(locals().get("worst_gain", 0.0), gain_dev)
+            worst_gain = max(worst_gain, gain_dev)
             assert gain_dev < GAIN_TOL, (k, float(p.grad), float(g["grad/" + k]))
             continue
         if gn < 1e-7:
@@ -359,7 +361,7 @@ def test_named_models_match_reference(name):
             worst_e = max(worst_e, e)
         assert e < (NAMED_GRAD_TOL if gref.size >= 64 else 0.12) or p.numel() < 64, (k, e)
     print(f"{name}: worst gradient-norm deviation {worst:.3e}, worst sub-sampled gradient tensor (>= 64 kept entries) {worst_e:.3e}, "
-          f"worst gain deviation {locals().get('worst_gain', 0.0):.3e}")
+          f"worst gain deviation {worst_gain:.3e}")
 
 
 @pytest.mark.parametrize("name", ["xl_d1", "tiny_p8"])
@@ -382,11 +384,12 @@ def test_generic_attention_models_match_reference(name):
     assert rel_err(losses["loss"].detach().cpu().numpy(), g["train_loss"]) < LOSS_TOL
     stride = 7 if "postw/x_embedder.weight" in g else 4099
     gain_scale = max(float(g["gradnorm/" + k]) for k, p in m.named_parameters() if p.dim() == 0)
+    worst_gain = 0.0
     worst = 0.0
     for k, p in m.named_parameters():
         if p.dim() == 0:
             gain_dev = abs(float(p.grad) - float(g["grad/" + k])) / (gain_scale + 1e-30)
-            worst_gain = max(locals().get("worst_gain", 0.0), gain_dev)
+            worst_gain = max(worst_gain, gain_dev)
             assert gain_dev < GAIN_TOL, k
             continue
         gn = float(g["gradnorm/" + k])
@@ -395,7 +398,7 @@ def test_generic_attention_models_match_reference(name):
         e = rel_err(sub(p.grad, stride=stride), g["grad/" + k])
         worst = max(worst, e)
         assert e < (GRAD_TOL if p.numel() >= 64 else SMALL_GRAD_TOL), (k, e)
-    print(f"{name}: worst gradient rel err {worst:.3e}; worst gain deviation {locals().get('worst_gain', 0.0):.3e}")
+    print(f"{name}: worst gradient rel err {worst:.3e}; worst gain deviation {worst_gain:.3e}")
 
 
 def test_deepcopy_and_state_dict_roundtrip():
