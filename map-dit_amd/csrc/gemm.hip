@@ -83,6 +83,30 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
     }
 }
 
+// one 1 KiB piece (j = 0..3 of this wave's four) of the same image
+template <int KIND, bool KTAIL>
+__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, int kmax,
+                                            char* tile, int wave, int lane, int j) {
+    const int seg = wave * 4 + j;
+    const bf16_t* src;
+    if (KIND == OP_ROW) {
+        const int row = seg * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        int grow = idx0 + row;
+        grow = grow < idx_max ? grow : idx_max - 1;
+        src = G + (size_t)grow * ld + k0 + c * 8;
+        if (KTAIL && k0 + c * 8 >= kmax) src = (const bf16_t*)g_zero16;
+    } else {
+        const int krow = seg * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (kswz(krow) << 1);
+        int col = idx0 + c * 8;
+        col = col < idx_max ? col : 0;
+        src = G + (size_t)(k0 + krow) * ld + col;
+        if (KTAIL && k0 + krow >= kmax) src = (const bf16_t*)g_zero16;
+    }
+    __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(tile + seg * 1024), 16, 0, 0);
+}
+
 // ---- fragment reads ---------------------------------------------------------------------------------
 // 16x16x32 operand fragment: lane l holds [idx = i0 + (l & 15)][k = 32 ks + 8 (l >> 4) + j], j = 0..7.
 template <int KIND, bool TR_ASM = true>
@@ -1337,6 +1361,207 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }
 }
 
+// ---- the one-wave-per-SIMD kernel: 256x256x64 tile, 4 waves (2 M x 2 N), 128x128 per wave ----------------------------
+// MEASURED AND REJECTED (round 3, profiles/r03_gemm_w4_experiment.log): bit-correct on all layouts, 7-10 % SLOWER than the 8-wave
+// kernel on every shape of the block (NN K = 3072: 1,174 vs 1,268 TFLOP/s; NT K = 768: 967 vs 1,077).  The ablation builds say why:
+// with neither LDS-DMA nor fragment reads in the loop both kernels run at ~1,650 TFLOP/s (the clock the part holds under MFMA load),
+// but a single wave per SIMD pays for every read and every DMA piece on its own in-order issue stream (reads alone: -24 % here,
+// -10 % in the 8-wave kernel, where the partner wave issues them beside the other wave's MFMAs).  Compiled only with
+// -DMAPDIT_GEMM_EXPERIMENTS (gemm_tuning phases = 5); never part of the product library.
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+// The 8-wave kernel above alternates two wave groups between LOAD and MFMA intervals: at any time one of the two waves of a SIMD
+// issues MFMAs, and its partner's LDS reads stretch those intervals (the matrix pipe issues 71 % of the K loop).  Here a SIMD has
+// ONE wave that owns the whole 512-entry register file: 256 accumulators (8 x 8 tiles of 16x16) and two sets of fragments, the
+// reads of the next 32-deep k-step and the LDS-DMA of the tile after next issued BETWEEN the MFMAs of the current k-step:
+//   * LDS bytes read per K-tile: 4 waves x 32 KiB = 128 KiB (8 waves x 24 KiB = 192 KiB above);
+//   * ONE barrier per K-tile, in the middle of it: before it every wave has issued and retired all its reads of tile t (the
+//     second k-step's fragments are in registers) and waited for its own LDS-DMA pieces of tile t+1; after it the stage of tile t
+//     is free (DMA of tile t+2 goes there: a two-stage ring, 128 KiB) and tile t+1 may be read (its first k-step's fragments are
+//     fetched under the MFMAs of tile t's second k-step).  RAW and WAR both hang on that one barrier.
+//   * every wave stages a quarter of each of the four 16 KiB slots {A rows 0-127, A rows 128-255, B cols 0-127, B cols 128-255}
+//     (the swizzled images of the 128^2 kernel): 16 LDS-DMA pieces per K-tile and wave.
+template <int AK, int BK, class Epi, bool KTAIL>
+__device__ __forceinline__ void gemm_w4_tile(const GemmP& p, const Epi& epi, char* smem, const int bid, const int nwg) {
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                         // per tile: nothing derived from the thread index is kept across tiles
+    const int tid = tid_, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int z = wg / p.tiles, tile = wg - z * p.tiles;
+    const int tiles_m = p.tiles / p.tiles_n;
+    const int bsz = tiles_m * p.band;
+    const int bidx = tile / bsz, rem = tile - bidx * bsz;
+    const int bw = (bidx + 1) * p.band <= p.tiles_n ? p.band : p.tiles_n - bidx * p.band;
+    const int m0 = (rem / bw) * BM2, n0 = (bidx * p.band + rem % bw) * BN2;
+    const int nkt = (p.K + BKT - 1) / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    const int kbeg = (z * kbase + (z < krem ? z : krem)) * BKT;
+    const int nk = kbase + (z < krem ? 1 : 0);
+    constexpr bool ASM_READS = AK == OP_KMAJ || BK == OP_KMAJ;      // transposing reads are inline asm: explicit lgkmcnt waits
+
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa0[8], fb0[8], fa1[8], fb1[8];
+
+    // LDS: three A stages and two B stages of two 16 KiB slots each (160 KiB): the A panels stream from HBM and get two K-tiles
+    // of prefetch distance, the B (weight) panel is L2-resident and gets one.  A(kt) -> A stage kt % 3, B(kt) -> B stage kt % 2.
+    constexpr int A_STAGE = 2 * SLOT_BYTES, B_BASE = 3 * A_STAGE, B_STAGE = 2 * SLOT_BYTES;
+    static_assert(B_BASE + 2 * B_STAGE <= SMEM_PH1, "LDS layout");
+    auto a_stage = [&](int kt) { return smem + (kt % 3) * A_STAGE; };
+    auto b_stage = [&](int kt) { return smem + B_BASE + (kt & 1) * B_STAGE; };
+    // piece q = 0..7 of an operand's K-tile: slot q >> 2 (rows / columns 0-127 | 128-255), piece q & 3 of this wave
+    auto stage_a = [&](int kt, int q) {
+        stage_piece<AK, KTAIL>(p.A, p.lda, m0 + 128 * (q >> 2), p.M, kbeg + kt * BKT, p.K, a_stage(kt) + (q >> 2) * SLOT_BYTES, wave, lane, q & 3);
+    };
+    auto stage_b = [&](int kt, int q) {
+        stage_piece<BK, KTAIL>(p.B, p.ldb, n0 + 128 * (q >> 2), p.N, kbeg + kt * BKT, p.K, b_stage(kt) + (q >> 2) * SLOT_BYTES, wave, lane, q & 3);
+    };
+#define W4_READ(FA, FB, KT, KS)                                                                                       \
+    {                                                                                                                 \
+        const char* a_slot_ = a_stage(KT) + wm * SLOT_BYTES;                                                          \
+        const char* b_slot_ = b_stage(KT) + wn * SLOT_BYTES;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) FA[i] = read_frag<AK>(a_slot_, i * 16, KS, lane);               \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) FB[j] = read_frag<BK>(b_slot_, j * 16, KS, lane);               \
+    }
+    // The MFMAs are inline asm with the accumulator operand constrained to the accumulator half of the register file ("+a"): left to
+    // itself hipcc spread 256 accumulators + 128 fragment registers over both halves and shuffled them with v_accvgpr_read / _write
+    // inside the loop.  A volatile asm also pins the program order of the LDS reads and LDS-DMA issues written between them.
+#if MAPDIT_DT == 1
+#define W4_MFMA1(I, J, FA, FB) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[J]), "v"(FA[I]))
+#else
+#define W4_MFMA1(I, J, FA, FB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[J]), "v"(FA[I]))
+#endif
+    // One 32-deep k-step: 64 MFMAs (rows i of A fragments x columns j of B fragments) with, between them, the 16 fragment reads
+    // of the NEXT k-step (READ_ROW0: the first of the two rows of MFMAs that carry them, one read per MFMA) and, in rows 0..3, the
+    // 16 LDS-DMA pieces of later tiles (one per two MFMAs).
+#define W4_STEP(FA, FB, NFA, NFB, NKT, NKS, READ_ROW0, DMA_B, DMA_B_KT, DMA_A, DMA_A_KT)                              \
+    {                                                                                                                 \
+        const char* a_slot_ = a_stage(NKT) + wm * SLOT_BYTES;                                                         \
+        const char* b_slot_ = b_stage(NKT) + wn * SLOT_BYTES;                                                         \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+                W4_MFMA1(i, j, FA, FB);                                                                               \
+                if (i >= (READ_ROW0) && i < (READ_ROW0) + 2 && !(MAPDIT_GEMM_ABLATE & 2)) {                           \
+                    const int r_ = (i - (READ_ROW0)) * 8 + j;     /* B fragments first (every row needs them) */      \
+                    if (r_ < 8) NFB[r_] = read_frag<BK>(b_slot_, r_ * 16, NKS, lane);                                 \
+                    else NFA[r_ - 8] = read_frag<AK>(a_slot_, (r_ - 8) * 16, NKS, lane);                              \
+                }                                                                                                     \
+                if (i < 4 && (j & 1) == 1) {                                                                          \
+                    const int q_ = i * 4 + (j >> 1);                                                                  \
+                    if (q_ < 8) { if ((DMA_B) && !(MAPDIT_GEMM_ABLATE & 1)) stage_b(DMA_B_KT, q_); }                  \
+                    else { if ((DMA_A) && !(MAPDIT_GEMM_ABLATE & 1)) stage_a(DMA_A_KT, q_ - 8); }                     \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+
+    // prologue, in steady-state order: {A(0) B(0)} {B(1) A(1)} {A(2)}; the wait leaves everything behind tile 0 in flight
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_a(0, q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_b(0, q);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stage_b(1, q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stage_a(1, q);
+    }
+    if (nk > 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stage_a(2, q);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    } else if (nk > 1) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    W4_READ(fa0, fb0, 0, 0);
+    for (int t = 0; t < nk; ++t) {
+        if (ASM_READS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // first k-step of tile t; the second one's fragments arrive under its first two rows of MFMAs
+        W4_STEP(fa0, fb0, fa1, fb1, t, 1, 0, false, 0, false, 0);
+        // A(t+1), B(t+1) (this wave's pieces) have landed - only A(t+2), the youngest eight pieces, may still fly - and every read
+        // of tile t has returned
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // second k-step.  Rows 0..3: the LDS-DMA of B(t+2) and A(t+3) into the stages tile t has just left; rows 4, 5: the first
+        // fragments of tile t+1 (after the last tile: a harmless read of stale LDS)
+        W4_STEP(fa1, fb1, fa0, fb0, t + 1, 0, 4, t + 2 < nk, t + 2, t + 3 < nk, t + 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by compiler code below (asm hides the hazard)
+#undef W4_STEP
+#undef W4_MFMA1
+#undef W4_READ
+    __syncthreads();                                       // (every wave's reads are long done; orders the image writes below)
+
+    // epilogue: two passes of 128 rows (rows [64 pass, 64 pass + 64) of both wave rows) through an fp32 image in LDS, then whole
+    // 8-column row chunks per thread with the pass's stream operands prefetched (as in the 8-wave kernel)
+    float* cs = (float*)smem;
+    const int ecol = (tid & 31) * 8, gn = n0 + ecol;
+    const bool col_ok = gn < p.N;
+    typename Epi::Tile tctx;
+    if (col_ok) tctx = epi.tile_begin(m0, (m0 + BM2 <= p.M ? m0 + BM2 : p.M) - 1, gn);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = wm * 64 + i * 16 + (lane & 15);
+                const int col = wn * 128 + j * 16 + 4 * (lane >> 4);
+                *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            typename Epi::Aux aux[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = (tid >> 5) + 8 * (half * 8 + it);
+                const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
+                if (gm < p.M && col_ok) aux[it] = epi.load(gm, gn);
+            }
+            if (half == 0) __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = (tid >> 5) + 8 * (half * 8 + it);
+                const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
+                if (gm < p.M && col_ok) {
+                    float v[8];
+                    *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + ecol);
+                    *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
+                    epi.apply(gm, gn, v, z, aux[it], tctx);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int AK, int BK, class Epi, bool KTAIL = false>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_PH1];
+    const int total = p.tiles * p.split_k;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        gemm_w4_tile<AK, BK, Epi, KTAIL>(p, epi, smem, v, total);
+        __syncthreads();
+    }
+}
+#endif   // MAPDIT_GEMM_EXPERIMENTS
+
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
 // One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
 template <class Epi>
@@ -1386,7 +1611,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -1402,7 +1627,7 @@ GemmEnv& mapdit_gemm_env_ref() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : 2;
     e.band = band;
 }
 
@@ -1494,6 +1719,16 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
 #endif
         using T2 = std::integral_constant<int, 2>;
         bool done = false;
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+        if constexpr (!kReduce<Epi>) {
+            if (p.phases == 5 && !ktail) {                 // the 4-wave kernel (one wave per SIMD): a rejected experiment, see its comment
+                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_w4_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+                else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_w4_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+                else hipLaunchKernelGGL((gemm_w4_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
+                done = true;
+            }
+        }
+#endif
         if constexpr (kHasTail<Epi>) {
             if (ktail) {
 #ifdef MAPDIT_GEMM_EXPERIMENTS

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=65536)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--cases", default="", help="comma-separated substrings: only the cases whose name contains one of them")
     args = ap.parse_args()
     D, M = args.hidden, args.tokens
     dev = "cuda"
@@ -78,7 +79,9 @@ def main():
         ("fc1  dW  TN split", 2, 4 * D, D, M, dh, 4 * D, x, D, None),
         ("proj dW  TN split", 2, D, D, M, dy, D, x, D, None),
     ]
-    variants = [("128", 128, 4), ("256/2ph", 256, 2), ("256/SP", 256, 3)]
+    variants = [("128", 128, 4), ("256/2ph", 256, 2), ("256/w4", 256, 5)]
+    if args.cases:
+        cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     print(f"{'case':20s} {'kernel':>8s} {'ms':>8s} {'TFLOP/s':>9s}")
     for name, layout, m, n, k, a, lda, b, ldb, e in cases:
         flops = 2.0 * m * n * k
