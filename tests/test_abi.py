@@ -29,6 +29,20 @@ def test_header_symbols_are_exported_and_bound():
     assert cdll.mapdit_abi_version() == 3
 
 
+def test_no_compiler_generated_packed_fp32_code():
+    """tools/check_packed_fp32.py on the built library: packed fp32 VALU arithmetic (v_pk_fma / mul / add_f32, v_pk_mov_b32) appears
+    only in the hand-written SiLU + derivative GEMM epilogue.  Compiler-packed fp32 code produced wrong lane sums while a second
+    process shared the GPU: the build flags that keep it out are a checked property, not a convention."""
+    import subprocess
+    import sys
+    import mapdit_amd
+    L = mapdit_amd._lib
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_packed_fp32.py"), L.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import mapdit_amd
     L = mapdit_amd._lib
