@@ -174,10 +174,11 @@ template <int T> struct Geo {
 };
 
 // ---- forward -----------------------------------------------------------------------------------------------
-template <int T>
+template <int T, bool MULTI>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                               const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
-                                                              float* __restrict__ lse, int H, float scale) {
+                                                              float* __restrict__ lse, int H, float scale, int Ttot) {
+    // T = the key tile staged in LDS at a time (the whole head when Ttot <= 256); Ttot = tokens per head, a multiple of T
     using G = Geo<T>;
     __shared__ __attribute__((aligned(16))) char smem[2 * T * 128];
     char* ks_ = smem;
@@ -186,20 +187,26 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     const int r = lane & 31, h2 = lane >> 5;
     const size_t bh = blockIdx.y;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
-    Staged<T, G::NTH> sk_, sv_;
-    sk_.load(kn + bh * T * 64, 64, tid);
-    sv_.load(v + bh * T * 64, 64, tid);
+    const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
     bf16x8_t qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
-    sk_.store(ks_, nullptr, tid);
-    sv_.store(vs_, nullptr, tid);
-    __syncthreads();
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * Ttot + q0 + r) * 64 + 16 * ks + 8 * h2);
 
     // one pass over the keys: cosine logits are bounded (|q^.k^| / 8 <= 8), so exp() needs no running maximum and every
-    // 32-key tile goes S -> exp -> P V straight from registers; nothing but the 32x64 output tile and the row sum is carried
-    f32x16_t oa[2] = {};
+    // 32-key tile goes S -> exp -> P V straight from registers; nothing but the 32x64 output tile and the row sum is carried -
+    // also across the key tiles of a head with more than 256 tokens (no rescaling between tiles: there is no maximum to track)
+    f32x16_t oa0 = {}, oa1 = {};                       // (named, not an array: carried across the tile loop an array went to scratch)
     float lsum = 0.f;
+    for (int kt0 = 0; kt0 < ntiles; ++kt0) {           // (the staging registers live inside one iteration: carried across the
+    if (MULTI && kt0) __syncthreads();                 //  loop or a barrier, hipcc parked them in scratch memory)
+    {                                                  // (barrier: every wave is done with the previous tile's images)
+        Staged<T, G::NTH> sk_, sv_;
+        sk_.load(kn + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
+        sv_.load(v + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
+        sk_.store(ks_, nullptr, tid);
+        sv_.store(vs_, nullptr, tid);
+    }
+    __syncthreads();
 #pragma unroll 2
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
@@ -210,11 +217,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa = pack8(a, 8 * s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                oa[dt] = MFMA32(pa, frag_tr_rows(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt]);
+            oa0 = MFMA32(pa, frag_tr_rows(vs_, 0, 32 * kt + 16 * s2, lane), oa0);
+            oa1 = MFMA32(pa, frag_tr_rows(vs_, 32, 32 * kt + 16 * s2, lane), oa1);
         }
     }
+    }   // key tiles
     lsum += __shfl_xor(lsum, 32, 64);
     const int b = (int)(bh / H), hh = (int)(bh % H);
     const int D = H * 64;
@@ -223,22 +230,22 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const float il = __shfl(inv_l, acc_row(i, lane), 64);
-        c0[i] = oa[0][i] * il;
-        c1[i] = oa[1][i] * il;
+        c0[i] = oa0[i] * il;
+        c1[i] = oa1[i] * il;
     }
     __syncthreads();                                   // K / V images are dead: reuse them as store buffers
-    store_wave_tile(smem + wave * WT_BYTES, c0, c1, o + ((size_t)b * T + q0) * D + hh * 64, D, lane);
-    if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
+    store_wave_tile(smem + wave * WT_BYTES, c0, c1, o + ((size_t)b * Ttot + q0) * D + hh * 64, D, lane);
+    if (lane < 32) lse[bh * Ttot + q0 + r] = __logf(lsum);
 }
 
 // ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
-template <int T>
+template <int T, bool MULTI>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                  const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dqn,
                                                                  int H, float scale, const float* __restrict__ sq,
-                                                                 bf16_t* __restrict__ dqkv) {
+                                                                 bf16_t* __restrict__ dqkv, int Ttot) {
     using G = Geo<T>;
     constexpr int SM = 2 * T * 128 > G::NW * WF_BYTES ? 2 * T * 128 : G::NW * WF_BYTES;   // operands | store buffers
     __shared__ __attribute__((aligned(16))) char smem[SM];
@@ -249,28 +256,33 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
-    Staged<T, G::NTH> sk_, sv_;
-    sk_.load(kn + bh * T * 64, 64, tid);
-    sv_.load(v + bh * T * 64, 64, tid);
+    const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
     bf16x8_t qf[4], dof[4];
     float del_p = 0.f;                      // delta_q = rowsum(dO * O): this lane's 32 of the 64 features
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = *(const bf16x8_t*)(qn + (bh * T + q0 + r) * 64 + 16 * ks + 8 * h2);
-        const size_t mo = ((size_t)b * T + q0 + r) * D + hh * 64 + 16 * ks + 8 * h2;
+        qf[ks] = *(const bf16x8_t*)(qn + (bh * Ttot + q0 + r) * 64 + 16 * ks + 8 * h2);
+        const size_t mo = ((size_t)b * Ttot + q0 + r) * D + hh * 64 + 16 * ks + 8 * h2;
         dof[ks] = *(const bf16x8_t*)(dO + mo);
         const bf16x8_t of = *(const bf16x8_t*)(O + mo);
 #pragma unroll
         for (int e = 0; e < 8; ++e) del_p += up16((bf16_t)dof[ks][e]) * up16((bf16_t)of[e]);
     }
-    const float lse_q = lse[bh * T + q0 + r];
-    sk_.store(ks_, nullptr, tid);
-    sv_.store(vs_, nullptr, tid);
+    const float lse_q = lse[bh * Ttot + q0 + r];
     const float del_q = del_p + __shfl_xor(del_p, 32, 64);
-    if (h2 == 0) delta[bh * T + q0 + r] = del_q;       // consumed by the dK/dV pass (launched after this kernel)
-    __syncthreads();
+    if (h2 == 0) delta[bh * Ttot + q0 + r] = del_q;    // consumed by the dK/dV pass (launched after this kernel)
 
-    f32x16_t dq[2] = {};
+    f32x16_t dq0 = {}, dq1 = {};
+    for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    if (MULTI && kt0) __syncthreads();
+    {
+        Staged<T, G::NTH> sk_, sv_;
+        sk_.load(kn + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
+        sv_.load(v + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
+        sk_.store(ks_, nullptr, tid);
+        sv_.store(vs_, nullptr, tid);
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t st = {}, dp = {};
@@ -287,34 +299,34 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t a = pack8(st, 8 * s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = MFMA32(a, frag_tr_rows(ks_, 32 * dt, 32 * kt + 16 * s2, lane), dq[dt]);
+            dq0 = MFMA32(a, frag_tr_rows(ks_, 0, 32 * kt + 16 * s2, lane), dq0);
+            dq1 = MFMA32(a, frag_tr_rows(ks_, 32, 32 * kt + 16 * s2, lane), dq1);
         }
     }
+    }   // key tiles
     __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
     if (dqkv) {
         // fused backward of q^ = q * s: straight into the q section of dqkv [M, 3D] (no dq^ round trip through HBM, no
         // separate merge kernel)
-        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dq[0], dq[1], dqkv + ((size_t)b * T + q0) * (3 * D) + hh * 64, 3 * D,
-                            qn + (bh * T + q0) * 64, sq + bh * T + q0, lane);
+        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dq0, dq1, dqkv + ((size_t)b * Ttot + q0) * (3 * D) + hh * 64, 3 * D,
+                            qn + (bh * Ttot + q0) * 64, sq + bh * Ttot + q0, lane);
         return;
     }
     char* wbuf = smem + wave * WT_BYTES;
     float c0[16], c1[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = dq[0][i]; c1[i] = dq[1][i]; }
-    store_wave_tile(wbuf, c0, c1, dqn + (bh * T + q0) * 64, 64, lane);
+    for (int i = 0; i < 16; ++i) { c0[i] = dq0[i]; c1[i] = dq1[i]; }
+    store_wave_tile(wbuf, c0, c1, dqn + (bh * Ttot + q0) * 64, 64, lane);
 }
 
 // ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
-template <int T>
+template <int T, bool MULTI>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                                   const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
                                                                   float scale, const float* __restrict__ sk,
-                                                                  bf16_t* __restrict__ dqkv) {
+                                                                  bf16_t* __restrict__ dqkv, int Ttot) {
     using G = Geo<T>;
     // (this pass keeps the transposed images: with four transposing reads per MFMA pair, their 2-way bank conflict on the
     // 128-byte-row layout costs more than the images' staging - measured 252 vs 228 us)
@@ -330,21 +342,26 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     const size_t bh = blockIdx.y;
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int k0 = blockIdx.x * 32 * G::NW + wave * 32;
-    Staged<T, G::NTH> sq_, sdo_;
-    sq_.load(qn + bh * T * 64, 64, tid);
-    sdo_.load(dO + (size_t)b * T * D + hh * 64, D, tid);
+    const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
     bf16x8_t kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *(const bf16x8_t*)(kn + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
-        vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+        kf[ks] = *(const bf16x8_t*)(kn + (bh * Ttot + k0 + r) * 64 + 16 * ks + 8 * h2);
+        vf[ks] = *(const bf16x8_t*)(v + (bh * Ttot + k0 + r) * 64 + 16 * ks + 8 * h2);
     }
-    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; del_s[i] = delta[bh * T + i]; }
-    sq_.store(qs_, qts_, tid);
-    sdo_.store(dos_, dots_, tid);
-    __syncthreads();
 
-    f32x16_t dk[2] = {}, dvv[2] = {};
+    f32x16_t dk0 = {}, dk1 = {}, dv0 = {}, dv1 = {};
+    for (int qt0 = 0; qt0 < ntiles; ++qt0) {               // query tiles of T rows (one when the head has <= 256 tokens)
+    if (MULTI && qt0) __syncthreads();
+    {
+        Staged<T, G::NTH> sq_, sdo_;
+        sq_.load(qn + (bh * Ttot + (size_t)qt0 * T) * 64, 64, tid);
+        sdo_.load(dO + ((size_t)b * Ttot + (size_t)qt0 * T) * D + hh * 64, D, tid);
+        for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * Ttot + qt0 * T + i]; del_s[i] = delta[bh * Ttot + qt0 * T + i]; }
+        sq_.store(qs_, qts_, tid);
+        sdo_.store(dos_, dots_, tid);
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int qt = 0; qt < G::NT; ++qt) {
         f32x16_t s = {}, dp = {};
@@ -363,41 +380,43 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dvv[dt] = MFMA32(pa, frag_tr<T>(dots_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt]);
-                dk[dt] = MFMA32(da, frag_tr<T>(qts_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt]);
-            }
+            dv0 = MFMA32(pa, frag_tr<T>(dots_, 0, 32 * qt + 16 * s2, lane), dv0);
+            dk0 = MFMA32(da, frag_tr<T>(qts_, 0, 32 * qt + 16 * s2, lane), dk0);
+            dv1 = MFMA32(pa, frag_tr<T>(dots_, 32, 32 * qt + 16 * s2, lane), dv1);
+            dk1 = MFMA32(da, frag_tr<T>(qts_, 32, 32 * qt + 16 * s2, lane), dk1);
         }
     }
+    }   // query tiles
     __syncthreads();                                   // Q / dO images are dead: reuse them as store buffers
     char* wbuf = smem + wave * WT_BYTES;
     float c0[16], c1[16];
     if (dqkv) {                                        // as in the dQ pass: k section with the normalisation Jacobian, v as is
-        bf16_t* dst = dqkv + ((size_t)b * T + k0) * (3 * D) + D + hh * 64;
-        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dk[0], dk[1], dst, 3 * D, kn + (bh * T + k0) * 64, sk + bh * T + k0, lane);
+        bf16_t* dst = dqkv + ((size_t)b * Ttot + k0) * (3 * D) + D + hh * 64;
+        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dk0, dk1, dst, 3 * D, kn + (bh * Ttot + k0) * 64, sk + bh * Ttot + k0, lane);
         wbuf = smem + wave * WF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
+        for (int i = 0; i < 16; ++i) { c0[i] = dv0[i]; c1[i] = dv1[i]; }
         store_wave_tile(wbuf, c0, c1, dst + D, 3 * D, lane);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = dk[0][i]; c1[i] = dk[1][i]; }
-    store_wave_tile(wbuf, c0, c1, dkn + (bh * T + k0) * 64, 64, lane);
+    for (int i = 0; i < 16; ++i) { c0[i] = dk0[i]; c1[i] = dk1[i]; }
+    store_wave_tile(wbuf, c0, c1, dkn + (bh * Ttot + k0) * 64, 64, lane);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
-    store_wave_tile(wbuf, c0, c1, dv + (bh * T + k0) * 64, 64, lane);
+    for (int i = 0; i < 16; ++i) { c0[i] = dv0[i]; c1[i] = dv1[i]; }
+    store_wave_tile(wbuf, c0, c1, dv + (bh * Ttot + k0) * 64, 64, lane);
 }
 
 MD_NS_CLOSE
 
+// TT = the tile of keys / queries a workgroup stages at a time: the whole head up to 256 tokens, 256 of them beyond (T % 256 == 0)
 #define ATTN_DISPATCH(T_, CALL)                                                         \
-    switch (T_) {                                                                       \
-        case 64: { constexpr int TT = 64; CALL; break; }                                \
-        case 128: { constexpr int TT = 128; CALL; break; }                              \
-        case 256: { constexpr int TT = 256; CALL; break; }                              \
-        default: mapdit_set_error("attention: T=%d unsupported (64, 128, 256)", T_); return MAPDIT_ERR_ARG; \
+    switch ((T_) > 256 && (T_) % 256 == 0 ? 512 : (T_)) {                               \
+        case 64: { constexpr int TT = 64; constexpr bool MT = false; CALL; break; }     \
+        case 128: { constexpr int TT = 128; constexpr bool MT = false; CALL; break; }   \
+        case 256: { constexpr int TT = 256; constexpr bool MT = false; CALL; break; }   \
+        case 512: { constexpr int TT = 256; constexpr bool MT = true; CALL; break; }    /* > 256 tokens: 256-token tiles */ \
+        default: mapdit_set_error("attention: T=%d unsupported (64, 128, 256 or a multiple of 256)", T_); return MAPDIT_ERR_ARG; \
     }
 
 // Generic-shape path (attention_generic.hip): any head_dim <= 96, any T <= 256.
@@ -405,7 +424,7 @@ extern "C" int MD_SYM(attn_generic_fwd)(const uint16_t*, const uint16_t*, const 
 extern "C" int MD_SYM(attn_generic_bwd)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*,
                                        const float*, float*, uint16_t*, uint16_t*, uint16_t*, int, int, int, int, void*);
 
-static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 || T == 128 || T == 256); }
+static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 || T == 128 || (T >= 256 && T % 256 == 0)); }
 // head_dim 72 (DiT-XL): MFMA kernels of attention72.hip; an escape hatch keeps the generic path reachable for A/B runs
 int MD_SYM(attn72_fwd)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
 int MD_SYM(attn72_bwd)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
@@ -423,8 +442,8 @@ extern "C" int MD_SYM(attn_cos_fwd)(const uint16_t* qn, const uint16_t* kn, cons
     if (!mfma_shape(T, head_dim)) return MD_SYM(attn_generic_fwd)(qn, kn, v, o, lse, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, o, lse, H, scale));
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, o, lse, H, scale, T));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
@@ -437,11 +456,11 @@ extern "C" int MD_SYM(attn_cos_bwd)(const uint16_t* qn, const uint16_t* kn, cons
     if (!mfma_shape(T, head_dim)) return MD_SYM(attn_generic_bwd)(qn, kn, v, dO, O, lse, delta, dqn, dkn, dv, B, T, H, head_dim, stream);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, O, lse, delta, dqn, H, scale, (const float*)nullptr, (bf16_t*)nullptr));
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, O, lse, delta, dqn, H, scale, (const float*)nullptr, (bf16_t*)nullptr, T));
     MD_LAUNCH_CHECK();
-    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, lse, delta, dkn, dv, H, scale, (const float*)nullptr, (bf16_t*)nullptr));
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, lse, delta, dkn, dv, H, scale, (const float*)nullptr, (bf16_t*)nullptr, T));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
@@ -450,16 +469,16 @@ extern "C" int MD_SYM(attn_cos_bwd_fused)(const uint16_t* qn, const uint16_t* kn
                                          const uint16_t* O, const float* lse, float* delta, const float* scales,
                                          uint16_t* dqkv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && scales && dqkv, "attn_cos_bwd_fused: null argument");
-    MD_CHECK(mfma_shape(T, head_dim), "attn_cos_bwd_fused: head_dim=%d, T=%d unsupported (64; 64/128/256)", head_dim, T);
+    MD_CHECK(mfma_shape(T, head_dim), "attn_cos_bwd_fused: head_dim=%d, T=%d unsupported (64; 64, 128 or a multiple of 256)", head_dim, T);
     const float scale = 0.125f;
     const float* sq = scales;
     const float* sk = scales + (size_t)B * H * T;
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, O, lse, delta, (bf16_t*)nullptr, H, scale, sq, dqkv));
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, O, lse, delta, (bf16_t*)nullptr, H, scale, sq, dqkv, T));
     MD_LAUNCH_CHECK();
-    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT>), dim3(TT / (32 * Geo<TT>::NW), B * H), dim3(Geo<TT>::NTH), 0, st,
-                                        qn, kn, v, dO, lse, delta, (bf16_t*)nullptr, (bf16_t*)nullptr, H, scale, sk, dqkv));
+    ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
+                                        qn, kn, v, dO, lse, delta, (bf16_t*)nullptr, (bf16_t*)nullptr, H, scale, sk, dqkv, T));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -311,7 +311,11 @@ int check_cfg(const mapdit_config_t* c) {
              "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
     MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
     const int g = c->input_size / c->patch, T = g * g;
-    MD_CHECK(T >= 1 && T <= 256, "engine: %d tokens per sample unsupported (<= 256)", T);
+    // up to 256 tokens: any count (MFMA attention for 64 / 128 / 256 tokens at head_dim 64 or 72, the generic kernels otherwise);
+    // beyond (64x64 latents at patch 2 = 1,024): the MFMA attention kernels loop over 256-token tiles - head_dim 64, bf16 / fp16
+    const int hd_ = c->hidden / c->num_heads;
+    MD_CHECK(T >= 1 && (T <= 256 || (T % 256 == 0 && T <= 16384 && hd_ == 64 && c->precision != MAPDIT_PREC_BF16X3)),
+             "engine: %d tokens per sample unsupported (<= 256; a multiple of 256 with head_dim 64 in bf16 / f16 precision)", T);
     MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
     MD_CHECK(c->patch * c->patch * c->in_channels <= 256 && (c->patch * c->patch * c->in_channels) % 4 == 0,
              "engine: patch dim %d unsupported", c->patch * c->patch * c->in_channels);
@@ -332,7 +336,7 @@ void init_dims(mapdit_engine* e) {
     e->hd = c.hidden / c.num_heads;
     // MFMA attention kernels: head_dim 64 and 64/128/256 tokens; everything else (XL: 72, patch-8: 16 tokens) takes the
     // generic fp32 path of attention_generic.hip
-    e->generic_attn = !(e->hd == 64 && (e->T == 64 || e->T == 128 || e->T == 256));
+    e->generic_attn = !(e->hd == 64 && (e->T == 64 || e->T == 128 || (e->T >= 256 && e->T % 256 == 0)));
     e->M_max = c.max_batch * e->T;
     const int D = c.hidden;
     e->rot = c.rotation != 0;

@@ -351,6 +351,12 @@ if __name__ == "__main__":
         fixture("tiny_p8", O.DiTConfig(depth=1, hidden_size=128, patch_size=8, input_size=32, in_channels=4, num_heads=2,
                                        num_classes=10), n=3, wseed=9, dseed=10, gains=0.3, perturb=0.3)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        # more than 256 tokens per sample: 64x64 latents at patch 2 = 1,024 tokens (DiT(input_size=...) is free in the reference,
+        # src/dit.py:15-27; attention is plain SDPA over all tokens, src/layers/attention.py:47): depth 2, head_dim 64
+        fixture("t1024_d2", O.DiTConfig(depth=2, hidden_size=128, patch_size=2, input_size=64, in_channels=4, num_heads=2,
+                                        num_classes=10), n=2, wseed=11, dseed=12, gains=0.3, perturb=0.3, full=False, check_tol=5e-5)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tables":
         tables()
         sys.exit(0)

@@ -71,7 +71,11 @@ def test_workspace_query_and_config_errors():
     assert b"hidden" in lib.last_error()
     big = L.Config(depth=2, hidden=256, patch=2, input_size=64, in_channels=4, num_heads=4, mlp_hidden=1024,
                    table_rows=11, max_batch=2)
-    assert lib.engine_workspace_bytes(ctypes.byref(big), 0) == 0 and b"tokens" in lib.last_error()   # 1024 tokens
+    assert lib.engine_workspace_bytes(ctypes.byref(big), 0) > 0             # 1,024 tokens, head_dim 64: tiled MFMA attention
+    big.num_heads = 8                                                      # head_dim 32 would need the generic kernels (<= 256 tokens)
+    assert lib.engine_workspace_bytes(ctypes.byref(big), 0) == 0 and b"tokens" in lib.last_error()
+    big.num_heads, big.input_size = 4, 36                                  # 324 tokens: not a multiple of 256
+    assert lib.engine_workspace_bytes(ctypes.byref(big), 0) == 0 and b"tokens" in lib.last_error()
 
 
 def test_build_is_decided_by_source_digest_not_file_times(monkeypatch):

@@ -491,7 +491,7 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
     a.T = T
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (1, 256, 3), (3, 128, 1)])
+@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (1, 256, 3), (3, 128, 1), (1, 512, 2), (2, 1024, 1)])     # > 256 tokens: 256-token tiles
 def test_attention_fwd_bwd(L, B, T, H):
     """qkv split + cosine normalise + attention forward and the whole backward chain vs autograd of the oracle ops."""
     from oracle.dit_oracle import normalize
@@ -536,7 +536,7 @@ def test_attention_fwd_bwd(L, B, T, H):
     assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
 
 
-@pytest.mark.parametrize("B,T,H,K", [(2, 64, 2, 128), (1, 256, 3, 192), (8, 128, 4, 256), (3, 64, 1, 64)])
+@pytest.mark.parametrize("B,T,H,K", [(2, 64, 2, 128), (1, 256, 3, 192), (8, 128, 4, 256), (3, 64, 1, 64), (1, 512, 2, 128), (1, 1024, 1, 64)])
 def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
     """QKV GEMM with the head split + cosine normalisation in its epilogue (MAPDIT_EPI_QKV_HEADS), attention forward, and
     the backward that writes dqkv directly (normalisation Jacobian + head merge inside the two passes) against autograd
