@@ -32,7 +32,7 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 3: _f16 twins; grad scale arguments (final_out_bwd, rotate_bwd, resid_mod_bwd_t.dgain_scale);
+int mapdit_abi_version(void);   /* 3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
                                  * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -91,6 +91,8 @@ typedef struct {
     long slab_stride;  /* elements between slabs (the consumer adds the slabs: mapdit_weightnorm_bwd) */
     void* out4;        /* QKV_HEADS only: the per-(token, head) normalisation scales */
     const void* rmb;   /* RMB only: const mapdit_resid_mod_bwd_t* (declared below) */
+    int rot2;          /* RESID with out3: != 0 = rotation modulation, out3 = bf16(out2 * scale2 + pairswap(out2) * shift2) with
+                        * scale2 / shift2 the A / B coefficient rows of mapdit_rot_coef_fwd (gain2 is not read) */
 } mapdit_epilogue_t;
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
@@ -187,6 +189,9 @@ typedef struct {
     /* optional: the scalar gain gradient itself - the partials are then summed here (in partial order, as mapdit_reduce_partials
      * does; inside the row-split form's second kernel when that form is taken) and *gain_partials_out receives 0 */
     float* dgain_out;
+    /* rotation modulation (0 = off): u[j] = scale[j] x'[j] + shift[j] x'[j ^ 1] with scale / shift the A / B coefficient rows of
+     * mapdit_rot_coef_fwd; dscale / dshift then receive dA / dB (input of mapdit_rot_coef_bwd) and no gain partial is produced */
+    int rot;
     /* optional (0 = 1): factor on the scalar gain gradient (its partials).  An fp16 engine runs its backward on gradients
      * multiplied by a power-of-two loss scale and passes 1/scale here: parameter gradients leave the library unscaled. */
     float dgain_scale;
@@ -194,13 +199,20 @@ typedef struct {
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
 
 /* Rotation modulation (the reference's README.md:1-3; NOT in its snapshot - parity unpinned, semantics: oracle.modulate_rot):
- * in place on the bf16 operand u [n_samples*T, D] = x * scale: (u[2i], u[2i+1]) <- R(*gain * theta[n, i]) (u[2i], u[2i+1]);
- * theta fp32 rows of D/2 angles, stride ldt.  The backward rotates the gradient back in place (dy <- R^T dy), writes
- * dtheta[n, i] = *gain * sum_t (dy1 y0 - dy0 y1) (y = the saved rotated operand) and n_samples * D/128 partial sums of dgain,
- * each multiplied by dgain_scale (1 unless the gradients carry a loss scale, see mapdit_resid_mod_bwd_t.dgain_scale). */
-int mapdit_rotate_fwd(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D, void* stream);
-int mapdit_rotate_bwd(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta, int ldd,
-                      float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream);
+ *   (y[2i], y[2i+1]) = R(*gain * theta[n, i]) (scale[n, 2i] x[2i], scale[n, 2i+1] x[2i+1])
+ * is linear in x per (sample, column): y[j] = A[n, j] x[j] + B[n, j] x[j ^ 1].  mapdit_rot_coef_fwd writes the fp32 rows A, B
+ * [n_samples][D] (stride ldc) from the theta (D/2 angles) and scale (D) rows of stride ldm - once per step and branch, one sincos
+ * per pair instead of one per token.  Consumers: MAPDIT_EPI_RESID with rot2 (the modulate fused into the residual GEMM epilogues),
+ * mapdit_rot_modulate_fwd (out = 16-bit(x * A + pairswap(x) * B): block 0's first modulate) and mapdit_resid_mod_bwd with rot,
+ * whose per-sample sums dA, dB mapdit_rot_coef_bwd turns into dtheta [n][D/2], dscale [n][D] (rows of stride ldd) and
+ * ceil(D/512) * n_samples partials of the gain gradient, each multiplied by dgain_scale (0 = 1; see dgain_scale above). */
+int mapdit_rot_coef_fwd(const float* theta, const float* scale, int ldm, const float* gain, float* A, float* B, int ldc,
+                        int n_samples, int D, void* stream);
+int mapdit_rot_coef_bwd(const float* dA, const float* dB, int ldc, const float* theta, const float* scale, int ldm,
+                        const float* gain, float* dtheta, float* dscale, int ldd, float* dgain_part, float dgain_scale,
+                        int n_samples, int D, void* stream);
+int mapdit_rot_modulate_fwd(const float* x, const float* A, const float* B, int ldc, uint16_t* out, int n_samples, int T, int D,
+                            void* stream);
 int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream);
 
 int mapdit_mpsilu_to_bf16(const float* x, uint16_t* out, long n, void* stream);          /* mp_silu.py:7 */
@@ -211,8 +223,9 @@ int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_strid
 
 /* ------------------------------------------------------------------------------------------------------------
  * Cosine attention (src/layers/attention.py:37-51).  Head-major operands are [B*H][T][head_dim] bf16, row-major.
- * head_dim 64 with T in {64, 128, 256} runs on the MFMA kernels; any other head_dim <= 96 / T <= 256 (DiT-XL: 72,
- * patch-8 models: 16 tokens) is dispatched to the generic fp32 path with the same interface.
+ * head_dim 64 with T in {64, 128, 256} - or any multiple of 256 (64x64 latents at patch 2: 1,024 tokens; the kernels then loop
+ * over 256-token key / query tiles) - runs on the MFMA kernels, head_dim 72 (DiT-XL) with T in {64, 128, 256} too; any other
+ * head_dim <= 96 with T <= 256 (patch-8 models: 16 tokens) is dispatched to the generic fp32 path with the same interface.
  * ------------------------------------------------------------------------------------------------------------ */
 /* qkv [B*T, 3*H*hd] -> qn, kn (cosine-normalised: q*sqrt(hd)/(|q|+eps)), v */
 int mapdit_qkv_split(const uint16_t* qkv, int B, int T, int H, int head_dim, uint16_t* qn, uint16_t* kn, uint16_t* v,
@@ -228,7 +241,7 @@ int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* 
                         int head_dim, void* stream);
 /* Same backward with the normalisation Jacobian of q^ = q * s, k^ = k * s (s = 8 / (|.| + 1e-4), attention.py:43 through
  * src/utils.py:19-23) and the head merge fused into the two passes: writes dqkv [B*T, 3*H*64] = grad of the QKV projection's
- * output directly.  scales = the fp32 [2][B*H][T] array MAPDIT_EPI_QKV_HEADS wrote.  head_dim 64, T in {64, 128, 256}. */
+ * output directly.  scales = the fp32 [2][B*H][T] array MAPDIT_EPI_QKV_HEADS wrote.  head_dim 64, T in {64, 128, 256} or a multiple of 256. */
 int mapdit_attn_cos_bwd_fused(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                               const float* lse, float* delta, const float* scales, uint16_t* dqkv, int B, int T, int H,
                               int head_dim, void* stream);
@@ -308,7 +321,8 @@ typedef struct {
                      * split into hi+lo bf16 terms along the reduction index (3x the GEMM work, unfused fp32 pointwise and
                      * attention kernels); logits, losses and parameter gradients agree with the fp32 reference to ~1e-5. */
     int rotation;   /* != 0: rotation modulation (README.md:1-3; parity unpinned): a block's modulation linear has 5*hidden rows
-                     * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m).  Not with MAPDIT_PREC_BF16X3. */
+                     * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m); the rotation is fused into the residual GEMM epilogues and
+                     * the residual / modulate backward (mapdit_rot_coef_fwd above).  Not with MAPDIT_PREC_BF16X3. */
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
                        * divided by it again before it is written.  0 = chosen per backward from the batch:
@@ -400,9 +414,8 @@ int mapdit_weightnorm_fwd_batch_f16(const mapdit_wn_job_t* jobs_dev, int njobs, 
 int mapdit_modulate_fwd_f16(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
                             uint16_t* out, int n_samples, int T, int D, void* stream);
 int mapdit_resid_mod_bwd_f16(const mapdit_resid_mod_bwd_t* args, void* stream);
-int mapdit_rotate_fwd_f16(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D, void* stream);
-int mapdit_rotate_bwd_f16(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta, int ldd,
-                          float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream);
+int mapdit_rot_modulate_fwd_f16(const float* x, const float* A, const float* B, int ldc, uint16_t* out, int n_samples, int T, int D,
+                                void* stream);
 int mapdit_mpsilu_to_f16(const float* x, uint16_t* out, long n, void* stream);
 int mapdit_f32_to_f16(const float* x, uint16_t* out, long n, float alpha, void* stream);
 int mapdit_f32_to_f16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream);

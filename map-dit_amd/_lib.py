@@ -24,7 +24,7 @@ class MapditError(RuntimeError):
 class Epilogue(C.Structure):
     _fields_ = [("kind", ci), ("out", vp), ("ldo", ci), ("out2", vp), ("aux", vp), ("gate", vp), ("ldg", ci),
                 ("rows_per_sample", ci), ("alpha", cf), ("beta", cf), ("accumulate", ci), ("out3", vp), ("shift2", vp), ("scale2", vp),
-                ("gain2", vp), ("ld2", ci), ("split_k", ci), ("slab_stride", cl), ("out4", vp), ("rmb", vp)]
+                ("gain2", vp), ("ld2", ci), ("split_k", ci), ("slab_stride", cl), ("out4", vp), ("rmb", vp), ("rot2", ci)]
 
 
 class ResidModBwd(C.Structure):
@@ -32,7 +32,7 @@ class ResidModBwd(C.Structure):
                 ("g_up", vp), ("dx", vp), ("dx_bf", vp), ("dshift", vp), ("dscale", vp), ("dgain_part", vp),
                 ("dy_up", vp), ("dg_up", vp), ("ldmod", ci), ("ldg_up", ci), ("ldd", ci), ("ldd_up", ci),
                 ("n_samples", ci), ("T", ci), ("D", ci), ("ca", cf), ("cb", cf), ("part_scratch", vp), ("part_scratch_bytes", C.c_size_t),
-                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("dgain_scale", cf)]
+                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("rot", ci), ("dgain_scale", cf)]
 
 
 class WnJob(C.Structure):          # mapdit_wn_job_t
@@ -77,8 +77,9 @@ _SIGS = {
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
-    "mapdit_rotate_fwd": [vp, vp, ci, vp, ci, ci, ci, vp],
-    "mapdit_rotate_bwd": [vp, vp, vp, ci, vp, vp, ci, vp, cf, ci, ci, ci, vp],
+    "mapdit_rot_coef_fwd": [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp],
+    "mapdit_rot_coef_bwd": [vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, cf, ci, ci, vp],
+    "mapdit_rot_modulate_fwd": [vp, vp, vp, ci, vp, ci, ci, ci, vp],
     "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
@@ -121,7 +122,7 @@ _SIGS = {
     "mapdit_engine_peek": [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(ci), C.POINTER(ci)],
 }
 # IEEE fp16 operand forms: same signatures (mapdit.h, "16-bit operand format")
-for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rotate_fwd", "rotate_bwd", "qkv_split",
+for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rot_modulate_fwd", "qkv_split",
            "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
            "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
     _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]

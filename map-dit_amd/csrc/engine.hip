@@ -52,7 +52,10 @@ struct mapdit_engine {
     // 5 D wide.  MW = its width, o_* = the offsets of the chunks (o_sh* = the shift resp. angle chunk).
     bool rot = false;
     int MW = 0, o_sha = 0, o_sca = 0, o_ga = 0, o_shm = 0, o_scm = 0, o_gm = 0;
-    float *zero_rows = nullptr, *sink_rows = nullptr, *zero_gain = nullptr, *sink_gain = nullptr;   // rotation mode: see engine_create
+    // rotation mode: A / B coefficient rows of every (block, branch) [N][L*2*D] (mapdit_rot_coef_fwd), scratch rows for their
+    // gradients [N][D] each, a zero scalar for the gain arguments the rotation forms do not read
+    float *rotA = nullptr, *rotB = nullptr, *rot_dA = nullptr, *rot_dB = nullptr, *zero_gain = nullptr;
+    int ldc = 0;                          // = L*2*D
     bool generic_attn = false;
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
     float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
@@ -251,10 +254,12 @@ size_t carve(mapdit_engine* e, void* base) {
         bf16_t* modall = cv.take<bf16_t>((size_t)3 * L * e->MW * D);                 // one [L*MW][3D] operand
         for (int i = 0; i < L; ++i) e->cp.img3[pidx_block(i, MAPDIT_B_MOD)] = modall + (size_t)i * e->MW * 3 * D;
         if (e->rot) {
-            e->zero_rows = cv.take<float>((size_t)N * L * e->MW);
-            e->sink_rows = cv.take<float>((size_t)N * L * e->MW);
+            e->ldc = L * 2 * D;
+            e->rotA = cv.take<float>((size_t)N * e->ldc);
+            e->rotB = cv.take<float>((size_t)N * e->ldc);
+            e->rot_dA = cv.take<float>((size_t)N * D);
+            e->rot_dB = cv.take<float>((size_t)N * D);
             e->zero_gain = cv.take<float>(64);
-            e->sink_gain = e->zero_gain + 32;
         }
     }
     if (e->train) {
@@ -397,8 +402,9 @@ mapdit_epilogue_t epi_dsilu(bf16_t* out, const bf16_t* pre, int ldo) {
 }
 const float CA = 0.7f / sqrtf(0.58f), CB = 0.3f / sqrtf(0.58f);   // mp_sum(x, y, 0.3): src/utils.py:15-16
 mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo,
-                            bf16_t* xm_next, const float* nshift, const float* nscale, int ldn, const float* ngain) {
+                            bf16_t* xm_next, const float* nshift, const float* nscale, int ldn, const float* ngain, int rot = 0) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
+    e.rot2 = rot;                                      // rotation form: nscale / nshift are the A / B rows (mapdit_rot_coef_fwd)
     e.kind = MAPDIT_EPI_RESID; e.out = y; e.out2 = xout; e.aux = xin; e.gate = gate; e.ldg = ldg; e.rows_per_sample = rows;
     e.ldo = ldo; e.alpha = CA; e.beta = CB;
     e.out3 = xm_next; e.shift2 = nshift; e.scale2 = nscale; e.ld2 = ldn; e.gain2 = ngain;   // modulate() of the next branch
@@ -423,12 +429,13 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
 // dxm (bf16) and mapdit_resid_mod_bwd follows (row-split at small batches).  Both can also run as ONE launch whose epilogue consumes
 // the accumulators (MAPDIT_EPI_RMB; whole 64-row blocks per sample, 256x256 tiles) - measured, not faster, opt-in (see below).
 // `a` arrives filled except for dxm.  Ends with the deterministic sum of the gain partials.
-// Rotation modulation (rot != nullptr): the dX result is first rotated back in place (mapdit_rotate_bwd: also the angle and gain
-// gradients), then the usual backward runs on it with shift = 0 and gain = 0, its shift / gain gradients going to sinks.
+// Rotation modulation (rot != nullptr): `a` arrives with scale / shift = the branch's A / B coefficient rows and rot = 1; the pass
+// leaves dA, dB in e->rot_dA / rot_dB and mapdit_rot_coef_bwd turns them into the block's dtheta / dscale chunks and the gain gradient.
 struct RotBwd {
-    const bf16_t* y;       // the saved rotated operand (xm / xm2 of the block)
-    const float* theta;    // the block's angle chunk in mod_all
-    float* dtheta;         // its slot in dmod
+    const float* theta;    // the branch's angle chunk in mod_all
+    const float* scale;    // its scale chunk
+    float* dtheta;         // their slots in dmod
+    float* dscale;
     const float* gain;     // the block's learnable gain
 };
 int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy, const bf16_t* wimg, mapdit_resid_mod_bwd_t& a,
@@ -445,12 +452,13 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     a.dgain_scale = e->ginv;                            // fp16: the gradients carry the loss scale, the gain gradient must not
     if (rot) {
         TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
-        TRY(DT_FN(e, mapdit_rotate_bwd)(e->dxm, rot->y, rot->theta, e->ldm, rot->gain, rot->dtheta, e->ldm, e->gain_part, e->ginv,
-                                        a.n_samples, a.T, D, st));
-        TRY(mapdit_reduce_partials(e->gain_part, a.n_samples * (D / 128), dgain, 0, st));
         a.dxm = e->dxm;
-        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&a, st));    // a.shift / a.gain / a.dshift point at the zero rows, zero gain and sinks
-        return MAPDIT_OK;
+        a.rot = 1;
+        a.dshift = e->rot_dB; a.dscale = e->rot_dA; a.ldd = D;
+        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&a, st));
+        TRY(mapdit_rot_coef_bwd(e->rot_dA, e->rot_dB, D, rot->theta, rot->scale, e->ldm, rot->gain, rot->dtheta, rot->dscale, e->ldm,
+                                e->gain_part, e->ginv, a.n_samples, D, st));
+        return mapdit_reduce_partials(e->gain_part, a.n_samples * cdiv(D / 2, 256), dgain, 0, st);
     }
     if (!no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
@@ -540,8 +548,6 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
     hipError_t he = hipMemsetAsync(fl.img, 0, (size_t)e->ldl * fl.cols * sizeof(bf16_t) * (cfg->precision == MAPDIT_PREC_BF16X3 ? 3 : 1),
                                    (hipStream_t)stream);
     if (he == hipSuccess && train && e->dlin) he = hipMemsetAsync(e->dlin, 0, e->zero_bytes_dlin, (hipStream_t)stream);
-    // rotation mode: the fused modulate kernels run with shift = 0 and gain = 0 (u = x * scale); their shift / gain gradients go to sinks
-    if (he == hipSuccess && e->rot) he = hipMemsetAsync(e->zero_rows, 0, (size_t)cfg->max_batch * e->ldm * sizeof(float), (hipStream_t)stream);
     if (he == hipSuccess && e->rot) he = hipMemsetAsync(e->zero_gain, 0, 64 * sizeof(float), (hipStream_t)stream);
     if (he != hipSuccess) {
         delete e;
@@ -895,20 +901,37 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_MPSILU, st));
     TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm), st));
     TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D), st));
-    // rotation modulation: the fused modulates run with shift = 0, gain = 0 (u = x * scale) and mapdit_rotate_fwd turns u in place
-    const float* sh_base = e->rot ? e->zero_rows : e->mod_all;            // where the "shift" chunks are read from
+    // The (scale, shift) rows of a branch's modulate and the gain it blends them with.  Rotation modulation: the A / B coefficient
+    // rows of y[j] = A x[j] + B x[j ^ 1] (mapdit_rot_coef_fwd: one pass over [samples, L * 2 * D], one sincos per pair), read by the
+    // same fused epilogues in their rot form - slot (block, branch) at column (2 * block + branch) * D.
+    if (e->rot) {
+        for (int i = 0; i < L; ++i) {
+            const float* mod = e->mod_all + (size_t)i * e->MW;
+            TRY(mapdit_rot_coef_fwd(mod + e->o_sha, mod + e->o_sca, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)],
+                                    e->rotA + (size_t)(2 * i) * D, e->rotB + (size_t)(2 * i) * D, e->ldc, N, D, st));
+            TRY(mapdit_rot_coef_fwd(mod + e->o_shm, mod + e->o_scm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)],
+                                    e->rotA + (size_t)(2 * i + 1) * D, e->rotB + (size_t)(2 * i + 1) * D, e->ldc, N, D, st));
+        }
+    }
+    const int rot = e->rot ? 1 : 0;
+    const int ldn = e->rot ? e->ldc : ldm;
+    auto sc_of = [&](int i, int br) -> const float* {       // br 0 = attention branch, 1 = MLP branch
+        return e->rot ? e->rotA + (size_t)(2 * i + br) * D : e->mod_all + (size_t)i * e->MW + (br ? e->o_scm : e->o_sca);
+    };
+    auto sh_of = [&](int i, int br) -> const float* {
+        return e->rot ? e->rotB + (size_t)(2 * i + br) * D : e->mod_all + (size_t)i * e->MW + (br ? e->o_shm : e->o_sha);
+    };
     auto gain_of = [&](int pidx) -> const float* { return e->rot ? e->zero_gain : e->params[pidx]; };
-    TRY(DT_FN(e, mapdit_modulate_fwd)(e->X[0], sh_base + e->o_sha, e->mod_all + e->o_sca, ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)),
-                            e->blk[0].xm, N, T, D, st));
+    if (e->rot) TRY(DT_FN(e, mapdit_rot_modulate_fwd)(e->X[0], sc_of(0, 0), sh_of(0, 0), ldn, e->blk[0].xm, N, T, D, st));
+    else TRY(DT_FN(e, mapdit_modulate_fwd)(e->X[0], sh_of(0, 0), sc_of(0, 0), ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)), e->blk[0].xm,
+                                           N, T, D, st));
     for (int i = 0; i < L; ++i) {
         BlockBufs& b = e->blk[save ? i : 0];
         const float* mod = e->mod_all + (size_t)i * e->MW;
-        const float* shm = sh_base + (size_t)i * e->MW;                    // the block's row of shift chunks (zeros with rotation)
         float* xin = e->X[save ? 2 * i : (2 * i) % 3];
         float* xmid = e->X[save ? 2 * i + 1 : (2 * i + 1) % 3];
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
         const float* gmlp = gain_of(pidx_block(i, MAPDIT_B_GAIN_MLP));
-        if (e->rot) TRY(DT_FN(e, mapdit_rotate_fwd)(b.xm, mod + e->o_sha, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)], N, T, D, st));
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         if (e->generic_attn) {
             TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
@@ -924,8 +947,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         }
         TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
-                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, shm + e->o_shm, mod + e->o_scm, ldm, gmlp), st));
-        if (e->rot) TRY(DT_FN(e, mapdit_rotate_fwd)(b.xm2, mod + e->o_shm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)], N, T, D, st));
+                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
@@ -933,7 +955,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm16(e, MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
                  i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
-                                       shm + e->MW + e->o_sha, mod + e->MW + e->o_sca, ldm, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)))
+                                       sh_of(i + 1, 0), sc_of(i + 1, 0), ldn, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)), rot)
                            : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
                                        e->params[MAPDIT_P_F_GAIN]), st));
     }
@@ -1062,21 +1084,24 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         float* dmod = e->dmod + (size_t)i * e->MW;            // [N][L*MW] like mod_all
         const float* mod = e->mod_all + (size_t)i * e->MW;
         const int ldm = e->ldm;
-        // rotation modulation: shift chunks read as zeros, their gradients (and the fused modulate's gain partials) written to sinks
-        const float* shm = (e->rot ? e->zero_rows : e->mod_all) + (size_t)i * e->MW;
-        float* dshm = (e->rot ? e->sink_rows : e->dmod) + (size_t)i * e->MW;
+        // rotation modulation: the (scale, shift) rows are the branch's A / B coefficient rows (dx_resid_mod_bwd routes the sums)
+        const float* sc_a = e->rot ? e->rotA + (size_t)(2 * i) * D : mod + e->o_sca;
+        const float* sh_a = e->rot ? e->rotB + (size_t)(2 * i) * D : mod + e->o_sha;
+        const float* sc_m = e->rot ? e->rotA + (size_t)(2 * i + 1) * D : mod + e->o_scm;
+        const float* sh_m = e->rot ? e->rotB + (size_t)(2 * i + 1) * D : mod + e->o_shm;
+        const int ldn = e->rot ? e->ldc : ldm;
         // MLP branch
         TRY(gemm16(e, MAPDIT_NN, M, Hm, D, e->dy, D, W(pidx_block(i, MAPDIT_B_FC2)), Hm, epi_mul_aux(e->dh, b.hdact, Hm), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC2), e->dy, D, b.hact, Hm, M, 1.f, st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = shm + e->o_shm; a.scale = mod + e->o_scm;
-            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldm;
-            a.dshift = dshm + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
+            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = sh_m; a.scale = sc_m;
+            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldn;
+            a.dshift = dmod + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
             a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
             a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            const RotBwd rb{b.xm2, mod + e->o_shm, dmod + e->o_shm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
+            const RotBwd rb{mod + e->o_shm, mod + e->o_scm, dmod + e->o_shm, dmod + e->o_scm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
             TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st,
                                  e->rot ? &rb : nullptr));
         }
@@ -1092,9 +1117,9 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = shm + e->o_sha; a.scale = mod + e->o_sca;
-            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldm;
-            a.dshift = dshm + e->o_sha; a.dscale = dmod + e->o_sca; a.ldd = ldm; a.dgain_part = e->gain_part;
+            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = sh_a; a.scale = sc_a;
+            a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldn;
+            a.dshift = dmod + e->o_sha; a.dscale = dmod + e->o_sca; a.ldd = ldm; a.dgain_part = e->gain_part;
             if (i > 0) {
                 const BlockBufs& bp = e->blk[i - 1];
                 a.y_up = bp.y2; a.g_up = mod - e->MW + e->o_gm; a.ldg_up = ldm; a.dy_up = e->dy;     // gate_mlp of block i-1
@@ -1104,7 +1129,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
             }
             a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
-            const RotBwd rb{b.xm, mod + e->o_sha, dmod + e->o_sha, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]};
+            const RotBwd rb{mod + e->o_sha, mod + e->o_sca, dmod + e->o_sha, dmod + e->o_sca, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]};
             TRY(dx_resid_mod_bwd(e, M, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), a, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), st,
                                  e->rot ? &rb : nullptr));
         }

@@ -312,6 +312,9 @@ struct EpiResid {
     bf16_t* y; const float* xin; float* xout; const float* gate; int ldo, ldg, rows; float ca, cb;
     // optional fused modulate of the NEXT branch (src/utils.py:11-16): xm = bf16(((1-g) xout scale + g shift) / den)
     bf16_t* xm; const float* nshift; const float* nscale; const float* ngain; int ldn;
+    // rot != 0: the next branch's modulate is the rotation form xm = bf16(xout * nscale + pairswap(xout) * nshift), nscale / nshift =
+    // the A / B coefficient rows of mapdit_rot_coef_fwd (pointwise.hip; reference README.md:1-3, parity unpinned); ngain is not read
+    int rot;
     struct Aux { float4 x0, x1; };
     struct Tile { float4 g0, g1, c0, c1, h0, h1; float ka, kb; int smp; };     // smp < 0: rows of several samples in the tile
     __device__ __forceinline__ void per_sample(int smp, int n, Tile& t) const {
@@ -327,7 +330,7 @@ struct EpiResid {
         Tile t;
         t.smp = m_first / rows == m_last / rows ? m_first / rows : -1;
         t.ka = t.kb = 0.f;
-        if (xm) {
+        if (xm && !rot) {
             const float gg = *ngain, den = sqrtf((1.f - gg) * (1.f - gg) + gg * gg);
             t.ka = (1.f - gg) / den; t.kb = gg / den;
         }
@@ -358,8 +361,13 @@ struct EpiResid {
             const float c[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
             const float h[8] = {t.h0.x, t.h0.y, t.h0.z, t.h0.w, t.h1.x, t.h1.y, t.h1.z, t.h1.w};
             float w[8];
+            if (rot) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
+                for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(o[i], c[i], o[i ^ 1] * h[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
+            }
             store8_bf16(xm + (size_t)m * ldo + n, w);
         }
     }
@@ -1815,11 +1823,12 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
         case MAPDIT_EPI_RESID:
             MD_CHECK(e->out2 && e->aux && e->gate && e->rows_per_sample > 0, "gemm: RESID needs out2, aux, gate, rows_per_sample");
             MD_CHECK(e->ldg % 4 == 0, "gemm: ldg=%d must be a multiple of 4", e->ldg);
-            MD_CHECK(!e->out3 || (e->shift2 && e->scale2 && e->gain2 && e->ld2 % 4 == 0), "gemm: RESID fused modulate needs shift2, scale2, gain2, ld2 %% 4 == 0");
+            MD_CHECK(!e->out3 || (e->shift2 && e->scale2 && (e->gain2 || e->rot2) && e->ld2 % 4 == 0),
+                     "gemm: RESID fused modulate needs shift2, scale2, gain2 (unless rot2), ld2 %% 4 == 0");
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
                                    e->rows_per_sample, e->alpha, e->beta, (bf16_t*)e->out3, e->shift2, e->scale2, e->gain2,
-                                   e->ld2}, st);
+                                   e->ld2, e->rot2}, st);
         case MAPDIT_EPI_SILU2_GRAD:
             MD_CHECK(e->out2, "gemm: SILU2_GRAD needs out2");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2Grad{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);

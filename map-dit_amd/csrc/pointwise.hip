@@ -50,6 +50,8 @@ struct RmbP {
     int ldmod, ldg_up, ldd, ldd_up;   // row strides of (shift,scale), g_up, dshift/dscale and dg_up
     int T, D; float ca, cb;
     float gscale;                     // factor on the scalar gain partials (1 / loss scale of an fp16 engine; 1 otherwise)
+    int rot;                          // rotation form: u[j] = scale[j] x'[j] + shift[j] x'[j ^ 1] (scale / shift = the A / B rows of
+                                      // rot_coef_fwd); dscale / dshift receive dA / dB; no gain partial
     // gridDim.z > 1: each block handles T / gridDim.z rows and parks its column sums in `part` ([z][sample][3][D]) and its gain
     // partial in dgain_part[(z * samples + n) * D/128 + column block]; rmb_finish_kernel adds the z slices in order
     float* part;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int d = cb0 + cl * 4;
     float g = 0.f, den = 1.f;
-    if (p.dxm) { g = *p.gain; den = mp_den(g); }
+    if (p.dxm && !p.rot) { g = *p.gain; den = mp_den(g); }
     const float k = (1.f - g) / den, kb = g / den, kd = 1.f / den;
     float4 sc = make_float4(0, 0, 0, 0), sh = sc, gu = sc;
     if (p.dxm) {
@@ -85,12 +87,21 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
                                  lo16(u.y), hi16(u.y)};
             float4 xv = *(const float4*)(p.x + off);
             const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            if (p.rot) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dx[i] += scv[i] * dm[i] + shv[i ^ 1] * dm[i ^ 1];       // u[j] = A[j] x[j] + B[j] x[j^1]
+                    a_sc[i] += xx[i] * dm[i];                               // dA
+                    a_sh[i] += xx[i ^ 1] * dm[i];                           // dB
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 dx[i] += k * scv[i] * dm[i];
                 a_sc[i] += k * xx[i] * dm[i];
                 a_sh[i] += kb * dm[i];
                 a_gain += dm[i] * (shv[i] - xx[i] * scv[i]) * kd;
+            }
             }
         }
         if (p.dx) *(float4*)(p.dx + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
@@ -165,73 +176,76 @@ __global__ void rmb_finish_kernel(const float* __restrict__ part, int Z, int N, 
 }
 
 // ---- rotation modulation (PARITY UNPINNED: not in the reference snapshot, its README.md:1-3 only; oracle.modulate_rot) ----------
-// The engine runs the rotation as a pass of its own over the bf16 operand u = x * scale that the fused modulate already produced
-// (shift = 0, gain = 0 there): (u[2i], u[2i+1]) <- R(g theta[n, i]) (u[2i], u[2i+1]), g = the block's learnable gain.
-__global__ __launch_bounds__(256) void rot_fwd_kernel(bf16_t* __restrict__ u, const float* __restrict__ theta, int ldt,
-                                                    const float* __restrict__ gain, long total8, int D, int T) {
-    const float g = *gain;
+//   (y[2i], y[2i+1]) = R(g theta[n, i]) (scale[2i] x[2i], scale[2i+1] x[2i+1]),      g = the block's learnable gain
+// is linear in x with per-(sample, column) coefficients:  y[j] = A[n, j] x[j] + B[n, j] x[j ^ 1],
+//   A[2i] = c sc[2i]   B[2i] = -s sc[2i+1]   A[2i+1] = c sc[2i+1]   B[2i+1] = s sc[2i]      (c, s = cos, sin of g theta[n, i]).
+// rot_coef_fwd builds the A / B rows once per step and branch ([samples, D]: one sincos per pair, not per token); the consumers
+// are the modulate fused into the residual GEMM epilogues (gemm.hip EpiResid, rot form), rot_modulate_fwd for block 0, and the
+// fused residual / modulate backward below, whose per-sample column sums become dA, dB; rot_coef_bwd turns those into the
+// gradients of theta, scale and the gain.  No pass over the token stream is added to the AdaLN engine's.
+__global__ void rot_coef_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ scale, int ldm,
+                                    const float* __restrict__ gain, float* __restrict__ A, float* __restrict__ B, int ldc, int n, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;              // one thread per (sample, pair)
+    const int h = D >> 1;
+    if (i >= n * h) return;
+    const int b = i / h, pr = i - b * h;
+    float sn, cs;
+    sincosf(*gain * theta[(size_t)b * ldm + pr], &sn, &cs);
+    const float2 sc = *(const float2*)(scale + (size_t)b * ldm + 2 * pr);
+    *(float2*)(A + (size_t)b * ldc + 2 * pr) = make_float2(cs * sc.x, cs * sc.y);
+    *(float2*)(B + (size_t)b * ldc + 2 * pr) = make_float2(-sn * sc.y, sn * sc.x);
+}
+
+// dtheta[n, i] = g dphi, dscale, and one partial of dgain = sum theta dphi per workgroup (summed in order by reduce_partials), from
+//   dA[n, j] = sum_t dy[j] x[j],  dB[n, j] = sum_t dy[j] x[j ^ 1]   (the rot form of resid_mod_bwd):
+//   dsc[2i] = c dA[2i] + s dB[2i+1]      dsc[2i+1] = c dA[2i+1] - s dB[2i]
+//   dphi    = -s (sc[2i] dA[2i] + sc[2i+1] dA[2i+1]) + c (sc[2i] dB[2i+1] - sc[2i+1] dB[2i])
+// Grid: (D / 512, samples); 256 threads, one pair each.
+__global__ __launch_bounds__(256) void rot_coef_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dB, int ldc,
+                                                         const float* __restrict__ theta, const float* __restrict__ scale, int ldm,
+                                                         const float* __restrict__ gain, float* __restrict__ dtheta,
+                                                         float* __restrict__ dscale, int ldd, float* __restrict__ dgain_part,
+                                                         float gscale, int D) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, pr = blockIdx.x * 256 + threadIdx.x;
+    float gs = 0.f;
+    if (pr < (D >> 1)) {
+        const float g = *gain, th = theta[(size_t)b * ldm + pr];
+        float sn, cs;
+        sincosf(g * th, &sn, &cs);
+        const float2 sc = *(const float2*)(scale + (size_t)b * ldm + 2 * pr);
+        const float2 a = *(const float2*)(dA + (size_t)b * ldc + 2 * pr), bb = *(const float2*)(dB + (size_t)b * ldc + 2 * pr);
+        *(float2*)(dscale + (size_t)b * ldd + 2 * pr) = make_float2(cs * a.x + sn * bb.y, cs * a.y - sn * bb.x);
+        const float dphi = -sn * (sc.x * a.x + sc.y * a.y) + cs * (sc.x * bb.y - sc.y * bb.x);
+        dtheta[(size_t)b * ldd + pr] = g * dphi;
+        gs = th * dphi;
+    }
+    gs = wave_sum(gs);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs;
+    __syncthreads();
+    if (threadIdx.x == 0) dgain_part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * gscale;
+}
+
+// out = 16-bit(x * A[n] + pairswap(x) * B[n]): the rotation modulate of block 0's attention branch (every later one is fused into
+// the residual GEMM epilogue that produces its input)
+__global__ __launch_bounds__(256) void rot_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                             const float* __restrict__ B, int ldc, bf16_t* __restrict__ out,
+                                                             long total8, int D, int T) {
     const int d8 = D >> 3;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
         const long m = i / d8;
         const int d = (int)(i % d8) * 8;
         const int n = (int)(m / T);
-        const float4 th = *(const float4*)(theta + (size_t)n * ldt + (d >> 1));
-        const float ang[4] = {g * th.x, g * th.y, g * th.z, g * th.w};
-        uint4 v = *(const uint4*)(u + m * D + d);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float sn, cs;
-            sincosf(ang[j], &sn, &cs);
-            const float a = lo16(w[j]), b = hi16(w[j]);
-            w[j] = pack16(cs * a - sn * b, sn * a + cs * b);
-        }
-        *(uint4*)(u + m * D + d) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-
-// Backward of the pass above, in place on the gradient: dy <- R^T dy (the gradient wrt x * scale, which the resid / modulate
-// backward then consumes as before), dtheta[n, i] = g * sum_t (dy1 y0 - dy0 y1) with y the saved rotated operand, and the block's
-// share of dgain = sum_i theta[n, i] * sum_t (...).  Block = one sample x 128 columns; 32 column-lanes (two pairs each) x 8 row
-// groups; LDS reduce over the row groups (no atomics).
-__global__ __launch_bounds__(256) void rot_bwd_kernel(bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
-                                                    const float* __restrict__ theta, int ldt, const float* __restrict__ gain,
-                                                    float* __restrict__ dtheta, int ldd, float* __restrict__ dgain_part, int T, int D, float gscale) {
-    __shared__ float red[8][32][2];
-    const int n = blockIdx.x, cb0 = blockIdx.y * 128;
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int d = cb0 + cl * 4;
-    const float g = *gain;
-    const float2 th = *(const float2*)(theta + (size_t)n * ldt + (d >> 1));
-    float sn[2], cs[2];
-    sincosf(g * th.x, &sn[0], &cs[0]);
-    sincosf(g * th.y, &sn[1], &cs[1]);
-    float acc[2] = {0.f, 0.f};
-    for (int t = rg; t < T; t += 8) {
-        const size_t off = ((size_t)n * T + t) * D + d;
-        const uint2 gv = *(const uint2*)(dy + off), yv = *(const uint2*)(y + off);
-        const uint32_t gw[2] = {gv.x, gv.y}, yw[2] = {yv.x, yv.y};
-        uint32_t o[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float g0 = lo16(gw[j]), g1 = hi16(gw[j]);
-            const float y0 = lo16(yw[j]), y1 = hi16(yw[j]);
-            acc[j] += g1 * y0 - g0 * y1;
-            o[j] = pack16(cs[j] * g0 + sn[j] * g1, cs[j] * g1 - sn[j] * g0);
-        }
-        *(uint2*)(dy + off) = make_uint2(o[0], o[1]);
-    }
-    red[rg][cl][0] = acc[0]; red[rg][cl][1] = acc[1];
-    __syncthreads();
-    if (rg == 0) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { s0 += red[r][cl][0]; s1 += red[r][cl][1]; }
-        *(float2*)(dtheta + (size_t)n * ldd + (d >> 1)) = make_float2(g * s0, g * s1);
-        float gs = th.x * s0 + th.y * s1;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
-        if (cl == 0) dgain_part[blockIdx.x * gridDim.y + blockIdx.y] = gs * gscale;
+        const float4* xp = (const float4*)(x + m * D + d);
+        const float4* ap = (const float4*)(A + (size_t)n * ldc + d);
+        const float4* bp = (const float4*)(B + (size_t)n * ldc + d);
+        const float4 x0 = xp[0], x1 = xp[1], a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+        uint4 u;
+        u.x = pack16(__builtin_fmaf(x0.x, a0.x, x0.y * b0.x), __builtin_fmaf(x0.y, a0.y, x0.x * b0.y));
+        u.y = pack16(__builtin_fmaf(x0.z, a0.z, x0.w * b0.z), __builtin_fmaf(x0.w, a0.w, x0.z * b0.w));
+        u.z = pack16(__builtin_fmaf(x1.x, a1.x, x1.y * b1.x), __builtin_fmaf(x1.y, a1.y, x1.x * b1.y));
+        u.w = pack16(__builtin_fmaf(x1.z, a1.z, x1.w * b1.z), __builtin_fmaf(x1.w, a1.w, x1.z * b1.w));
+        *(uint4*)(out + m * D + d) = u;
     }
 }
 
@@ -386,6 +400,7 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
     p.dgain_part = a->dgain_part; p.dy_up = a->dy_up; p.dg_up = a->dg_up;
     p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
     p.gscale = a->dgain_scale != 0.f ? a->dgain_scale : 1.f;
+    p.rot = a->rot;
     // Small batches: one block per (sample, 128 columns) is too few blocks to stream at the HBM rate (32 samples x 6 = 192 blocks:
     // 60 us for 25 us of traffic).  With scratch given, the rows of a sample are cut into Z pieces (grid z), the column sums
     // parked per piece and added in order by a second small kernel; the gain partials simply become Z times as many.
@@ -413,26 +428,40 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
     return MAPDIT_OK;
 }
 
-extern "C" int MD_SYM(rotate_fwd)(uint16_t* u, const float* theta, int ldt, const float* gain, int n_samples, int T, int D,
-                                 void* stream) {
-    MD_CHECK(u && theta && gain && n_samples > 0, "rotate_fwd: null/empty argument");
-    MD_CHECK(D % 8 == 0 && ldt % 4 == 0 && ((uintptr_t)theta & 15) == 0, "rotate_fwd: D %% 8, ldt %% 4 and a 16-byte aligned theta");
+extern "C" int MD_SYM(rot_modulate_fwd)(const float* x, const float* A, const float* B, int ldc, uint16_t* out, int n_samples, int T,
+                                        int D, void* stream) {
+    MD_CHECK(x && A && B && out && n_samples > 0, "rot_modulate_fwd: null/empty argument");
+    MD_CHECK(D % 8 == 0 && ldc % 4 == 0 && ((((uintptr_t)A | (uintptr_t)B)) & 15) == 0, "rot_modulate_fwd: D %% 8, ldc %% 4, 16-byte aligned rows");
     const long total8 = (long)n_samples * T * (D / 8);
     const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(rot_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)u, theta, ldt, gain, total8, D, T);
+    hipLaunchKernelGGL(rot_modulate_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, A, B, ldc, (bf16_t*)out, total8, D, T);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
 
-extern "C" int MD_SYM(rotate_bwd)(uint16_t* dy, const uint16_t* y, const float* theta, int ldt, const float* gain, float* dtheta,
-                                 int ldd, float* dgain_part, float dgain_scale, int n_samples, int T, int D, void* stream) {
-    MD_CHECK(dy && y && theta && gain && dtheta && dgain_part && n_samples > 0, "rotate_bwd: null/empty argument");
-    MD_CHECK(D % 128 == 0 && ldt % 2 == 0 && ldd % 2 == 0, "rotate_bwd: D=%d must be a multiple of 128, even row strides", D);
-    hipLaunchKernelGGL(rot_bwd_kernel, dim3(n_samples, D / 128), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, (const bf16_t*)y,
-                       theta, ldt, gain, dtheta, ldd, dgain_part, T, D, dgain_scale);
+#if MAPDIT_DT == 0
+extern "C" int mapdit_rot_coef_fwd(const float* theta, const float* scale, int ldm, const float* gain, float* A, float* B, int ldc,
+                                   int n_samples, int D, void* stream) {
+    MD_CHECK(theta && scale && gain && A && B && n_samples > 0, "rot_coef_fwd: null/empty argument");
+    MD_CHECK(D % 2 == 0 && ldm % 2 == 0 && ldc % 2 == 0 && ((((uintptr_t)scale | (uintptr_t)A | (uintptr_t)B)) & 7) == 0,
+             "rot_coef_fwd: even D / row strides and 8-byte aligned rows");
+    hipLaunchKernelGGL(rot_coef_fwd_kernel, dim3(cdiv((long)n_samples * (D / 2), 256)), dim3(256), 0, (hipStream_t)stream, theta, scale,
+                       ldm, gain, A, B, ldc, n_samples, D);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
+
+extern "C" int mapdit_rot_coef_bwd(const float* dA, const float* dB, int ldc, const float* theta, const float* scale, int ldm,
+                                   const float* gain, float* dtheta, float* dscale, int ldd, float* dgain_part, float dgain_scale,
+                                   int n_samples, int D, void* stream) {
+    MD_CHECK(dA && dB && theta && scale && gain && dtheta && dscale && dgain_part && n_samples > 0, "rot_coef_bwd: null/empty argument");
+    MD_CHECK(D % 2 == 0 && ldm % 2 == 0 && ldc % 2 == 0 && ldd % 2 == 0, "rot_coef_bwd: even D and row strides");
+    hipLaunchKernelGGL(rot_coef_bwd_kernel, dim3(cdiv(D / 2, 256), n_samples), dim3(256), 0, (hipStream_t)stream, dA, dB, ldc, theta,
+                       scale, ldm, gain, dtheta, dscale, ldd, dgain_part, dgain_scale != 0.f ? dgain_scale : 1.f, D);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+#endif
 
 #if MAPDIT_DT == 0
 extern "C" int mapdit_reduce_partials(const float* part, int count, float* out, int accumulate, void* stream) {

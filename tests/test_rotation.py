@@ -110,7 +110,7 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
         want = O.dit_forward({k: v.clone() for k, v in rsd.items()}, rcfg, x, t, y, train=False)
     e = rel_err(out.numpy(), want.numpy())
     print(f"rotation: eval logits vs oracle {e:.3e}")
-    assert e < 2e-2
+    assert e < 7e-3                                    # measured 3.3e-3
     m.train()
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     losses = create_diffusion("").training_losses(m, x.to(dev), t.to(dev), dict(y=y.to(dev)), noise=noise.to(dev))
@@ -131,7 +131,7 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
             continue
         e = rel_err(sub(p.grad), sub(gref))
         worst = max(worst, e)
-        assert e < 6e-2 or float(gref.norm()) < 1e-7, (k, e)
+        assert e < 1.4e-2 or float(gref.norm()) < 1e-7, (k, e)          # measured: worst tensor 6.9e-3
     print(f"rotation: worst gradient rel err vs oracle {worst:.3e}")
     # the modulation weight's angle rows do receive gradient
     mw = dict(m.named_parameters())["blocks.0.modulation.1.weight"].grad
@@ -140,3 +140,86 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
     m.gemm_precision = "bf16x3"
     with pytest.raises(L.MapditError):
         m(x.to(dev), t.to(dev), y.to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,ltol,gtol", [("bf16", 1.6e-2, 1e-2), ("f16", 1.5e-3, 1.5e-3)])
+def test_rotation_at_dit_b2_size(precision, ltol, gtol):
+    """BASELINE config 3's model (DiT-B/2 with rotation modulation) at its real width and depth, 2 samples: (1) zero gains = the
+    AdaLN engine's logits bit for bit (the rotation is fused into the same residual-GEMM epilogues: theta = 0 gives A = scale,
+    B = 0); (2) the rotation preserves every feature pair's norm (block 0's rotated operand against x0 * scale); (3) eval logits,
+    training loss and all gradients against the oracle's restatement; (4) the step is bit-reproducible."""
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.models import DIT_MODELS
+    from oracle.diffusion_oracle import DiffusionOracle
+    dev = "cuda"
+    cfg = O.model_config("DiT-B/2", in_channels=4, input_size=32, num_classes=1000)
+    rcfg = O.model_config("DiT-B/2", in_channels=4, input_size=32, num_classes=1000, rotation_modulation=True)
+    g = torch.Generator().manual_seed(16)
+    n = 2
+    x, t, y = torch.randn(n, 4, 32, 32, generator=g), torch.randint(0, 1000, (n,), generator=g), torch.randint(0, 1000, (n,), generator=g)
+    noise = torch.randn(n, 4, 32, 32, generator=g)
+    xd, td, yd = x.to(dev), t.to(dev), y.to(dev)
+
+    def model(c, sd):
+        m = DIT_MODELS["DiT-B/2"](in_channels=4, input_size=32, num_classes=1000, rotation_modulation=c.rotation_modulation)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        m.gemm_precision = precision
+        return m
+
+    # (1) zero gains
+    sd0 = O.init_state_dict(cfg, seed=4)
+    with torch.no_grad():
+        assert torch.equal(model(cfg, sd0)(xd, td, yd), model(rcfg, _rot_state_from(sd0, cfg))(xd, td, yd))
+    # (3) against the restatement
+    rsd = O.init_state_dict(rcfg, seed=7, gains=0.3, perturb_reference=0.3)
+    m = model(rcfg, rsd)
+    with torch.no_grad():
+        out = m(xd, td, yd)
+        want = O.dit_forward({k: v.clone() for k, v in rsd.items()}, rcfg, x, t, y, train=False)
+    e = rel_err(out.cpu().numpy(), want.numpy())
+    print(f"rotation B/2 [{precision}]: eval logits vs oracle {e:.3e}")
+    assert e < ltol
+    m.train()
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    m(xd, td, yd)                                      # a training-mode forward keeps the intermediates for _peek
+    # (2) norm preservation, block 0: |(xm[2i], xm[2i+1])| = |(x0 scale)[2i], (x0 scale)[2i+1]|
+    D = rcfg.hidden_size
+    xm = m._peek("xm", 0).float().view(n, -1, D)
+    x0 = m._peek("x0").view(n, -1, D)
+    scale = m._peek("mod_all")[:, D // 2: D // 2 + D].unsqueeze(1)
+    pair = lambda v: v.reshape(*v.shape[:-1], -1, 2).norm(dim=-1)
+    en = rel_err(pair(xm).cpu().numpy(), pair(x0 * scale).cpu().numpy())
+    print(f"rotation B/2 [{precision}]: pair-norm preservation {en:.3e}")
+    assert en < (4e-3 if precision == "bf16" else 6e-4)
+    runs = []
+    for _ in range(2):
+        m.load_state_dict(rsd)                         # (the training forward rewrites the weights: same start for both runs)
+        for p in m.parameters():
+            p.grad = None
+        losses = create_diffusion("").training_losses(m, xd, td, dict(y=yd), noise=noise.to(dev))
+        losses["loss"].mean().backward()
+        torch.cuda.synchronize()
+        runs.append((losses["loss"].detach().clone(), m._gflat.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])          # (4)
+    osd = {k: v.clone().requires_grad_(k not in O.BUFFER_KEYS) for k, v in rsd.items()}
+    drop = torch.zeros(n, dtype=torch.bool)
+    ref = DiffusionOracle("").training_losses(lambda xx, tt, **kw: O.dit_forward(osd, rcfg, xx, tt, kw["y"], train=True, drop=drop),
+                                              x, t, dict(y=y), noise=noise)
+    ref["loss"].mean().backward()
+    el = rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy())
+    num = den = 0.0
+    gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if "gain_" in k)
+    for k, p in m.named_parameters():
+        gref = osd[k].grad
+        if p.dim() == 0:
+            assert abs(float(p.grad) - float(gref)) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            continue
+        d = (p.grad.cpu().double() - gref.double())
+        num, den = num + float((d * d).sum()), den + float((gref.double() ** 2).sum())
+    pooled = (num / den) ** 0.5
+    print(f"rotation B/2 [{precision}]: loss vs oracle {el:.3e}, gradients pooled {pooled:.3e}")
+    assert el < ltol and pooled < gtol
+    mw = dict(m.named_parameters())["blocks.5.modulation.1.weight"].grad
+    assert float(mw[: D // 2].abs().sum()) > 0 and float(mw[D // 2 + 2 * D: 3 * D].abs().sum()) > 0    # both angle chunks get gradient
