@@ -1,20 +1,23 @@
 #!/bin/bash
 # Round-end measurements on the GPU box: bench JSON lines, rocprofv3 kernel stats of the bench command, PMC passes for the roofline
-# kernel (fc1 GEMM).  Everything lands under gpurun_out/r02_final/; tools/summarise_profiles.py turns it into profiles/r02_*.
+# kernel (fc1 GEMM).  Everything lands under gpurun_out/<tag>_final/ (tag = $1, default r03); tools/summarise_profiles.py <tag>
+# turns it into profiles/<tag>_*.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r02_final
+tag=${1:-r03}
+out=gpurun_out/${tag}_final
 mkdir -p $out
 sha256sum map-dit_amd/csrc/gemm.hip > $out/gemm_hip.sha256
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "bench default done: $(tail -c 300 $out/bench_default.json | head -c 200)"
-for b in 128 64 32; do python bench.py --steps 30 --warmup 5 --batch-per-gpu $b --no-cpu-baseline --no-parity > $out/bench_b$b.json 2>/dev/null; done
+for b in 128 64 32; do python bench.py --steps 30 --warmup 5 --batch-per-gpu $b --no-cpu-baseline --no-parity --no-f16-leg > $out/bench_b$b.json 2>/dev/null; done
 python bench.py --steps 20 --warmup 5 --rotation-modulation > $out/bench_rotation.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --model DiT-S/2 --no-cpu-baseline > $out/bench_S2.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --model DiT-XL/2 --batch-per-gpu 64 --no-cpu-baseline > $out/bench_XL2_b64.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --precision f16 --no-cpu-baseline > $out/bench_f16.json 2>/dev/null
 echo "benches done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-parity > $out/bench_under_rocprof.json 2> $out/rocprof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof32 -o bench32 -- python3 bench.py --steps 10 --warmup 3 --batch-per-gpu 32 --no-cpu-baseline --no-parity > $out/bench32_under_rocprof.json 2>> $out/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-parity --no-f16-leg > $out/bench_under_rocprof.json 2> $out/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof32 -o bench32 -- python3 bench.py --steps 10 --warmup 3 --batch-per-gpu 32 --no-cpu-baseline --no-parity --no-f16-leg > $out/bench32_under_rocprof.json 2>> $out/rocprof.err
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Turn what tools/collect_profiles.sh left under gpurun_out/r02_final/ into the committed summaries under profiles/:
-r02_kernel_stats_bench_steps5.csv (+ _batch32), r02_fc1_pmc_traffic.json (HBM bytes per launch of the roofline kernel, corrected as
-MI355X_MICROARCH.md prescribes, tied to the sha256 of the gemm.hip it was collected on), r02_bench_*.json(l)."""
+"""Turn what tools/collect_profiles.sh <tag> left under gpurun_out/<tag>_final/ into the committed summaries under profiles/:
+<tag>_kernel_stats_bench_steps5.csv (+ _batch32), <tag>_fc1_pmc_traffic.json (HBM bytes per launch of the roofline kernel, corrected as
+MI355X_MICROARCH.md prescribes, tied to the sha256 of the gemm.hip it was collected on), <tag>_bench_lines.jsonl.
+    python tools/summarise_profiles.py [tag = r03]"""
 import csv
 import hashlib
 import json
@@ -10,7 +11,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02_final")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", TAG + "_final")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -24,8 +26,8 @@ def counter(tag, names):
     return out
 
 
-shutil.copy(os.path.join(SRC, "prof", "bench_kernel_stats.csv"), os.path.join(DST, "r02_kernel_stats_bench_steps5.csv"))
-shutil.copy(os.path.join(SRC, "prof32", "bench32_kernel_stats.csv"), os.path.join(DST, "r02_kernel_stats_bench_batch32_steps10.csv"))
+shutil.copy(os.path.join(SRC, "prof", "bench_kernel_stats.csv"), os.path.join(DST, TAG + "_kernel_stats_bench_steps5.csv"))
+shutil.copy(os.path.join(SRC, "prof32", "bench32_kernel_stats.csv"), os.path.join(DST, TAG + "_kernel_stats_bench_batch32_steps10.csv"))
 fetch = counter("FETCH_SIZE", ["FETCH_SIZE"])
 write = counter("WRITE_SIZE", ["WRITE_SIZE"])
 tcc = counter("TCC_HIT_sum_TCC_MISS_sum", ["TCC_HIT_sum", "TCC_MISS_sum"])
@@ -50,13 +52,13 @@ d = {
     "mfma_busy_over_sq_busy": mf["SQ_VALU_MFMA_BUSY_CYCLES"] / max(32 * mf["SQ_BUSY_CYCLES"], 1),
     "SQ_VALU_MFMA_BUSY_CYCLES": mf["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_BUSY_CYCLES": mf["SQ_BUSY_CYCLES"], "SQ_WAVE_CYCLES": mf["SQ_WAVE_CYCLES"],
 }
-json.dump(d, open(os.path.join(DST, "r02_fc1_pmc_traffic.json"), "w"), indent=1)
+json.dump(d, open(os.path.join(DST, TAG + "_fc1_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: d[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "l2_hit_rate", "mfma_busy_over_sq_busy")}))
-with open(os.path.join(DST, "r02_bench_lines.jsonl"), "w") as f:
-    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_under_rocprof"):
+with open(os.path.join(DST, TAG + "_bench_lines.jsonl"), "w") as f:
+    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_f16", "bench_under_rocprof"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 10:
             line = [ln for ln in open(p) if ln.startswith("{")]
             if line:
                 f.write(json.dumps({"run": name, **json.loads(line[-1])}) + "\n")
-print("wrote profiles/r02_*")
+print(f"wrote profiles/{TAG}_*")
