@@ -350,7 +350,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
         vf[ks] = *(const bf16x8_t*)(v + (bh * Ttot + k0 + r) * 64 + 16 * ks + 8 * h2);
     }
 
-    f32x16_t dk0 = {}, dk1 = {}, dv0 = {}, dv1 = {};
+    f32x16_t dk[2] = {}, dvv[2] = {};
     for (int qt0 = 0; qt0 < ntiles; ++qt0) {               // query tiles of T rows (one when the head has <= 256 tokens)
     if (MULTI && qt0) __syncthreads();
     {
@@ -380,10 +380,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
-            dv0 = MFMA32(pa, frag_tr<T>(dots_, 0, 32 * qt + 16 * s2, lane), dv0);
-            dk0 = MFMA32(da, frag_tr<T>(qts_, 0, 32 * qt + 16 * s2, lane), dk0);
-            dv1 = MFMA32(pa, frag_tr<T>(dots_, 32, 32 * qt + 16 * s2, lane), dv1);
-            dk1 = MFMA32(da, frag_tr<T>(qts_, 32, 32 * qt + 16 * s2, lane), dk1);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvv[dt] = MFMA32(pa, frag_tr<T>(dots_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt]);
+                dk[dt] = MFMA32(da, frag_tr<T>(qts_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt]);
+            }
         }
     }
     }   // query tiles
@@ -392,18 +393,18 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     float c0[16], c1[16];
     if (dqkv) {                                        // as in the dQ pass: k section with the normalisation Jacobian, v as is
         bf16_t* dst = dqkv + ((size_t)b * Ttot + k0) * (3 * D) + D + hh * 64;
-        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dk0, dk1, dst, 3 * D, kn + (bh * Ttot + k0) * 64, sk + bh * Ttot + k0, lane);
+        store_wave_tile_jac((float*)(smem + wave * WF_BYTES), dk[0], dk[1], dst, 3 * D, kn + (bh * Ttot + k0) * 64, sk + bh * Ttot + k0, lane);
         wbuf = smem + wave * WF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { c0[i] = dv0[i]; c1[i] = dv1[i]; }
+        for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
         store_wave_tile(wbuf, c0, c1, dst + D, 3 * D, lane);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = dk0[i]; c1[i] = dk1[i]; }
+    for (int i = 0; i < 16; ++i) { c0[i] = dk[0][i]; c1[i] = dk[1][i]; }
     store_wave_tile(wbuf, c0, c1, dkn + (bh * Ttot + k0) * 64, 64, lane);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = dv0[i]; c1[i] = dv1[i]; }
+    for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
     store_wave_tile(wbuf, c0, c1, dv + (bh * Ttot + k0) * 64, 64, lane);
 }
 

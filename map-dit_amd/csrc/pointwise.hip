@@ -57,13 +57,14 @@ struct RmbP {
     float* part;
 };
 
+template <bool ROT>     // ROT: the rotation form (compile-time: the AdaLN form's loop carries no trace of it)
 __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     __shared__ float red[8][32][13];
     const int n = blockIdx.x, cb0 = blockIdx.y * 128;
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int d = cb0 + cl * 4;
     float g = 0.f, den = 1.f;
-    if (p.dxm && !p.rot) { g = *p.gain; den = mp_den(g); }
+    if (p.dxm && !ROT) { g = *p.gain; den = mp_den(g); }
     const float k = (1.f - g) / den, kb = g / den, kd = 1.f / den;
     float4 sc = make_float4(0, 0, 0, 0), sh = sc, gu = sc;
     if (p.dxm) {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
                                  lo16(u.y), hi16(u.y)};
             float4 xv = *(const float4*)(p.x + off);
             const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-            if (p.rot) {
+            if (ROT) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dx[i] += scv[i] * dm[i] + shv[i ^ 1] * dm[i ^ 1];       // u[j] = A[j] x[j] + B[j] x[j^1]
@@ -411,7 +412,8 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
             Z *= 2;
     }
     p.part = Z > 1 ? a->part_scratch : nullptr;
-    hipLaunchKernelGGL(resid_mod_bwd_kernel, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.rot) hipLaunchKernelGGL(resid_mod_bwd_kernel<true>, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(resid_mod_bwd_kernel<false>, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
     MD_LAUNCH_CHECK();
     const int npart = a->n_samples * (a->D / 128) * Z;
     const bool own_gain = a->dgain_out != nullptr && a->dxm != nullptr;
