@@ -51,6 +51,13 @@ template <int T, int NTHREADS> struct Staged {
             v[k] = *(const uint4*)(src + (size_t)row * ld + c * 8);
         }
     }
+    __device__ __forceinline__ void store_rows(char* rows_tile, int tid) const {          // the row-major image only, no pointer tests
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = tid + k * NTHREADS, row = i >> 3, c = i & 7;
+            *(uint4*)(rows_tile + row * 128 + ((c ^ (row & 7)) << 4)) = v[k];
+        }
+    }
     __device__ __forceinline__ void store(char* rows_tile, char* tr_tile, int tid) const {
         constexpr int VLD = 2 * T + 8;
 #pragma unroll
@@ -188,6 +195,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     const size_t bh = blockIdx.y;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
     const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
+    Staged<T, G::NTH> sk1_, sv1_;                      // single tile: its loads go first, ahead of the wave's own rows
+    if (!MULTI) {
+        sk1_.load(kn + bh * Ttot * 64, 64, tid);
+        sv1_.load(v + bh * Ttot * 64, 64, tid);
+    }
     bf16x8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qn + (bh * Ttot + q0 + r) * 64 + 16 * ks + 8 * h2);
@@ -199,12 +211,15 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     float lsum = 0.f;
     for (int kt0 = 0; kt0 < ntiles; ++kt0) {           // (the staging registers live inside one iteration: carried across the
     if (MULTI && kt0) __syncthreads();                 //  loop or a barrier, hipcc parked them in scratch memory)
-    {                                                  // (barrier: every wave is done with the previous tile's images)
+    if (MULTI) {                                       // (barrier: every wave is done with the previous tile's images)
         Staged<T, G::NTH> sk_, sv_;
         sk_.load(kn + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
         sv_.load(v + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
         sk_.store(ks_, nullptr, tid);
         sv_.store(vs_, nullptr, tid);
+    } else {
+        sk1_.store(ks_, nullptr, tid);
+        sv1_.store(vs_, nullptr, tid);
     }
     __syncthreads();
 #pragma unroll 2
@@ -257,6 +272,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int q0 = blockIdx.x * 32 * G::NW + wave * 32;
     const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
+    Staged<T, G::NTH> sk1_, sv1_;
+    if (!MULTI) {
+        sk1_.load(kn + bh * Ttot * 64, 64, tid);
+        sv1_.load(v + bh * Ttot * 64, 64, tid);
+    }
     bf16x8_t qf[4], dof[4];
     float del_p = 0.f;                      // delta_q = rowsum(dO * O): this lane's 32 of the 64 features
 #pragma unroll
@@ -275,12 +295,15 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dq_kernel(const bf16_t* 
     f32x16_t dq0 = {}, dq1 = {};
     for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     if (MULTI && kt0) __syncthreads();
-    {
+    if (MULTI) {
         Staged<T, G::NTH> sk_, sv_;
         sk_.load(kn + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
         sv_.load(v + (bh * Ttot + (size_t)kt0 * T) * 64, 64, tid);
         sk_.store(ks_, nullptr, tid);
         sv_.store(vs_, nullptr, tid);
+    } else {
+        sk1_.store(ks_, nullptr, tid);
+        sv1_.store(vs_, nullptr, tid);
     }
     __syncthreads();
 #pragma unroll 1
@@ -343,6 +366,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
     const int k0 = blockIdx.x * 32 * G::NW + wave * 32;
     const int ntiles = MULTI ? Ttot / T : 1;           // MULTI = false (heads of <= 256 tokens): no tile loop in the code at all
+    Staged<T, G::NTH> sq1_, sdo1_;
+    if (!MULTI) {
+        sq1_.load(qn + bh * Ttot * 64, 64, tid);
+        sdo1_.load(dO + (size_t)b * Ttot * D + hh * 64, D, tid);
+    }
     bf16x8_t kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -353,17 +381,24 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
     f32x16_t dk[2] = {}, dvv[2] = {};
     for (int qt0 = 0; qt0 < ntiles; ++qt0) {               // query tiles of T rows (one when the head has <= 256 tokens)
     if (MULTI && qt0) __syncthreads();
-    {
+    if (MULTI) {
         Staged<T, G::NTH> sq_, sdo_;
         sq_.load(qn + (bh * Ttot + (size_t)qt0 * T) * 64, 64, tid);
         sdo_.load(dO + ((size_t)b * Ttot + (size_t)qt0 * T) * D + hh * 64, D, tid);
         for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * Ttot + qt0 * T + i]; del_s[i] = delta[bh * Ttot + qt0 * T + i]; }
         sq_.store(qs_, qts_, tid);
         sdo_.store(dos_, dots_, tid);
+    } else {
+        for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * Ttot + i]; del_s[i] = delta[bh * Ttot + i]; }
+        sq1_.store(qs_, qts_, tid);
+        sdo1_.store(dos_, dots_, tid);
     }
     __syncthreads();
+#ifndef ATTN_PROBE
+#define ATTN_PROBE 0
+#endif
 #pragma unroll 1
-    for (int qt = 0; qt < G::NT; ++qt) {
+    for (int qt = 0; qt < (ATTN_PROBE == 1 ? 0 : G::NT); ++qt) {
         f32x16_t s = {}, dp = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -406,6 +441,542 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
     for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
     store_wave_tile(wbuf, c0, c1, dv + (bh * Ttot + k0) * 64, 64, lane);
+}
+
+
+// ---- backward as ONE kernel per head: 5 products, dS handed over through LDS (heads of <= 256 tokens) ----------------------------
+// The two passes above recompute S and dP (7 products) and read the head's tensors twice (12 head tensors of traffic).  Here a wave
+// owns 32 keys and keeps dK, dV in registers as in pass B; what pass A recomputed - dQ = dS K, a sum over ALL keys - is formed from
+// the dS tiles the waves have in hand anyway: every wave parks its 32-key slice of dS^T for the current 32-query tile in LDS
+// ([key][query], packed 8-byte stores of four consecutive queries), and one barrier later the waves share the 32 x 64 tile of dQ
+// out as eight 16 x 16 pieces (v_mfma 16x16x32: A = dS by transposing reads of that image, B = K by transposing reads of the
+// row-major K tile, 256 keys deep), while they already compute S, dP of the next query tile.  dQ leaves through a small fp32
+// image with the cosine-normalisation Jacobian applied, as in pass A.  Per head: q^, k^, v, dO, O read once (5 tensors), dqkv
+// written once (3): 8 tensors of traffic instead of 12, 5 MFMA products instead of 7, one launch, one barrier per query tile.
+// delta = rowsum(dO * O) is computed while dO is staged (the thread that stages a 16-byte chunk of dO loads the same chunk of O).
+constexpr int DS_LD = 72;                                   // bytes per key row of the dS^T image: 32 queries x 2 B + 8 B pad (rows 4
+                                                            // apart land on different banks for the packed stores)
+constexpr int DQ_LD = 68;                                   // floats per row of the dQ image
+template <int T>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                    const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                                    const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                                    float* __restrict__ delta, int H, float scale,
+                                                                    const float* __restrict__ sq, const float* __restrict__ sk,
+                                                                    bf16_t* __restrict__ dqkv) {
+    using G = Geo<T>;
+    constexpr int OPS = 3 * T * 128;                        // Q | dO | K row-major tiles
+    constexpr int DS_BYTES = T * DS_LD, DQ_BYTES = 32 * DQ_LD * 4;
+    constexpr int SM0 = OPS + 2 * DS_BYTES + 2 * DQ_BYTES + 3 * T * 4;
+    constexpr int SM = SM0 > G::NW * (WF_BYTES + WT_BYTES) ? SM0 : G::NW * (WF_BYTES + WT_BYTES);
+    __shared__ __attribute__((aligned(16))) char smem[SM];
+    char* qs_ = smem;
+    char* dos_ = smem + T * 128;
+    char* ks_ = smem + 2 * T * 128;
+    char* dsb_ = smem + OPS;                                // [2][T keys][DS_LD]
+    float* dqb_ = (float*)(dsb_ + 2 * DS_BYTES);            // [2][32][DQ_LD]
+    float* lse_s = dqb_ + 2 * 32 * DQ_LD;
+    float* del_s = lse_s + T;
+    float* sq_s = del_s + T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const size_t bh = blockIdx.x;
+    const int b = (int)(bh / H), hh = (int)(bh % H), D = H * 64;
+    const int k0 = wave * 32;                               // this wave's keys
+
+    // ---- stage Q, dO, K (row-major tiles) and delta; this wave's K / V rows as MFMA B operands ----
+    for (int i = tid; i < T; i += G::NTH) { lse_s[i] = lse[bh * T + i]; sq_s[i] = sq[bh * T + i]; }   // (ahead of the staging block: no loop between its loads and stores)
+    {
+        Staged<T, G::NTH> sq_, sdo_, sk_;
+        sq_.load(qn + bh * T * 64, 64, tid);
+        sdo_.load(dO + (size_t)b * T * D + hh * 64, D, tid);
+        sk_.load(kn + bh * T * 64, 64, tid);
+        uint4 ov[Staged<T, G::NTH>::N];
+#pragma unroll
+        for (int k = 0; k < Staged<T, G::NTH>::N; ++k) {
+            const int i = tid + k * G::NTH, row = i >> 3, c = i & 7;
+            ov[k] = *(const uint4*)(O + ((size_t)b * T + row) * D + hh * 64 + c * 8);
+        }
+        sq_.store_rows(qs_, tid);
+        sk_.store_rows(ks_, tid);
+#pragma unroll
+        for (int k = 0; k < Staged<T, G::NTH>::N; ++k) {    // delta: 8 lanes share a row (chunks c = 0..7 of it)
+            const uint4 a = sdo_.v[k], o = ov[k];
+            float d = lo16(a.x) * lo16(o.x) + hi16(a.x) * hi16(o.x) + lo16(a.y) * lo16(o.y) + hi16(a.y) * hi16(o.y) +
+                      lo16(a.z) * lo16(o.z) + hi16(a.z) * hi16(o.z) + lo16(a.w) * lo16(o.w) + hi16(a.w) * hi16(o.w);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            const int i = tid + k * G::NTH, row = i >> 3;
+            if ((i & 7) == 0) { del_s[row] = d; delta[bh * T + row] = d; }
+        }
+        sdo_.store_rows(dos_, tid);
+    }
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *(const bf16x8_t*)(kn + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+        vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+    }
+    __syncthreads();
+
+    f32x16_t dk[2] = {}, dvv[2] = {};
+    // the 16x16 pieces of a query tile's dQ this wave computes: piece = wave + NW * j (8 pieces: 2 query halves x 4 column blocks)
+    constexpr int PIECES = 8 / G::NW;
+    const int gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;        // transposing reads: lane (4 lq + lp) of group gi
+
+    auto dq_tile = [&](int qt) {                             // dQ of query tile qt from dS^T image qt & 1 -> dQ image qt & 1
+        const char* dsi = dsb_ + (qt & 1) * DS_BYTES;
+        float* dqi = dqb_ + (qt & 1) * 32 * DQ_LD;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int piece = wave + G::NW * j, mq = piece >> 2, nd = piece & 3;
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // two chains: consecutive MFMAs do not wait for each other
+#pragma unroll
+            for (int kb = 0; kb < T; kb += 32) {
+                const int krow = kb + 8 * gi + lq;           // key row this lane addresses (and krow + 4)
+                typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+                const char* pa = dsi + krow * DS_LD + (16 * mq + 4 * lp) * 2;
+                const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
+                const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(pa + 4 * DS_LD));
+                const int col = 16 * nd + 4 * lp, r0 = krow, r1 = krow + 4;
+                const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_v4*)(ks_ + r0 * 128 + ((((col >> 3) ^ (r0 & 7)) << 4) | ((col & 7) << 1))));
+                const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_v4*)(ks_ + r1 * 128 + ((((col >> 3) ^ (r1 & 7)) << 4) | ((col & 7) << 1))));
+                const bf16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if ((kb >> 5) & 1) acc1 = MFMA16(av, bv, acc1);
+                else acc0 = MFMA16(av, bv, acc0);
+            }
+            const f32x4_t acc = acc0 + acc1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dqi[(16 * mq + 4 * gi + e) * DQ_LD + 16 * nd + li] = acc[e];
+        }
+    };
+    auto dq_store = [&](int qt) {                            // dQ image qt & 1 -> Jacobian of q^ = q s -> the q section of dqkv
+        // every thread takes CW columns of one row (no idle waves, no divergent region: with one, hipcc parked g / x in scratch)
+        constexpr int CW = 2048 / G::NTH, LPR = 64 / CW;     // 4 | 8 | 16 columns per thread; 16 | 8 | 4 lanes per row
+        const float* dqi = dqb_ + (qt & 1) * 32 * DQ_LD;
+        const int row = tid / LPR, c0 = (tid % LPR) * CW;
+        const int q = 32 * qt + row;
+        float g[CW], x[CW], dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < CW; e += 4) *(f32x4_t*)(g + e) = *(const f32x4_t*)(dqi + row * DQ_LD + c0 + e);
+        const char* xrow = qs_ + q * 128;                    // x^ from the staged Q tile (no global load behind the barrier)
+#pragma unroll
+        for (int e = 0; e < CW; e += 4) {
+            const int col = c0 + e;
+            const uint2 w = *(const uint2*)(xrow + ((((col >> 3) ^ (q & 7)) << 4) | ((col & 7) << 1)));
+            x[e] = lo16(w.x); x[e + 1] = hi16(w.x); x[e + 2] = lo16(w.y); x[e + 3] = hi16(w.y);
+        }
+#pragma unroll
+        for (int e = 0; e < CW; ++e) dot += g[e] * x[e];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) dot += __shfl_xor(dot, o, 64);
+        const float sc = sq_s[q], n = 8.f / sc - NORM_EPS;
+        const float cc = dot / (8.f * fmaxf(n, 1e-30f));
+        uint32_t* op = (uint32_t*)(dqkv + ((size_t)b * T + q) * (3 * D) + hh * 64 + c0);
+#pragma unroll
+        for (int e = 0; e < CW; e += 2) op[e >> 1] = pack16(sc * g[e] - x[e] * cc, sc * g[e + 1] - x[e + 1] * cc);
+    };
+
+#ifndef ATTN_PROBE
+#define ATTN_PROBE 0
+#endif
+#pragma unroll 1
+    for (int qt = 0; qt < (ATTN_PROBE == 1 ? 0 : G::NT); ++qt) {
+        f32x16_t s = {}, dp = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = MFMA32(frag_rows(qs_, 32 * qt, ks, lane), kf[ks], s);
+            dp = MFMA32(frag_rows(dos_, 32 * qt, ks, lane), vf[ks], dp);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = 32 * qt + acc_row(i, lane);
+#if ATTN_PROBE == 4
+            (void)qr;
+#else
+            const float p = __expf(s[i] * scale - lse_s[qr]);
+            s[i] = p;
+            dp[i] = p * (dp[i] - del_s[qr]) * scale;
+#endif
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pa = pack8(s, 8 * s2), da = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvv[dt] = MFMA32(pa, frag_tr_rows(dos_, 32 * dt, 32 * qt + 16 * s2, lane), dvv[dt]);
+                dk[dt] = MFMA32(da, frag_tr_rows(qs_, 32 * dt, 32 * qt + 16 * s2, lane), dk[dt]);
+            }
+        }
+        // this wave's slice of dS^T: key row k0 + r, queries 8 g + 4 h2 + 0..3 of the tile in registers 4 g .. 4 g + 3
+        char* dsw = dsb_ + (qt & 1) * DS_BYTES + (k0 + r) * DS_LD + 8 * h2;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *(uint2*)(dsw + 16 * g4) = make_uint2(pack16(dp[4 * g4], dp[4 * g4 + 1]), pack16(dp[4 * g4 + 2], dp[4 * g4 + 3]));
+        if (qt > 0 && ATTN_PROBE != 2) dq_tile(qt - 1);                         // (image of the previous tile: complete since the last barrier)
+        __syncthreads();
+        if (qt > 0 && ATTN_PROBE != 2 && ATTN_PROBE != 3) dq_store(qt - 1);
+    }
+    dq_tile(G::NT - 1);
+    __syncthreads();                                         // also: every wave is done with the Q / dO / K tiles
+    dq_store(G::NT - 1);
+
+    // dK (with the normalisation Jacobian of k^) and dV of this wave's 32 keys, through per-wave LDS tiles over the dead operands
+    bf16_t* dst = dqkv + ((size_t)b * T + k0) * (3 * D) + D + hh * 64;
+    float* wf = (float*)(smem + wave * (WF_BYTES + WT_BYTES));
+    store_wave_tile_jac(wf, dk[0], dk[1], dst, 3 * D, kn + (bh * T + k0) * 64, sk + bh * T + k0, lane);
+    float c0[16], c1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c0[i] = dvv[0][i]; c1[i] = dvv[1][i]; }
+    store_wave_tile((char*)wf + WF_BYTES, c0, c1, dst + D, 3 * D, lane);
+}
+
+
+// ---- backward, heads of 256 tokens: PERSISTENT workgroups, operands streamed -------------------------------------------------
+// The kernel above fills the LDS with one head (one workgroup per CU), so nothing overlaps its loads and stores with its products:
+// measured on 3,072 heads, 157 us of its 379 us are the load-everything prologue and the store epilogue alone.  Here a workgroup
+// stays on its CU and walks its share of the heads; what the next query tile - of this head or of the next one - needs is already
+// on its way while the current tile is computed, with no drain between heads:
+//   * Q and dO reach the LDS as 32-row tiles through rings (Q 4 slots: the dQ Jacobian of tile t reads x^ one barrier after its
+//     products; dO 2 slots).  A tile's 16-byte chunks are loaded into registers right after barrier t (waves 0-3 Q; waves 4-7 dO
+//     and O, whose chunk pair gives the thread's share of delta = rowsum(dO * O) - O never enters the LDS) and written to their slot
+//     at the end of the next interval, tile t + 2: a full interval of products hides the HBM latency.
+//   * K of the NEXT head is fetched in four 8 KiB pieces during the first intervals of a head into the second K image; lse and
+//     the cosine scales of q^, k^ (3 KiB per head) and this wave's V fragments (registers) follow in later intervals.
+//   * the dS^T -> dQ hand-over of the one-head kernel runs across head boundaries (tile counter t = 8 * head + query tile).
+//   * dK, dV leave in the interval after a head's last barrier through the wave's own 32 rows of the dS^T image that all waves
+//     have just finished reading (2,304 bytes, private until the wave writes its next dS^T slice): the k^ Jacobian is applied in
+//     the accumulator layout (x^ by eight transposing reads of the K image, the row dot product by five xor-shuffles), then four
+//     32 x 32 pieces go through the slice and leave as 16-byte stores.
+// One barrier per query tile, no other synchronisation; every wave runs the same number of intervals.
+// Sum over aligned groups of 2^n lanes by DPP (no index register, no LDS traffic; ds_swizzle for the 16 <-> 16 step): every lane of
+// a group ends with the group's sum.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum8(float d) {
+    d += dpp_f<0xB1>(d);                                    // quad_perm [1,0,3,2]
+    d += dpp_f<0x4E>(d);                                    // quad_perm [2,3,0,1]
+    d += dpp_f<0x141>(d);                                   // row_half_mirror
+    return d;
+}
+__device__ __forceinline__ float sum16(float d) { d = sum8(d); return d + dpp_f<0x140>(d); }          // row_mirror
+__device__ __forceinline__ float sum32(float d) {
+    d = sum16(d);
+    return d + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, d), 0x401F));   // lane ^ 16
+}
+// A value the optimiser cannot prove loop-invariant: address arithmetic derived from it stays inside the loop body instead of being
+// hoisted into registers that live across the whole kernel (hipcc hoisted ~30 such values here and spilled them to scratch - and
+// a scratch reload waits for vmcnt(0), i.e. for every prefetch in flight).
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#ifndef SB_PROBE
+#define SB_PROBE 0
+#endif
+constexpr int SB_T = 256, SB_NT = 8, SB_NTH = 512;
+template <bool B> struct BoolC { static constexpr bool value = B; };
+typedef __attribute__((ext_vector_type(4))) unsigned int u4v;   // (a native vector: HIP's uint4 is a struct hipcc keeps in scratch when it lives across the loop)
+__global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+                                                                const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                                const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                                float* __restrict__ delta, int H, int nheads, float scale,
+                                                                const float* __restrict__ sq, const float* __restrict__ sk,
+                                                                bf16_t* __restrict__ dqkv) {
+    constexpr int T = SB_T, NT = SB_NT, NTH = SB_NTH;
+    constexpr int KB = T * 128, TB = 32 * 128;               // a K image, a 32-row tile
+    constexpr int DS_BYTES = T * DS_LD, DQ_FLOATS = 32 * DQ_LD;
+    constexpr int OFF_Q = 2 * KB, OFF_DO = OFF_Q + 4 * TB, OFF_DS = OFF_DO + 2 * TB, OFF_DQ = OFF_DS + 2 * DS_BYTES,
+                  OFF_SM = OFF_DQ + 2 * DQ_FLOATS * 4, SM = OFF_SM + (6 * T + 4 * 32) * 4;
+    static_assert(SM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char smem[SM];
+    char* const ks_ = smem;                                  // [2][T][128]   K images, head parity
+    char* const qr_ = smem + OFF_Q;                          // [4][32][128]  Q tiles, tile & 3
+    char* const dor_ = smem + OFF_DO;                        // [2][32][128]  dO tiles, tile & 1
+    char* const dsb_ = smem + OFF_DS;                        // [2][T][DS_LD] dS^T, tile & 1
+    float* const dqb_ = (float*)(smem + OFF_DQ);             // [2][32][DQ_LD] dQ, tile & 1
+    float* const lse_s = (float*)(smem + OFF_SM);            // [2][T] lse * log2(e), head parity
+    float* const sq_s = lse_s + 2 * T;                       // [2][T]
+    float* const sk_s = sq_s + 2 * T;                        // [2][T]
+    float* const del_s = sk_s + 2 * T;                       // [4][32] tile & 3
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int D = H * 64, k0 = wave * 32;
+    const int nh = (nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this workgroup (>= 1)
+    const int U = nh * NT;                                   // its query tiles
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = scale * LOG2E;
+    // head j of this workgroup -> (head index, sample, head of the sample); kept for the previous, the current and the next head
+    // (wave-uniform, one 32-bit division per head: as size_t arithmetic per tile it was two 64-bit divisions in every interval)
+    struct HeadRef { int bh, b, h; };
+    auto head_ref = [&](int j) {
+        HeadRef x;
+        x.bh = (int)blockIdx.x + j * (int)gridDim.x;
+        x.b = (int)((unsigned)x.bh / (unsigned)H);
+        x.h = x.bh - x.b * H;
+        return x;
+    };
+    HeadRef hprev = head_ref(0), hcur = hprev, hnext = head_ref(nh > 1 ? 1 : 0);
+
+    // ---- staging roles: thread -> one 16-byte chunk (row trow, chunk tc) of a 32-row tile; waves 0-3 Q, waves 4-7 dO and O ----
+    const bool qrole = wave < 4;
+    const int trow = (tid & 255) >> 3, tc = tid & 7;
+    const int tswz = trow * 128 + ((tc ^ (trow & 7)) << 4);
+    u4v pa = {}, po = {};                                  // the staged chunk(s) of tile t + 2 ... t + 1
+    auto tile_issue = [&](int t, const HeadRef& hr) {
+        const size_t bh = hr.bh;
+        const int q0 = 32 * (t & 7);
+        // (one load through a selected pointer, not a load in each arm: hipcc merges the arms' stores into one store through a
+        //  selected ADDRESS of pa / po, which pins both in scratch)
+        const size_t off = ((size_t)hr.b * T + q0 + trow) * D + hr.h * 64 + tc * 8;
+        const bf16_t* src = qrole ? qn + (bh * T + q0 + trow) * 64 + tc * 8 : dO + off;
+        pa = *(const u4v*)src;
+        if (!qrole) po = *(const u4v*)(O + off);
+    };
+    auto tile_commit = [&](int t, const HeadRef& hr) {
+        if (qrole) *(u4v*)(qr_ + (t & 3) * TB + tswz) = pa;
+        else {
+            *(u4v*)(dor_ + (t & 1) * TB + tswz) = pa;
+            float d = lo16(pa.x) * lo16(po.x) + hi16(pa.x) * hi16(po.x) + lo16(pa.y) * lo16(po.y) + hi16(pa.y) * hi16(po.y) +
+                      lo16(pa.z) * lo16(po.z) + hi16(pa.z) * hi16(po.z) + lo16(pa.w) * lo16(po.w) + hi16(pa.w) * hi16(po.w);
+            d = sum8(d);
+            if (tc == 0) {
+                del_s[(t & 3) * 32 + trow] = d;
+                delta[(size_t)hr.bh * T + 32 * (t & 7) + trow] = d;
+            }
+        }
+    };
+    // next head: K piece (4 of them, 512 chunks each), the per-token scalars, this wave's V fragments
+    u4v kp = {};
+    float l1 = 0.f;
+    auto kpiece_issue = [&](size_t bh, int piece) {
+        const int i = tid + piece * NTH;
+        kp = *(const u4v*)(kn + (bh * T + (i >> 3)) * 64 + (i & 7) * 8);
+    };
+    auto kpiece_commit = [&](int j, int piece) {
+        const int i = tid + piece * NTH, row = i >> 3, c = i & 7;
+        *(u4v*)(ks_ + (j & 1) * KB + row * 128 + ((c ^ (row & 7)) << 4)) = kp;
+    };
+    // the per-token scalars in two steps of one register: lse (threads 0-255) and the q^ scales (256-511), then the k^ scales
+    auto scal_issue = [&](size_t bh, int step) {
+        const float* src = step ? sk : tid < T ? lse : sq;
+        if (!step || tid < T) l1 = src[bh * T + (tid & (T - 1))];
+    };
+    auto scal_commit = [&](int j, int step) {
+        if (step) { if (tid < T) sk_s[(j & 1) * T + tid] = l1; }
+        else if (tid < T) lse_s[(j & 1) * T + tid] = l1 * LOG2E;
+        else sq_s[(j & 1) * T + tid - T] = l1;
+    };
+    bf16x8_t vf[4];
+    auto vf_issue = [&](size_t bh) {                         // straight into the fragments: from the last dP product of a head on they are dead
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+    };
+
+    // ---- first head: everything at once ----
+    {
+        const size_t bh = hcur.bh;
+        vf_issue(bh);
+#pragma unroll
+        for (int piece = 0; piece < 4; ++piece) { kpiece_issue(bh, piece); kpiece_commit(0, piece); }
+        scal_issue(bh, 0);
+        scal_commit(0, 0);
+        scal_issue(bh, 1);
+        scal_commit(0, 1);
+        tile_issue(0, hcur);
+        tile_commit(0, hcur);
+        tile_issue(1, hcur);
+        tile_commit(1, hcur);
+    }
+    __syncthreads();
+
+    f32x16_t dk[2] = {}, dvv[2] = {};
+    const int gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;        // transposing reads: lane (4 lq + lp) of group gi
+    typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+
+    auto dq_tile = [&](int t) {                              // dQ of tile t: dS^T image t & 1, K image of its head -> dQ image t & 1
+        const char* dsi = dsb_ + (t & 1) * DS_BYTES;
+        const char* kt = ks_ + ((t >> 3) & 1) * KB;
+        float* dqi = dqb_ + (t & 1) * DQ_FLOATS;
+        const int mq = wave >> 2, nd = wave & 3;             // this wave's 16 x 16 piece: query half, column block
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int kb = 0; kb < T; kb += 32) {
+            const int krow = kb + 8 * gi + lq;               // key row this lane addresses (and krow + 4)
+            const char* pa_ = dsi + krow * DS_LD + (16 * mq + 4 * lp) * 2;
+            const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa_);
+            const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(pa_ + 4 * DS_LD));
+            const int col = 16 * nd + 4 * lp, r0 = krow, r1 = krow + 4;
+            const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_v4*)(kt + r0 * 128 + ((((col >> 3) ^ (r0 & 7)) << 4) | ((col & 7) << 1))));
+            const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_v4*)(kt + r1 * 128 + ((((col >> 3) ^ (r1 & 7)) << 4) | ((col & 7) << 1))));
+            const bf16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            if ((kb >> 5) & 1) acc1 = MFMA16(av, bv, acc1);
+            else acc0 = MFMA16(av, bv, acc0);
+        }
+        const f32x4_t acc = acc0 + acc1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dqi[(16 * mq + 4 * gi + e) * DQ_LD + 16 * nd + li] = acc[e];
+    };
+    auto dq_store = [&](int t, const HeadRef& hr) {          // dQ image t & 1 -> Jacobian of q^ = q s -> the q section of dqkv
+        const float* dqi = dqb_ + (t & 1) * DQ_FLOATS;
+        const int tid_ = opaque(tid);
+        const int row = tid_ >> 4, c0 = (tid_ & 15) * 4;     // 16 lanes per row, 4 columns each
+        const int q = 32 * (t & 7) + row;
+        const f32x4_t g = *(const f32x4_t*)(dqi + row * DQ_LD + c0);
+        const uint2 w = *(const uint2*)(qr_ + (t & 3) * TB + row * 128 + ((((c0 >> 3) ^ (row & 7)) << 4) | ((c0 & 7) << 1)));
+        const float x0 = lo16(w.x), x1 = hi16(w.x), x2 = lo16(w.y), x3 = hi16(w.y);
+        float dot = g[0] * x0 + g[1] * x1 + g[2] * x2 + g[3] * x3;
+        dot = sum16(dot);
+        const float sc = sq_s[((t >> 3) & 1) * T + q], n = 8.f / sc - NORM_EPS;
+        const float cc = dot / (8.f * fmaxf(n, 1e-30f));
+        uint2 o;
+        o.x = pack16(sc * g[0] - x0 * cc, sc * g[1] - x1 * cc);
+        o.y = pack16(sc * g[2] - x2 * cc, sc * g[3] - x3 * cc);
+        if (SB_PROBE != 7 || o.x == 0x12345678u)
+        *(uint2*)(dqkv + ((size_t)hr.b * T + q) * (size_t)(3 * D) + hr.h * 64 + c0) = o;
+    };
+    auto head_out = [&](int j, int t) {                      // dK (k^ Jacobian) and dV of this wave's 32 keys of head j, after barrier t
+        const char* kt = ks_ + (j & 1) * KB;
+        const float* sks = sk_s + (j & 1) * T + k0;
+        const int lane = opaque(tid) & 63, r = lane & 31, h2 = lane >> 5, gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+        char* slice = dsb_ + ((t + 1) & 1) * DS_BYTES + k0 * DS_LD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float x0[4], x1[4];
+            const int row = k0 + 8 * g + 4 * h2 + lq;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int col = 32 * tt + 16 * (gi & 1) + 4 * lp;
+                const bf16x4_t w = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_v4*)(kt + row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1))));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) (tt ? x1 : x0)[e] = up16((bf16_t)w[e]);
+            }
+            const f32x4_t scv = *(const f32x4_t*)(sks + 8 * g + 4 * h2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * g + e;
+                float d = dk[0][i] * x0[e] + dk[1][i] * x1[e];
+                d = sum32(d);
+                const float sc = scv[e], n = 8.f / sc - NORM_EPS;
+                const float cc = d / (8.f * fmaxf(n, 1e-30f));
+                dk[0][i] = sc * dk[0][i] - x0[e] * cc;
+                dk[1][i] = sc * dk[1][i] - x1[e] * cc;
+            }
+        }
+        bf16_t* dst = dqkv + ((size_t)hcur.b * T + k0) * (size_t)(3 * D) + D + hcur.h * 64;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {            // dK columns 0-31, 32-63, dV columns 0-31, 32-63
+            const f32x16_t& src = round < 2 ? dk[round & 1] : dvv[round & 1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *(bf16_t*)(slice + acc_row(i, lane) * DS_LD + 2 * r) = cvt16(src[i]);
+            __builtin_amdgcn_wave_barrier();
+            const char* rp = slice + (lane >> 1) * DS_LD + (lane & 1) * 32;
+            const uint2 a = *(const uint2*)rp, b2 = *(const uint2*)(rp + 8), c = *(const uint2*)(rp + 16), d2 = *(const uint2*)(rp + 24);
+            bf16_t* gp = dst + (size_t)(lane >> 1) * (3 * D) + (round >> 1) * D + (round & 1) * 32 + (lane & 1) * 16;
+            if (SB_PROBE != 6 || a.x == 0x12345678u) {
+            *(uint4*)gp = make_uint4(a.x, a.y, b2.x, b2.y);
+            *(uint4*)(gp + 8) = make_uint4(c.x, c.y, d2.x, d2.y);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    // One interval = one query tile.  LAST = the head's last tile, a copy of its own: it requests the next head's V fragments once
+    // the last dP product has read the current ones, and waits for them at its end.  (With that load inside the common loop body,
+    // hipcc's wait-count pass, which merges all paths, makes every interval's first MFMA wait for vmcnt(0) - which also drains the
+    // tile prefetch issued a moment earlier.)
+#ifndef SB_PROBE
+#define SB_PROBE 0
+#endif
+#if SB_PROBE == 2
+#define SB_SCHED
+#else
+#define SB_SCHED __builtin_amdgcn_sched_barrier(0)
+#endif
+    auto interval = [&](auto last_c, const int t, const int j, const int qt, const bool has_next) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const char* qs_ = qr_ + (t & 3) * TB;
+        const char* dos_ = dor_ + (t & 1) * TB;
+        f32x16_t s = {}, dp = {};
+        const char* kt = ks_ + (j & 1) * KB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                     // (this wave's K rows: re-read from the K image, 16 registers less to carry)
+            s = MFMA32(frag_rows(qs_, 0, ks, lane), frag_rows(kt, k0, ks, lane), s);
+            dp = MFMA32(frag_rows(dos_, 0, ks, lane), vf[ks], dp);
+        }
+        if (LAST && has_next) vf_issue((size_t)hnext.bh);      // the rest of this interval hides the latency
+        SB_SCHED;
+        if (t > 0 && SB_PROBE != 3) dq_tile(t - 1);
+        SB_SCHED;
+        const float* lsp = lse_s + (j & 1) * T + 32 * qt + 4 * h2;
+        const float* dlp = del_s + (t & 3) * 32 + 4 * h2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t lv = *(const f32x4_t*)(lsp + 8 * g), dv4 = *(const f32x4_t*)(dlp + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * g + e;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lv[e]));
+                s[i] = p;
+                dp[i] = p * (dp[i] - dv4[e]) * scale;
+            }
+        }
+        SB_SCHED;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pa8 = pack8(s, 8 * s2), da8 = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvv[dt] = MFMA32(pa8, frag_tr_rows(dos_, 32 * dt, 16 * s2, lane), dvv[dt]);
+                dk[dt] = MFMA32(da8, frag_tr_rows(qs_, 32 * dt, 16 * s2, lane), dk[dt]);
+            }
+        }
+        // this wave's slice of dS^T: key row k0 + r, queries 8 g + 4 h2 + 0..3 of the tile in registers 4 g .. 4 g + 3
+        char* dsw = dsb_ + (t & 1) * DS_BYTES + (k0 + r) * DS_LD + 8 * h2;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *(uint2*)(dsw + 16 * g4) = make_uint2(pack16(dp[4 * g4], dp[4 * g4 + 1]), pack16(dp[4 * g4 + 2], dp[4 * g4 + 3]));
+        SB_SCHED;
+        // what was requested after the last barrier has had this interval to arrive
+        if (t >= 1 && t + 1 < U && SB_PROBE != 1) tile_commit(t + 1, LAST ? hnext : hcur);
+        if (!LAST && has_next && SB_PROBE != 1) {
+            if (qt >= 1 && qt <= 4) kpiece_commit(j + 1, qt - 1);
+            if (qt == 5) scal_commit(j + 1, 0);
+            if (qt == 6) scal_commit(j + 1, 1);
+        }
+        __syncthreads();
+        if (t + 2 < U && SB_PROBE != 1) tile_issue(t + 2, qt >= NT - 2 ? hnext : hcur);
+        if (!LAST && has_next && SB_PROBE != 1) {
+            const size_t bhn = hnext.bh;
+            if (qt < 4) kpiece_issue(bhn, qt);
+            if (qt == 4) scal_issue(bhn, 0);
+            if (qt == 5) scal_issue(bhn, 1);
+        }
+        if (t > 0 && SB_PROBE != 3 && SB_PROBE != 5) dq_store(t - 1, qt == 0 ? hprev : hcur);
+        if (LAST) {
+            if (SB_PROBE != 4) head_out(j, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dvv[0][i] = 0.f; dvv[1][i] = 0.f; }
+            if (has_next) asm volatile("" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));      // (the wait for them: here)
+        }
+    };
+#pragma unroll 1
+    for (int j = 0; j < nh; ++j) {
+        const bool has_next = j + 1 < nh;
+        if (j > 0) { hprev = hcur; hcur = hnext; if (has_next) hnext = head_ref(j + 1); }
+#pragma unroll 1
+        for (int qt = 0; qt < NT - 1; ++qt) interval(BoolC<false>{}, NT * j + qt, j, qt, has_next);
+        interval(BoolC<true>{}, NT * j + NT - 1, j, NT - 1, has_next);
+    }
+    dq_tile(U - 1);
+    __syncthreads();
+    dq_store(U - 1, hcur);
 }
 
 MD_NS_CLOSE
@@ -475,6 +1046,24 @@ extern "C" int MD_SYM(attn_cos_bwd_fused)(const uint16_t* qn, const uint16_t* kn
     const float* sq = scales;
     const float* sk = scales + (size_t)B * H * T;
     hipStream_t st = (hipStream_t)stream;
+    static const bool two_pass = [] { const char* e = getenv("MAPDIT_ATTN_BWD"); return e && e[0] == '2'; }();   // A/B switch, read once
+    static const int one_head = [] { const char* e = getenv("MAPDIT_ATTN_BWD"); return e && e[0] == '1'; }();       // (the kernel below for T = 256 too)
+    if (T == 256 && !two_pass && !one_head) {              // persistent workgroups, operands streamed
+        static const int ncu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        const int nheads = B * H, grid = nheads < ncu ? nheads : ncu;
+        hipLaunchKernelGGL(attn_bwd_stream_kernel, dim3(grid), dim3(SB_NTH), 0, st, qn, kn, v, dO, O, lse, delta, H, nheads, scale, sq, sk, dqkv);
+        MD_LAUNCH_CHECK();
+        return MAPDIT_OK;
+    }
+    if (T <= 256 && !two_pass) {                           // one kernel per head: 5 products, 8 head tensors of traffic
+        switch (T) {
+            case 64: hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), dim3(B * H), dim3(Geo<64>::NTH), 0, st, qn, kn, v, dO, O, lse, delta, H, scale, sq, sk, dqkv); break;
+            case 128: hipLaunchKernelGGL((attn_bwd_fused_kernel<128>), dim3(B * H), dim3(Geo<128>::NTH), 0, st, qn, kn, v, dO, O, lse, delta, H, scale, sq, sk, dqkv); break;
+            default: hipLaunchKernelGGL((attn_bwd_fused_kernel<256>), dim3(B * H), dim3(Geo<256>::NTH), 0, st, qn, kn, v, dO, O, lse, delta, H, scale, sq, sk, dqkv); break;
+        }
+        MD_LAUNCH_CHECK();
+        return MAPDIT_OK;
+    }
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_bwd_dq_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
                                         qn, kn, v, dO, O, lse, delta, (bf16_t*)nullptr, H, scale, sq, dqkv, T));
     MD_LAUNCH_CHECK();
