@@ -642,8 +642,8 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
 // stays on its CU and walks its share of the heads; what the next query tile - of this head or of the next one - needs is already
 // on its way while the current tile is computed, with no drain between heads:
 //   * Q and dO reach the LDS as 32-row tiles through rings (Q 4 slots: the dQ Jacobian of tile t reads x^ one barrier after its
-//     products; dO 2 slots).  A tile's 16-byte chunks are loaded into registers right after barrier t (waves 0-3 Q; waves 4-7 dO
-//     and O, whose chunk pair gives the thread's share of delta = rowsum(dO * O) - O never enters the LDS) and written to their slot
+//     products; dO 2 slots).  Every thread loads one 8-byte piece of a Q, a dO and an O row into registers right after barrier t
+//     (the dO / O pair gives the thread's share of delta = rowsum(dO * O): O never enters the LDS) and writes them to their slots
 //     at the end of the next interval, tile t + 2: a full interval of products hides the HBM latency.
 //   * K of the NEXT head is fetched in four 8 KiB pieces during the first intervals of a head into the second K image; lse and
 //     the cosine scales of q^, k^ (3 KiB per head) and this wave's V fragments (registers) follow in later intervals.
@@ -673,12 +673,34 @@ __device__ __forceinline__ float sum32(float d) {
 // hoisted into registers that live across the whole kernel (hipcc hoisted ~30 such values here and spilled them to scratch - and
 // a scratch reload waits for vmcnt(0), i.e. for every prefetch in flight).
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
-#ifndef SB_PROBE
-#define SB_PROBE 0
+#ifdef SB_STAMP        // A/B builds only (tools/build_probe.sh attention SB_STAMP 1): in-kernel time stamps of waves 0 and 4 of workgroup 0
+__device__ long long g_sb_stamps[2 * 8 * 8];
+#define SB_STAMP_AT(slot) do { if (blockIdx.x == 0 && (wave & 3) == 0 && t >= 16 && t < 24) { __builtin_amdgcn_sched_barrier(0); \
+    const long long c_ = __builtin_readcyclecounter(); if (lane == 0) g_sb_stamps[((wave >> 2) * 8 + (t - 16)) * 8 + (slot)] = c_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SB_STAMP_AT(slot) do {} while (0)
 #endif
 constexpr int SB_T = 256, SB_NT = 8, SB_NTH = 512;
 template <bool B> struct BoolC { static constexpr bool value = B; };
-typedef __attribute__((ext_vector_type(4))) unsigned int u4v;   // (a native vector: HIP's uint4 is a struct hipcc keeps in scratch when it lives across the loop)
+typedef __attribute__((ext_vector_type(4))) unsigned int u4v;   // (native vectors: HIP's uint4 is a struct hipcc keeps in scratch when it lives across the loop)
+typedef __attribute__((ext_vector_type(2))) unsigned int u2v;
+// loads / stores at  uniform base + 32-bit lane offset  (the saddr form: one address VGPR, no 64-bit lane arithmetic)
+template <class V> __device__ __forceinline__ V gload(const void* sbase, unsigned voff) { return *(const V*)((const char*)sbase + voff); }
+template <class V> __device__ __forceinline__ void gstore(void* sbase, unsigned voff, V x) { *(V*)((char*)sbase + voff) = x; }
+#define SB_FENCE __builtin_amdgcn_sched_barrier(0)
+// LDS layouts of this kernel, found by search over XOR keys that are linear in the row bits with the bank model of
+// tools/lds_conflicts.py (MI355X_MICROARCH.md, LDS): every access pattern below costs its conflict-free cycle count.
+//   [rows][64 x 16-bit] tiles (Q, dO, K): 16-byte chunk ch of row `row` at row * 128 + ((ch ^ tkey(row)) << 4).  The usual
+//   (row & 7) key leaves the ds_read_b128 row reads of the 32x32x16 A operand AND the transposing reads 2-way (8 / 4 cycles
+//   instead of 4 / 2; SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE).  The key does not depend on bits 0 and 3 of the
+//   row: a read 8 rows on is an immediate offset, one 16 rows on needs its own address (XOR 64).
+//   dS^T image [keys][32 x 16-bit]: unpadded 64-byte rows, 8-byte piece pc of a row at row * 64 + ((pc ^ dkey(row)) << 3)
+//   (the padded 72-byte rows were conflict-free for the stores, 2-way for the transposing reads); independent of bits 0 and 4.
+__device__ __forceinline__ int tkey(int row) { return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 4)) & 1) << 2); }
+__device__ __forceinline__ int toff(int row, int ch) { return row * 128 + ((ch ^ tkey(row)) << 4); }
+__device__ __forceinline__ int dkey(int row) { return ((row >> 1) & 3) | ((((row >> 2) ^ (row >> 3)) & 1) << 2); }
+__device__ __forceinline__ int doff(int row, int pc) { return row * 64 + ((pc ^ dkey(row)) << 3); }
+constexpr int SB_DS_LD = 64, SB_DQ_LD = 64;                 // bytes per dS^T row; floats per dQ image row (256-byte rows: conflict-free b128 reads)
 __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                                 const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                 const bf16_t* __restrict__ O, const float* __restrict__ lse,
@@ -687,20 +709,24 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
                                                                 bf16_t* __restrict__ dqkv) {
     constexpr int T = SB_T, NT = SB_NT, NTH = SB_NTH;
     constexpr int KB = T * 128, TB = 32 * 128;               // a K image, a 32-row tile
-    constexpr int DS_BYTES = T * DS_LD, DQ_FLOATS = 32 * DQ_LD;
+    constexpr int DS_LD = SB_DS_LD, DQ_LD = SB_DQ_LD, DS_BYTES = T * DS_LD, DQ_FLOATS = 32 * DQ_LD;
     constexpr int OFF_Q = 2 * KB, OFF_DO = OFF_Q + 4 * TB, OFF_DS = OFF_DO + 2 * TB, OFF_DQ = OFF_DS + 2 * DS_BYTES,
-                  OFF_SM = OFF_DQ + 2 * DQ_FLOATS * 4, SM = OFF_SM + (6 * T + 4 * 32) * 4;
+                  OFF_SM = OFF_DQ + 2 * DQ_FLOATS * 4, SM = OFF_SM + (10 * T + 4 * 32) * 4;
     static_assert(SM <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[SM];
     char* const ks_ = smem;                                  // [2][T][128]   K images, head parity
     char* const qr_ = smem + OFF_Q;                          // [4][32][128]  Q tiles, tile & 3
     char* const dor_ = smem + OFF_DO;                        // [2][32][128]  dO tiles, tile & 1
     char* const dsb_ = smem + OFF_DS;                        // [2][T][DS_LD] dS^T, tile & 1
-    float* const dqb_ = (float*)(smem + OFF_DQ);             // [2][32][DQ_LD] dQ, tile & 1
-    float* const lse_s = (float*)(smem + OFF_SM);            // [2][T] lse * log2(e), head parity
-    float* const sq_s = lse_s + 2 * T;                       // [2][T]
-    float* const sk_s = sq_s + 2 * T;                        // [2][T]
-    float* const del_s = sk_s + 2 * T;                       // [4][32] tile & 3
+    char* const dqb_ = smem + OFF_DQ;                        // [2][32][DQ_LD] floats: dQ, tile & 1
+    // per-token scalars, [2][T] each by head parity: lse * log2(e); the scale s of q^ = q s and c = 1 / (8 |q|) of its Jacobian
+    // dq = s g - q^ (g . q^) c; the same two for k^
+    float* const lse_s = (float*)(smem + OFF_SM);
+    float* const sq_s = lse_s + 2 * T;
+    float* const qc_s = sq_s + 2 * T;
+    float* const sk_s = qc_s + 2 * T;
+    float* const kc_s = sk_s + 2 * T;
+    float* const del_s = kc_s + 2 * T;                       // [4][32] delta * scale, tile & 3
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h2 = lane >> 5;
@@ -721,128 +747,143 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
     };
     HeadRef hprev = head_ref(0), hcur = hprev, hnext = head_ref(nh > 1 ? 1 : 0);
 
-    // ---- staging roles: thread -> one 16-byte chunk (row trow, chunk tc) of a 32-row tile; waves 0-3 Q, waves 4-7 dO and O ----
-    const bool qrole = wave < 4;
-    const int trow = (tid & 255) >> 3, tc = tid & 7;
-    const int tswz = trow * 128 + ((tc ^ (trow & 7)) << 4);
-    u4v pa = {}, po = {};                                  // the staged chunk(s) of tile t + 2 ... t + 1
+    // ---- lane offsets, formed once (32-bit; every global access below is  uniform base + one of these) ----
+    // staging: thread -> the 8-byte piece (row trow, piece tp of 16) of each of the tile's Q, dO and O rows; the same work for every
+    // wave (with waves 0-3 on Q and waves 4-7 on dO, O and delta, the in-kernel stamps showed waves 0-3 waiting 1,300 cycles of each
+    // 6,400-cycle interval at the barrier for waves 4-7).  The dQ Jacobian uses the same (row, piece) assignment.
+    const int trow = tid >> 4, tp = tid & 15;
+    const unsigned o_tsw = toff(trow, tp >> 1) + ((tp & 1) << 3);                            // piece in a swizzled 32-row tile
+    const unsigned o_q = (trow * 64 + tp * 4) * 2, o_d = (trow * D + tp * 4) * 2, o_s = (trow * 3 * D + tp * 4) * 2;
+    const unsigned o_dqi = (trow * DQ_LD + tp * 4) * 4, o_row4 = trow * 4;
+    const unsigned o_kp = toff(tid >> 3, tid & 7);                                           // 16-byte chunk tid of a 64-row K piece
+    u2v pq = {}, pd = {}, po = {};                           // the staged pieces of tile t + 2 ... t + 1
     auto tile_issue = [&](int t, const HeadRef& hr) {
-        const size_t bh = hr.bh;
         const int q0 = 32 * (t & 7);
-        // (one load through a selected pointer, not a load in each arm: hipcc merges the arms' stores into one store through a
-        //  selected ADDRESS of pa / po, which pins both in scratch)
-        const size_t off = ((size_t)hr.b * T + q0 + trow) * D + hr.h * 64 + tc * 8;
-        const bf16_t* src = qrole ? qn + (bh * T + q0 + trow) * 64 + tc * 8 : dO + off;
-        pa = *(const u4v*)src;
-        if (!qrole) po = *(const u4v*)(O + off);
+        const size_t db = (((size_t)hr.b * T + q0) * D + hr.h * 64) * 2;
+        pq = gload<u2v>((const char*)qn + ((size_t)hr.bh * T + q0) * 128, o_q);
+        pd = gload<u2v>((const char*)dO + db, o_d);
+        po = gload<u2v>((const char*)O + db, o_d);
     };
     auto tile_commit = [&](int t, const HeadRef& hr) {
-        if (qrole) *(u4v*)(qr_ + (t & 3) * TB + tswz) = pa;
-        else {
-            *(u4v*)(dor_ + (t & 1) * TB + tswz) = pa;
-            float d = lo16(pa.x) * lo16(po.x) + hi16(pa.x) * hi16(po.x) + lo16(pa.y) * lo16(po.y) + hi16(pa.y) * hi16(po.y) +
-                      lo16(pa.z) * lo16(po.z) + hi16(pa.z) * hi16(po.z) + lo16(pa.w) * lo16(po.w) + hi16(pa.w) * hi16(po.w);
-            d = sum8(d);
-            if (tc == 0) {
-                del_s[(t & 3) * 32 + trow] = d;
-                delta[(size_t)hr.bh * T + 32 * (t & 7) + trow] = d;
-            }
+        *(u2v*)(qr_ + (t & 3) * TB + o_tsw) = pq;
+        *(u2v*)(dor_ + (t & 1) * TB + o_tsw) = pd;
+        float d = lo16(pd.x) * lo16(po.x) + hi16(pd.x) * hi16(po.x) + lo16(pd.y) * lo16(po.y) + hi16(pd.y) * hi16(po.y);
+        d = sum16(d);
+        if (tp == 0) {
+            *(float*)((char*)del_s + (t & 3) * 128 + o_row4) = d * scale;
+            gstore<float>((char*)delta + ((size_t)hr.bh * T + 32 * (t & 7)) * 4, o_row4, d);
         }
     };
-    // next head: K piece (4 of them, 512 chunks each), the per-token scalars, this wave's V fragments
+    // next head: K piece (4 of them, 64 rows each), the per-token scalars, this wave's V fragments
     u4v kp = {};
     float l1 = 0.f;
-    auto kpiece_issue = [&](size_t bh, int piece) {
-        const int i = tid + piece * NTH;
-        kp = *(const u4v*)(kn + (bh * T + (i >> 3)) * 64 + (i & 7) * 8);
-    };
-    auto kpiece_commit = [&](int j, int piece) {
-        const int i = tid + piece * NTH, row = i >> 3, c = i & 7;
-        *(u4v*)(ks_ + (j & 1) * KB + row * 128 + ((c ^ (row & 7)) << 4)) = kp;
-    };
+    auto kpiece_issue = [&](int bh, int piece) { kp = gload<u4v>((const char*)kn + ((size_t)bh * T + 64 * piece) * 128, tid * 16); };
+    auto kpiece_commit = [&](int j, int piece) { *(u4v*)(ks_ + (j & 1) * KB + piece * 64 * 128 + o_kp) = kp; };
     // the per-token scalars in two steps of one register: lse (threads 0-255) and the q^ scales (256-511), then the k^ scales
-    auto scal_issue = [&](size_t bh, int step) {
+    auto scal_issue = [&](int bh, int step) {
         const float* src = step ? sk : tid < T ? lse : sq;
-        if (!step || tid < T) l1 = src[bh * T + (tid & (T - 1))];
+        if (!step || tid < T) l1 = gload<float>((const char*)src + (size_t)bh * T * 4, (tid & (T - 1)) * 4);
     };
     auto scal_commit = [&](int j, int step) {
-        if (step) { if (tid < T) sk_s[(j & 1) * T + tid] = l1; }
+        const float c = 1.f / (8.f * fmaxf(8.f / l1 - NORM_EPS, 1e-30f));
+        if (step) { if (tid < T) { sk_s[(j & 1) * T + tid] = l1; kc_s[(j & 1) * T + tid] = c; } }
         else if (tid < T) lse_s[(j & 1) * T + tid] = l1 * LOG2E;
-        else sq_s[(j & 1) * T + tid - T] = l1;
+        else { sq_s[(j & 1) * T + tid - T] = l1; qc_s[(j & 1) * T + tid - T] = c; }
     };
+    // V rows of this wave's keys as the B operand of dP = dO V^T, times the softmax scale (a power of two: exact), so that dS needs no
+    // multiplication by it: dS = P (dP scale - delta scale)
     bf16x8_t vf[4];
-    auto vf_issue = [&](size_t bh) {                         // straight into the fragments: from the last dP product of a head on they are dead
+    const unsigned o_vf = (r * 64 + 8 * h2) * 2;
+    auto vf_issue = [&](int bh) {                            // straight into the fragments: from the last dP product of a head on they are dead
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8_t*)(v + (bh * T + k0 + r) * 64 + 16 * ks + 8 * h2);
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = gload<bf16x8_t>((const char*)v + ((size_t)bh * T + k0) * 128 + 32 * ks, o_vf);
+    };
+    auto vf_scale = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u4v w = __builtin_bit_cast(u4v, vf[ks]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pack16(lo16(w[e]) * scale, hi16(w[e]) * scale);
+            vf[ks] = __builtin_bit_cast(bf16x8_t, w);
+        }
     };
 
     // ---- first head: everything at once ----
     {
-        const size_t bh = hcur.bh;
-        vf_issue(bh);
+        vf_issue(hcur.bh);
 #pragma unroll
-        for (int piece = 0; piece < 4; ++piece) { kpiece_issue(bh, piece); kpiece_commit(0, piece); }
-        scal_issue(bh, 0);
+        for (int piece = 0; piece < 4; ++piece) { kpiece_issue(hcur.bh, piece); kpiece_commit(0, piece); }
+        scal_issue(hcur.bh, 0);
         scal_commit(0, 0);
-        scal_issue(bh, 1);
+        scal_issue(hcur.bh, 1);
         scal_commit(0, 1);
         tile_issue(0, hcur);
         tile_commit(0, hcur);
         tile_issue(1, hcur);
         tile_commit(1, hcur);
+        vf_scale();
     }
     __syncthreads();
 
     f32x16_t dk[2] = {}, dvv[2] = {};
-    const int gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;        // transposing reads: lane (4 lq + lp) of group gi
     typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+    // ---- lane offsets of the interval's LDS accesses ----
+    // One lane offset per access pattern; the variants of a pattern (k-step, column half, rows + 16) differ from it by an XOR and an
+    // immediate and are formed AFTER the (loop-variant) image offset has been added, so that hipcc cannot hoist them out of the loop
+    // into registers of their own (it did, and spilled them).  All image offsets are multiples of 128 bytes.
+    const unsigned o_fr = toff(r, h2);                       // row operand: row r, 16-byte chunk 2 ks + h2 at (image + o_fr) ^ (32 ks)
+    const int gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;         // transposing reads: lane (4 lq + lp) of group gi
+    // transposed operand (tile, columns 32 dt.., rows 16 s2..): first read at ((image + o_tr) ^ (64 (dt ^ s2))) + 2048 s2, second + 1024
+    const unsigned o_tr = toff(4 * (gi >> 1) + lq, 2 * (gi & 1) + (lp >> 1)) + ((lp & 1) << 3);
+    const int mq = wave >> 2, nd = wave & 3;                 // this wave's 16 x 16 piece of a dQ tile: query half, column block
+    // Key order inside a 32-key step of the dQ products: the reduction index of the MFMA may be permuted as long as A and B agree, so
+    // the 16 lanes of group gi take keys 4 gi + lq (first read) and 16 + 4 gi + lq (second read): a half-wave then reads 8
+    // CONSECUTIVE rows of either image - conflict-free on the swizzled K image (the natural order 8 gi + lq, + 4 puts groups 0 and 1 on
+    // rows 8 apart: same banks, same swizzle key, 2-way on every read; SQ_LDS_BANK_CONFLICT was 38 % of the LDS cycles).
+    const int krow = 4 * gi + lq, kcol = 16 * nd + 4 * lp;
+    const unsigned o_dsa = doff(krow, 4 * mq + lp);
+    const unsigned o_kqb = toff(krow, kcol >> 3) + ((kcol & 7) << 1);        // rows + 16: ((image + o_kqb) ^ 64) + 2048
+    const unsigned o_sc = 4 * h2 * 4;                        // rows 8 g + 4 h2 + 0..3 of a 32-float array
+    const unsigned o_dsw = doff(k0 + r, h2);                 // this wave's rows of a dS^T image: pieces h2 + 2 s at o_dsw ^ (16 s)
+    const unsigned o_dqw = ((16 * mq + 4 * gi) * DQ_LD + 16 * nd + li) * 4;
+    auto tr8 = [&](const char* p0, const char* p1) {
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p0);
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
 
-    auto dq_tile = [&](int t) {                              // dQ of tile t: dS^T image t & 1, K image of its head -> dQ image t & 1
-        const char* dsi = dsb_ + (t & 1) * DS_BYTES;
-        const char* kt = ks_ + ((t >> 3) & 1) * KB;
-        float* dqi = dqb_ + (t & 1) * DQ_FLOATS;
-        const int mq = wave >> 2, nd = wave & 3;             // this wave's 16 x 16 piece: query half, column block
+    auto dq_tile_last = [&](int t) {                         // the dQ products of the very last tile (after the loop)
+        const char* dsa = dsb_ + (t & 1) * DS_BYTES + o_dsa;
+        const char* kqb = ks_ + ((t >> 3) & 1) * KB + o_kqb;
+        const char* kqb2 = ks_ + (((((t >> 3) & 1) * KB + o_kqb) ^ 64) + 2048);
         f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-        for (int kb = 0; kb < T; kb += 32) {
-            const int krow = kb + 8 * gi + lq;               // key row this lane addresses (and krow + 4)
-            const char* pa_ = dsi + krow * DS_LD + (16 * mq + 4 * lp) * 2;
-            const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa_);
-            const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(pa_ + 4 * DS_LD));
-            const int col = 16 * nd + 4 * lp, r0 = krow, r1 = krow + 4;
-            const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (lds_v4*)(kt + r0 * 128 + ((((col >> 3) ^ (r0 & 7)) << 4) | ((col & 7) << 1))));
-            const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (lds_v4*)(kt + r1 * 128 + ((((col >> 3) ^ (r1 & 7)) << 4) | ((col & 7) << 1))));
-            const bf16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            if ((kb >> 5) & 1) acc1 = MFMA16(av, bv, acc1);
-            else acc0 = MFMA16(av, bv, acc0);
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8_t a = tr8(dsa + 32 * i * DS_LD, dsa + (32 * i + 16) * DS_LD), b = tr8(kqb + 32 * i * 128, kqb2 + 32 * i * 128);
+            if (i & 1) acc1 = MFMA16(a, b, acc1); else acc0 = MFMA16(a, b, acc0);
         }
         const f32x4_t acc = acc0 + acc1;
+        char* dqw = dqb_ + (t & 1) * DQ_FLOATS * 4 + o_dqw;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dqi[(16 * mq + 4 * gi + e) * DQ_LD + 16 * nd + li] = acc[e];
+        for (int e = 0; e < 4; ++e) *(float*)(dqw + e * DQ_LD * 4) = acc[e];
     };
-    auto dq_store = [&](int t, const HeadRef& hr) {          // dQ image t & 1 -> Jacobian of q^ = q s -> the q section of dqkv
-        const float* dqi = dqb_ + (t & 1) * DQ_FLOATS;
-        const int tid_ = opaque(tid);
-        const int row = tid_ >> 4, c0 = (tid_ & 15) * 4;     // 16 lanes per row, 4 columns each
-        const int q = 32 * (t & 7) + row;
-        const f32x4_t g = *(const f32x4_t*)(dqi + row * DQ_LD + c0);
-        const uint2 w = *(const uint2*)(qr_ + (t & 3) * TB + row * 128 + ((((c0 >> 3) ^ (row & 7)) << 4) | ((c0 & 7) << 1)));
+    auto dq_store = [&](int t, const HeadRef& hr, bool live) {   // dQ image t & 1 -> Jacobian of q^ = q s -> the q section of dqkv
+        const int hp = (t >> 3) & 1, q0 = 32 * (t & 7);
+        const f32x4_t g = *(const f32x4_t*)(dqb_ + (t & 1) * DQ_FLOATS * 4 + o_dqi);
+        const u2v w = *(const u2v*)(qr_ + (t & 3) * TB + o_tsw);
+        const float sc = *(const float*)((const char*)sq_s + (hp * T + q0) * 4 + o_row4);
+        const float qc = *(const float*)((const char*)qc_s + (hp * T + q0) * 4 + o_row4);
         const float x0 = lo16(w.x), x1 = hi16(w.x), x2 = lo16(w.y), x3 = hi16(w.y);
-        float dot = g[0] * x0 + g[1] * x1 + g[2] * x2 + g[3] * x3;
-        dot = sum16(dot);
-        const float sc = sq_s[((t >> 3) & 1) * T + q], n = 8.f / sc - NORM_EPS;
-        const float cc = dot / (8.f * fmaxf(n, 1e-30f));
-        uint2 o;
+        const float cc = sum16(g[0] * x0 + g[1] * x1 + g[2] * x2 + g[3] * x3) * qc;
+        u2v o;
         o.x = pack16(sc * g[0] - x0 * cc, sc * g[1] - x1 * cc);
         o.y = pack16(sc * g[2] - x2 * cc, sc * g[3] - x3 * cc);
-        if (SB_PROBE != 7 || o.x == 0x12345678u)
-        *(uint2*)(dqkv + ((size_t)hr.b * T + q) * (size_t)(3 * D) + hr.h * 64 + c0) = o;
+        if (live) gstore<u2v>((char*)dqkv + (((size_t)hr.b * T + q0) * (3 * D) + hr.h * 64) * 2, o_s, o);
     };
     auto head_out = [&](int j, int t) {                      // dK (k^ Jacobian) and dV of this wave's 32 keys of head j, after barrier t
         const char* kt = ks_ + (j & 1) * KB;
         const float* sks = sk_s + (j & 1) * T + k0;
+        const float* kcs = kc_s + (j & 1) * T + k0;
         const int lane = opaque(tid) & 63, r = lane & 31, h2 = lane >> 5, gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
         char* slice = dsb_ + ((t + 1) & 1) * DS_BYTES + k0 * DS_LD;
 #pragma unroll
@@ -852,21 +893,17 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int col = 32 * tt + 16 * (gi & 1) + 4 * lp;
-                const bf16x4_t w = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_v4*)(kt + row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1))));
+                const bf16x4_t w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(kt + toff(row, col >> 3) + ((col & 7) << 1)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) (tt ? x1 : x0)[e] = up16((bf16_t)w[e]);
             }
-            const f32x4_t scv = *(const f32x4_t*)(sks + 8 * g + 4 * h2);
+            const f32x4_t scv = *(const f32x4_t*)(sks + 8 * g + 4 * h2), kcv = *(const f32x4_t*)(kcs + 8 * g + 4 * h2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
-                float d = dk[0][i] * x0[e] + dk[1][i] * x1[e];
-                d = sum32(d);
-                const float sc = scv[e], n = 8.f / sc - NORM_EPS;
-                const float cc = d / (8.f * fmaxf(n, 1e-30f));
-                dk[0][i] = sc * dk[0][i] - x0[e] * cc;
-                dk[1][i] = sc * dk[1][i] - x1[e] * cc;
+                const float cc = sum32(dk[0][i] * x0[e] + dk[1][i] * x1[e]) * kcv[e];
+                dk[0][i] = scv[e] * dk[0][i] - x0[e] * cc;
+                dk[1][i] = scv[e] * dk[1][i] - x1[e] * cc;
             }
         }
         bf16_t* dst = dqkv + ((size_t)hcur.b * T + k0) * (size_t)(3 * D) + D + hcur.h * 64;
@@ -879,10 +916,8 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
             const char* rp = slice + (lane >> 1) * DS_LD + (lane & 1) * 32;
             const uint2 a = *(const uint2*)rp, b2 = *(const uint2*)(rp + 8), c = *(const uint2*)(rp + 16), d2 = *(const uint2*)(rp + 24);
             bf16_t* gp = dst + (size_t)(lane >> 1) * (3 * D) + (round >> 1) * D + (round & 1) * 32 + (lane & 1) * 16;
-            if (SB_PROBE != 6 || a.x == 0x12345678u) {
             *(uint4*)gp = make_uint4(a.x, a.y, b2.x, b2.y);
             *(uint4*)(gp + 8) = make_uint4(c.x, c.y, d2.x, d2.y);
-            }
             __builtin_amdgcn_wave_barrier();
         }
     };
@@ -891,79 +926,123 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
     // the last dP product has read the current ones, and waits for them at its end.  (With that load inside the common loop body,
     // hipcc's wait-count pass, which merges all paths, makes every interval's first MFMA wait for vmcnt(0) - which also drains the
     // tile prefetch issued a moment earlier.)
-#ifndef SB_PROBE
-#define SB_PROBE 0
-#endif
-#if SB_PROBE == 2
-#define SB_SCHED
-#else
-#define SB_SCHED __builtin_amdgcn_sched_barrier(0)
-#endif
     auto interval = [&](auto last_c, const int t, const int j, const int qt, const bool has_next) {
         constexpr bool LAST = decltype(last_c)::value;
-        const char* qs_ = qr_ + (t & 3) * TB;
-        const char* dos_ = dor_ + (t & 1) * TB;
-        f32x16_t s = {}, dp = {};
-        const char* kt = ks_ + (j & 1) * KB;
+        // The part before the barrier is one straight-line block in a FIXED order (sched_barrier between the steps): each group of LDS
+        // reads is issued a step before the products that consume it.  The dQ products of tile t - 1 are independent of this tile's
+        // chain S, dP -> P, dS -> dV, dK and fill its gaps; they run for t = 0 too (on whatever the images hold: never stored).
+        const int tq = t - 1;                                // the tile whose dQ is formed
+        const unsigned qfr = OFF_Q + (t & 3) * TB + o_fr, dfr = OFF_DO + (t & 1) * TB + o_fr, kfr = (j & 1) * KB + k0 * 128 + o_fr;
+        const unsigned qtr = OFF_Q + (t & 3) * TB + o_tr, dtr = OFF_DO + (t & 1) * TB + o_tr;
+        const char* dsa = dsb_ + (tq & 1) * DS_BYTES + o_dsa;
+        const char* kqb = ks_ + ((tq >> 3) & 1) * KB + o_kqb;
+        const char* kqb2 = ks_ + (((((tq >> 3) & 1) * KB + o_kqb) ^ 64) + 2048);
+        // 1: operands of S, dP (this wave's K rows re-read from the K image: 16 registers less to carry); half of the dQ operands
+        bf16x8_t qa[4], da[4], ka[4], xa[4], xb[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                     // (this wave's K rows: re-read from the K image, 16 registers less to carry)
-            s = MFMA32(frag_rows(qs_, 0, ks, lane), frag_rows(kt, k0, ks, lane), s);
-            dp = MFMA32(frag_rows(dos_, 0, ks, lane), vf[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) {
+            qa[ks] = *(const bf16x8_t*)(smem + (qfr ^ (32 * ks)));
+            ka[ks] = *(const bf16x8_t*)(smem + (kfr ^ (32 * ks)));
+            da[ks] = *(const bf16x8_t*)(smem + (dfr ^ (32 * ks)));
         }
-        if (LAST && has_next) vf_issue((size_t)hnext.bh);      // the rest of this interval hides the latency
-        SB_SCHED;
-        if (t > 0 && SB_PROBE != 3) dq_tile(t - 1);
-        SB_SCHED;
-        const float* lsp = lse_s + (j & 1) * T + 32 * qt + 4 * h2;
-        const float* dlp = del_s + (t & 3) * 32 + 4 * h2;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4_t lv = *(const f32x4_t*)(lsp + 8 * g), dv4 = *(const f32x4_t*)(dlp + 8 * g);
+        for (int i = 0; i < 4; ++i) { xa[i] = tr8(dsa + 32 * i * DS_LD, dsa + (32 * i + 16) * DS_LD); xb[i] = tr8(kqb + 32 * i * 128, kqb2 + 32 * i * 128); }
+        SB_FENCE;
+        SB_STAMP_AT(0);
+        // 2: S, dP
+        f32x16_t s = MFMA32(qa[0], ka[0], (f32x16_t){}), dp = MFMA32(da[0], vf[0], (f32x16_t){});
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * g + e;
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lv[e]));
-                s[i] = p;
-                dp[i] = p * (dp[i] - dv4[e]) * scale;
+        for (int ks = 1; ks < 4; ++ks) { s = MFMA32(qa[ks], ka[ks], s); dp = MFMA32(da[ks], vf[ks], dp); }
+        if (LAST && has_next) vf_issue(hnext.bh);            // the rest of this interval hides the latency
+        SB_FENCE;
+        // 3: first half of the dQ products; the other half of their operands
+        f32x4_t acc0 = MFMA16(xa[0], xb[0], (f32x4_t){}), acc1 = MFMA16(xa[1], xb[1], (f32x4_t){});
+        acc0 = MFMA16(xa[2], xb[2], acc0);
+        acc1 = MFMA16(xa[3], xb[3], acc1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xa[i] = tr8(dsa + (128 + 32 * i) * DS_LD, dsa + (144 + 32 * i) * DS_LD); xb[i] = tr8(kqb + (128 + 32 * i) * 128, kqb2 + (128 + 32 * i) * 128); }
+        SB_FENCE;
+        SB_STAMP_AT(1);
+        // 4: P, dS (the S, dP products have had step 3 to finish)
+        {
+            const char* lsp = (const char*)lse_s + ((j & 1) * T + 32 * qt) * 4 + o_sc;
+            const char* dlp = (const char*)del_s + (t & 3) * 128 + o_sc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t lv = *(const f32x4_t*)(lsp + 32 * g), dv4 = *(const f32x4_t*)(dlp + 32 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lv[e]));
+                    s[i] = p;
+                    dp[i] = p * (dp[i] - dv4[e]);
+                }
             }
         }
-        SB_SCHED;
+        SB_FENCE;
+        SB_STAMP_AT(2);
+        // 5: second half of the dQ products; the transposed operands of the first half (queries 0-15 of the tile) of dV, dK
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (i & 1) acc1 = MFMA16(xa[i], xb[i], acc1); else acc0 = MFMA16(xa[i], xb[i], acc0); }
+        bf16x8_t tdo[2], tq_[2];
+        auto tr_operands = [&](int s2) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const unsigned da_ = (dtr ^ (64 * (dt ^ s2))) + 2048 * s2, qa_ = (qtr ^ (64 * (dt ^ s2))) + 2048 * s2;
+                tdo[dt] = tr8(smem + da_, smem + da_ + 1024);
+                tq_[dt] = tr8(smem + qa_, smem + qa_ + 1024);
+            }
+        };
+        tr_operands(0);
+        SB_FENCE;
+        // 6: dV, dK; this wave's slice of dS^T: key row k0 + r, queries 8 g + 4 h2 + 0..3 of the tile are registers 4 g .. 4 g + 3 -
+        //    the same pairs the MFMA operand packs, so the packed words serve both
+        const unsigned dsw = OFF_DS + (t & 1) * DS_BYTES + o_dsw;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa8 = pack8(s, 8 * s2), da8 = pack8(dp, 8 * s2);
+            const u4v dw = __builtin_bit_cast(u4v, da8);
+            *(u2v*)(smem + (dsw ^ (32 * s2))) = (u2v){dw[0], dw[1]};
+            *(u2v*)(smem + (dsw ^ (32 * s2 + 16))) = (u2v){dw[2], dw[3]};
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dvv[dt] = MFMA32(pa8, frag_tr_rows(dos_, 32 * dt, 16 * s2, lane), dvv[dt]);
-                dk[dt] = MFMA32(da8, frag_tr_rows(qs_, 32 * dt, 16 * s2, lane), dk[dt]);
+                dvv[dt] = MFMA32(pa8, tdo[dt], dvv[dt]);
+                dk[dt] = MFMA32(da8, tq_[dt], dk[dt]);
             }
+            if (s2 == 0) { SB_FENCE; tr_operands(1); SB_FENCE; }
         }
-        // this wave's slice of dS^T: key row k0 + r, queries 8 g + 4 h2 + 0..3 of the tile in registers 4 g .. 4 g + 3
-        char* dsw = dsb_ + (t & 1) * DS_BYTES + (k0 + r) * DS_LD + 8 * h2;
+        SB_FENCE;
+        SB_STAMP_AT(3);
+        {                                                    // dQ of tile t - 1 -> its image
+            const f32x4_t acc = acc0 + acc1;
+            char* dqw = dqb_ + (tq & 1) * DQ_FLOATS * 4 + o_dqw;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            *(uint2*)(dsw + 16 * g4) = make_uint2(pack16(dp[4 * g4], dp[4 * g4 + 1]), pack16(dp[4 * g4 + 2], dp[4 * g4 + 3]));
-        SB_SCHED;
+            for (int e = 0; e < 4; ++e) *(float*)(dqw + e * DQ_LD * 4) = acc[e];
+        }
+        SB_STAMP_AT(4);
         // what was requested after the last barrier has had this interval to arrive
-        if (t >= 1 && t + 1 < U && SB_PROBE != 1) tile_commit(t + 1, LAST ? hnext : hcur);
-        if (!LAST && has_next && SB_PROBE != 1) {
+        if (t >= 1 && t + 1 < U) tile_commit(t + 1, LAST ? hnext : hcur);
+        if (!LAST && has_next) {
             if (qt >= 1 && qt <= 4) kpiece_commit(j + 1, qt - 1);
             if (qt == 5) scal_commit(j + 1, 0);
             if (qt == 6) scal_commit(j + 1, 1);
         }
+        SB_STAMP_AT(5);
         __syncthreads();
-        if (t + 2 < U && SB_PROBE != 1) tile_issue(t + 2, qt >= NT - 2 ? hnext : hcur);
-        if (!LAST && has_next && SB_PROBE != 1) {
-            const size_t bhn = hnext.bh;
-            if (qt < 4) kpiece_issue(bhn, qt);
-            if (qt == 4) scal_issue(bhn, 0);
-            if (qt == 5) scal_issue(bhn, 1);
+        SB_STAMP_AT(6);
+        if (t + 2 < U) tile_issue(t + 2, qt >= NT - 2 ? hnext : hcur);
+        if (!LAST && has_next) {
+            if (qt < 4) kpiece_issue(hnext.bh, qt);
+            if (qt == 4) scal_issue(hnext.bh, 0);
+            if (qt == 5) scal_issue(hnext.bh, 1);
         }
-        if (t > 0 && SB_PROBE != 3 && SB_PROBE != 5) dq_store(t - 1, qt == 0 ? hprev : hcur);
+        dq_store(t - 1, qt == 0 ? hprev : hcur, t > 0);
+        SB_STAMP_AT(7);
         if (LAST) {
-            if (SB_PROBE != 4) head_out(j, t);
+            head_out(j, t);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dvv[0][i] = 0.f; dvv[1][i] = 0.f; }
-            if (has_next) asm volatile("" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));      // (the wait for them: here)
+            if (has_next) vf_scale();                        // (the wait for the V fragments: here)
         }
     };
 #pragma unroll 1
@@ -974,12 +1053,16 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
         for (int qt = 0; qt < NT - 1; ++qt) interval(BoolC<false>{}, NT * j + qt, j, qt, has_next);
         interval(BoolC<true>{}, NT * j + NT - 1, j, NT - 1, has_next);
     }
-    dq_tile(U - 1);
+    dq_tile_last(U - 1);
     __syncthreads();
-    dq_store(U - 1, hcur);
+    dq_store(U - 1, hcur, true);
 }
 
 MD_NS_CLOSE
+
+#if defined(SB_STAMP) && MAPDIT_DT == 0
+extern "C" int mapdit_debug_attn_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sb_stamps), sizeof(long long) * 128); }
+#endif
 
 // TT = the tile of keys / queries a workgroup stages at a time: the whole head up to 256 tokens, 256 of them beyond (T % 256 == 0)
 #define ATTN_DISPATCH(T_, CALL)                                                         \

@@ -20,7 +20,13 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
     __bf16 b = (__bf16)x;                                        // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// one v_cvt_pk_bf16_f32 for the pair (as two scalar conversions merged by shift + or, hipcc emitted four instructions per pair)
+typedef __attribute__((ext_vector_type(2))) float md_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 md_bf16x2_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const md_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, md_bf16x2_t));
+}
 
 // ---- the 16-bit operand format of a translation unit ---------------------------------------------------------------------
 // Every kernel file that reads or writes 16-bit GEMM / attention operands is compiled TWICE (csrc/Makefile): MAPDIT_DT = 0 with
