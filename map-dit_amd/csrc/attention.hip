@@ -31,7 +31,16 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int base) {
     return r.v;
 }
 
-// Row-major [rows][64] bf16 tiles in LDS have 128-B rows with 16-B chunks XOR-swizzled by (row & 7).
+// Row-major [rows][64] 16-bit tiles in LDS have 128-byte rows with the 16-byte chunks XOR-swizzled by (row & 7) - in the kernels of
+// this file except the streaming backward, which uses tkey(row): chunk ch of row `row` at toff(row, ch).  That key was found by
+// search over keys linear in the row bits with the bank model of tools/lds_conflicts.py (MI355X_MICROARCH.md, LDS): with it the
+// ds_read_b128 row reads of the 32x32x16 A operand, the transposing reads (both MFMA shapes) and the 8- and 16-byte staging stores
+// all cost their conflict-free cycle count in the model.  It does not depend on bits 0 and 3 of the row: a read 8 rows on is an
+// immediate offset, one 16 rows on needs its own address (XOR 64).  (Tried in the other kernels too: forward 95 -> 99 us, two-pass
+// backward 426 -> 457 us, one kernel per head 379 -> 373 us on 3,072 heads - kept only where it was measured to help.)
+__device__ __forceinline__ int tkey(int row) { return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 4)) & 1) << 2); }
+__device__ __forceinline__ int toff(int row, int ch) { return row * 128 + ((ch ^ tkey(row)) << 4); }
+
 // A-operand fragment of 32x32x16: lane (r, h) holds [row0 + r][16 ks + 8 h + 0..7].
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int ks, int lane) {
     const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
@@ -563,11 +572,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
         float g[CW], x[CW], dot = 0.f;
 #pragma unroll
         for (int e = 0; e < CW; e += 4) *(f32x4_t*)(g + e) = *(const f32x4_t*)(dqi + row * DQ_LD + c0 + e);
-        const char* xrow = qs_ + q * 128;                    // x^ from the staged Q tile (no global load behind the barrier)
+        // x^ from the staged Q tile (no global load behind the barrier)
 #pragma unroll
         for (int e = 0; e < CW; e += 4) {
             const int col = c0 + e;
-            const uint2 w = *(const uint2*)(xrow + ((((col >> 3) ^ (q & 7)) << 4) | ((col & 7) << 1)));
+            const uint2 w = *(const uint2*)(qs_ + q * 128 + ((((col >> 3) ^ (q & 7)) << 4) | ((col & 7) << 1)));
             x[e] = lo16(w.x); x[e + 1] = hi16(w.x); x[e + 2] = lo16(w.y); x[e + 3] = hi16(w.y);
         }
 #pragma unroll
@@ -690,14 +699,9 @@ template <class V> __device__ __forceinline__ void gstore(void* sbase, unsigned 
 #define SB_FENCE __builtin_amdgcn_sched_barrier(0)
 // LDS layouts of this kernel, found by search over XOR keys that are linear in the row bits with the bank model of
 // tools/lds_conflicts.py (MI355X_MICROARCH.md, LDS): every access pattern below costs its conflict-free cycle count.
-//   [rows][64 x 16-bit] tiles (Q, dO, K): 16-byte chunk ch of row `row` at row * 128 + ((ch ^ tkey(row)) << 4).  The usual
-//   (row & 7) key leaves the ds_read_b128 row reads of the 32x32x16 A operand AND the transposing reads 2-way (8 / 4 cycles
-//   instead of 4 / 2; SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE).  The key does not depend on bits 0 and 3 of the
-//   row: a read 8 rows on is an immediate offset, one 16 rows on needs its own address (XOR 64).
+//   [rows][64 x 16-bit] tiles (Q, dO, K): toff() above (SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE with the (row & 7) key).
 //   dS^T image [keys][32 x 16-bit]: unpadded 64-byte rows, 8-byte piece pc of a row at row * 64 + ((pc ^ dkey(row)) << 3)
 //   (the padded 72-byte rows were conflict-free for the stores, 2-way for the transposing reads); independent of bits 0 and 4.
-__device__ __forceinline__ int tkey(int row) { return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 4)) & 1) << 2); }
-__device__ __forceinline__ int toff(int row, int ch) { return row * 128 + ((ch ^ tkey(row)) << 4); }
 __device__ __forceinline__ int dkey(int row) { return ((row >> 1) & 3) | ((((row >> 2) ^ (row >> 3)) & 1) << 2); }
 __device__ __forceinline__ int doff(int row, int pc) { return row * 64 + ((pc ^ dkey(row)) << 3); }
 constexpr int SB_DS_LD = 64, SB_DQ_LD = 64;                 // bytes per dS^T row; floats per dQ image row (256-byte rows: conflict-free b128 reads)
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
                                                                 float* __restrict__ delta, int H, int nheads, float scale,
                                                                 const float* __restrict__ sq, const float* __restrict__ sk,
                                                                 bf16_t* __restrict__ dqkv) {
-    constexpr int T = SB_T, NT = SB_NT, NTH = SB_NTH;
+    constexpr int T = SB_T, NT = SB_NT;
     constexpr int KB = T * 128, TB = 32 * 128;               // a K image, a 32-row tile
     constexpr int DS_LD = SB_DS_LD, DQ_LD = SB_DQ_LD, DS_BYTES = T * DS_LD, DQ_FLOATS = 32 * DQ_LD;
     constexpr int OFF_Q = 2 * KB, OFF_DO = OFF_Q + 4 * TB, OFF_DS = OFF_DO + 2 * TB, OFF_DQ = OFF_DS + 2 * DS_BYTES,

@@ -21,7 +21,7 @@ DEV = "cuda"
 LOGIT_TOL = 7e-3          # tiny fixtures (depth 2-3): measured <= 3.5e-3
 LOSS_TOL = 1.5e-4         # measured <= 7.2e-5
 GRAD_TOL = 1e-2           # per tensor of >= 64 entries: measured <= 5.0e-3
-GAIN_TOL = 5e-2           # scalar gain gradients, deviation relative to the largest gain gradient of the model (provisional)
+GAIN_TOL = 8e-3           # scalar gain gradients, deviation relative to the largest gain gradient of the model: measured <= 4.1e-3 (s2_n4)
 SMALL_GRAD_TOL = 2e-2     # tensors of < 64 entries (MPScale references: sums with heavy cancellation): measured <= 4.9e-3
 
 
@@ -310,7 +310,7 @@ def test_sampler_matches_reference(precision, tol):
     assert out.shape == z.shape and torch.isfinite(out).all()
 
 
-NAMED_GRAD_TOL = 4e-2     # (provisional until measured per tensor; the pooled figure bench.py prints for b2_n2 is 3.8e-3)
+NAMED_GRAD_TOL = 4e-2     # sub-sampled tensors of >= 64 kept entries: measured <= 2.6e-2 (s2_n4; b2_n2 9.6e-3, xl2_n2 1.5e-2; pooled 3.8e-3)
 
 
 @pytest.mark.parametrize("name", ["s4_n8", "s2_n2", "s2_n4", "b2_n2", "xl2_n2"])
@@ -636,7 +636,7 @@ def test_forced_weight_normalization_off(precision, ltol, gtol):
     for k, p in m.named_parameters():
         gref = osd[k].grad
         if p.dim() == 0:
-            assert abs(float(p.grad) - float(gref)) < (0.05 if precision == "bf16" else 1e-3) * gain_scale + 1e-7, k
+            assert abs(float(p.grad) - float(gref)) < (GAIN_TOL if precision == "bf16" else 1e-3) * gain_scale + 1e-7, k
             continue
         e = rel_err(p.grad.cpu().numpy(), gref.numpy())
         assert e < (gtol if gref.numel() >= 64 else 10 * gtol) or float(gref.norm()) < 1e-7, (k, e)

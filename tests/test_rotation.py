@@ -123,16 +123,17 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
     ref["loss"].mean().backward()
     assert rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy()) < 2e-2
     gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if "gain_" in k)
-    worst = 0.0
+    worst = worst_gain = 0.0
     for k, p in m.named_parameters():
         gref = osd[k].grad
         if p.dim() == 0:
-            assert abs(float(p.grad) - float(gref)) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            worst_gain = max(worst_gain, abs(float(p.grad) - float(gref)) / (gain_scale + 1e-30))
+            assert abs(float(p.grad) - float(gref)) < 1e-2 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
             continue
         e = rel_err(sub(p.grad), sub(gref))
         worst = max(worst, e)
         assert e < 1.4e-2 or float(gref.norm()) < 1e-7, (k, e)          # measured: worst tensor 6.9e-3
-    print(f"rotation: worst gradient rel err vs oracle {worst:.3e}")
+    print(f"rotation: worst gradient rel err vs oracle {worst:.3e}, worst gain deviation {worst_gain:.3e}")
     # the modulation weight's angle rows do receive gradient
     mw = dict(m.named_parameters())["blocks.0.modulation.1.weight"].grad
     assert float(mw[:64].abs().sum()) > 0
@@ -209,17 +210,18 @@ def test_rotation_at_dit_b2_size(precision, ltol, gtol):
                                               x, t, dict(y=y), noise=noise)
     ref["loss"].mean().backward()
     el = rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy())
-    num = den = 0.0
+    num = den = worst_gain = 0.0
     gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if "gain_" in k)
     for k, p in m.named_parameters():
         gref = osd[k].grad
         if p.dim() == 0:
-            assert abs(float(p.grad) - float(gref)) < 0.05 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            worst_gain = max(worst_gain, abs(float(p.grad) - float(gref)) / (gain_scale + 1e-30))
+            assert abs(float(p.grad) - float(gref)) < (5e-2 if precision == "bf16" else 5e-3) * gain_scale + 1e-7, (k, float(p.grad), float(gref))   # measured: 2.5e-2 / 2.7e-3 (final_layer.gain_mod)
             continue
         d = (p.grad.cpu().double() - gref.double())
         num, den = num + float((d * d).sum()), den + float((gref.double() ** 2).sum())
     pooled = (num / den) ** 0.5
-    print(f"rotation B/2 [{precision}]: loss vs oracle {el:.3e}, gradients pooled {pooled:.3e}")
+    print(f"rotation B/2 [{precision}]: loss vs oracle {el:.3e}, gradients pooled {pooled:.3e}, worst gain deviation {worst_gain:.3e}")
     assert el < ltol and pooled < gtol
     mw = dict(m.named_parameters())["blocks.5.modulation.1.weight"].grad
     assert float(mw[: D // 2].abs().sum()) > 0 and float(mw[D // 2 + 2 * D: 3 * D].abs().sum()) > 0    # both angle chunks get gradient
