@@ -558,7 +558,9 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
                 if ((kb >> 5) & 1) acc1 = MFMA16(av, bv, acc1);
                 else acc0 = MFMA16(av, bv, acc0);
             }
-            const f32x4_t acc = acc0 + acc1;
+            float acc[4];                                   // (element by element: a vector add becomes v_pk_add_f32, which the build forbids)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc0[e] + acc1[e];
 #pragma unroll
             for (int e = 0; e < 4; ++e) dqi[(16 * mq + 4 * gi + e) * DQ_LD + 16 * nd + li] = acc[e];
         }
@@ -866,7 +868,9 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
             const bf16x8_t a = tr8(dsa + 32 * i * DS_LD, dsa + (32 * i + 16) * DS_LD), b = tr8(kqb + 32 * i * 128, kqb2 + 32 * i * 128);
             if (i & 1) acc1 = MFMA16(a, b, acc1); else acc0 = MFMA16(a, b, acc0);
         }
-        const f32x4_t acc = acc0 + acc1;
+        float acc[4];                                   // (element by element: a vector add becomes v_pk_add_f32, which the build forbids)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc0[e] + acc1[e];
         char* dqw = dqb_ + (t & 1) * DQ_FLOATS * 4 + o_dqw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) *(float*)(dqw + e * DQ_LD * 4) = acc[e];
@@ -1018,7 +1022,9 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
         SB_FENCE;
         SB_STAMP_AT(3);
         {                                                    // dQ of tile t - 1 -> its image
-            const f32x4_t acc = acc0 + acc1;
+            float acc[4];                                   // (element by element: a vector add becomes v_pk_add_f32, which the build forbids)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc0[e] + acc1[e];
             char* dqw = dqb_ + (tq & 1) * DQ_FLOATS * 4 + o_dqw;
 #pragma unroll
             for (int e = 0; e < 4; ++e) *(float*)(dqw + e * DQ_LD * 4) = acc[e];
