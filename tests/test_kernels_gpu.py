@@ -596,6 +596,43 @@ def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
         lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 72, st())
 
 
+@pytest.mark.parametrize("B,H", [(30, 12), (64, 12), (23, 13)])
+def test_streaming_attention_backward_many_heads(L, B, H):
+    """The one-launch attention backward of 256-token heads keeps one workgroup per CU and walks several heads per workgroup (K
+    images, scalars and V fragments of the next head fetched during the current one, the dS^T -> dQ hand-over running across the
+    head boundary): 360 heads (one or two per workgroup on 256 CUs), 768 (three each) and 299 (uneven, 13 heads per sample) against
+    the two-pass kernels (each verified against autograd above) on the same inputs, plus delta = rowsum(dO * O)."""
+    T, D = 256, H * 64
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(100 + B)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    raw_q, raw_k = rn(B * H, T, 64), rn(B * H, T, 64)
+    nq, nk = raw_q.norm(dim=-1, keepdim=True), raw_k.norm(dim=-1, keepdim=True)
+    qn, kn, v = (8 * raw_q / (nq + 1e-4)).to(MODE["dt"]), (8 * raw_k / (nk + 1e-4)).to(MODE["dt"]), rn(B * H, T, 64).to(MODE["dt"])
+    scales = torch.stack([8.0 / (nq.squeeze(-1) + 1e-4), 8.0 / (nk.squeeze(-1) + 1e-4)]).contiguous()
+    dO = (rn(B * T, D) * 0.05).to(MODE["dt"])
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
+    o, lse = mk(B * T, D), torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd(p(qn), p(kn), p(v), p(o), p(lse), B, T, H, 64, st())
+    delta1, delta2 = torch.zeros(B * H, T, device=DEV), torch.zeros(B * H, T, device=DEV)
+    dqkv = torch.full((B * T, 3 * D), float("nan"), device=DEV).to(MODE["dt"])                  # every element must be written
+    lib.attn_cos_bwd_fused(p(qn), p(kn), p(v), p(dO), p(o), p(lse), p(delta1), p(scales), p(dqkv), B, T, H, 64, st())
+    dqn, dkn, dv = mk(B * H, T, 64), mk(B * H, T, 64), mk(B * H, T, 64)
+    lib.attn_cos_bwd(p(qn), p(kn), p(v), p(dO), p(o), p(lse), p(delta2), p(dqn), p(dkn), p(dv), B, T, H, 64, st())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dqkv.float()).all()
+    d_ref = (dO.float() * o.float()).view(B, T, H, 64).sum(-1).transpose(1, 2).reshape(B * H, T)
+    assert rel_err(delta1.cpu().numpy(), d_ref.cpu().numpy()) < 1e-5 and rel_err(delta2.cpu().numpy(), d_ref.cpu().numpy()) < 1e-5
+    got = dqkv.float().view(B, T, 3, H, 64)
+    heads = lambda z: z.float().view(B, H, T, 64).transpose(1, 2)                                 # -> [B, T, H, 64]
+    assert rel_err(got[:, :, 2].cpu().numpy(), heads(dv).cpu().numpy()) < 6e-3                    # dV: the same products, other order
+    # dQ, dK: the two-pass kernels return the gradient w.r.t. the normalised rows; apply the Jacobian of x^ = x s here
+    for idx, dn, xh, sc, raw_n in ((0, dqn, qn, scales[0], nq), (1, dkn, kn, scales[1], nk)):
+        gg, xx = dn.float(), xh.float()
+        dx = sc.unsqueeze(-1) * gg - xx * (gg * xx).sum(-1, keepdim=True) / (8.0 * raw_n)
+        assert rel_err(got[:, :, idx].cpu().numpy(), heads(dx).cpu().numpy()) < 1.2e-2, idx
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(2, 64, 2, 72), (1, 256, 2, 72), (3, 16, 2, 64), (2, 48, 1, 40)])
 def test_generic_attention_fwd_bwd(L, B, T, H, hd):
     """The fp32 VALU path for head sizes / token counts the MFMA kernels do not take (DiT-XL head_dim 72, patch-8 T = 16)."""
