@@ -395,7 +395,8 @@ int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void** ptr, long
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct mapdit_comm mapdit_comm_t;
 int mapdit_comm_unique_id(void* id128);
-int mapdit_comm_create(const void* id128, int rank, int world, mapdit_comm_t** out);
+int mapdit_comm_create(const void* id128, int rank, int world, mapdit_comm_t** out);   /* binds the calling thread's current HIP device: the
+                                                                                          collectives refuse to run from another device */
 void mapdit_comm_destroy(mapdit_comm_t* comm);
 int mapdit_allreduce_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);
 int mapdit_reduce_scatter_bucket(mapdit_comm_t* comm, float* buf, long count, void* stream);

@@ -184,6 +184,7 @@ class OverlappedGradReducer:
         for buf in opt.ema:
             mine = buf[rank * self.per:(rank + 1) * self.per]
             whole = buf[:self.world * self.per]
+            before = _range_checksum(mine)
             if _host_staged(self.group, buf):
                 parts = [torch.empty(self.per, dtype=buf.dtype) for _ in range(self.world)]
                 dist.all_gather(parts, mine.detach().cpu(), group=self.group)
@@ -193,6 +194,32 @@ class OverlappedGradReducer:
                 dist.all_gather_into_tensor(whole, mine, group=self.group)          # in place: `mine` is part `rank` of `whole`
             else:
                 dist.all_gather(list(whole.chunk(self.world)), mine.clone(), group=self.group)
+            _verify_gather(whole, self.per, self.world, before, self.group)
+
+
+def _range_checksum(x):
+    """(sum, sum of squares) of a range in float64: what its owner publishes before a gather."""
+    d = x.detach().double()
+    return torch.stack([d.sum(), (d * d).sum()])
+
+
+def _verify_gather(whole, per, world, mine_before, group):
+    """After an in-place all-gather of `world` ranges of `per` elements: every range of the gathered buffer must carry the checksum
+    its owner computed BEFORE the gather.  The in-place RCCL forms (all_gather_into_tensor with the input a slice of the output)
+    only ever ran with one rank before a multi-GPU node was available; a wrong offset or an aliasing problem there would corrupt EMA
+    snapshots and checkpoints silently.  Cost: one read of the buffer, at snapshot / checkpoint cadence."""
+    if dist.get_backend(group) == "nccl" and whole.is_cuda:
+        pub = torch.empty(world, 2, dtype=torch.float64, device=whole.device)
+        dist.all_gather_into_tensor(pub, mine_before.view(1, 2), group=group)
+    else:
+        parts = [torch.empty(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, mine_before.cpu(), group=group)
+        pub = torch.stack(parts).to(whole.device)
+    got = torch.stack([_range_checksum(whole[r * per:(r + 1) * per]) for r in range(world)])
+    if not torch.allclose(got, pub, rtol=1e-12, atol=0.0):
+        bad = [r for r in range(world) if not torch.allclose(got[r], pub[r], rtol=1e-12, atol=0.0)]
+        raise RuntimeError(f"gather_state: ranges of ranks {bad} arrived with a different checksum than their owners computed "
+                           f"(rank {dist.get_rank(group)}): the gathered state is not to be trusted")
 
 
 class _ReducerBase:
@@ -281,19 +308,21 @@ class Zero1Reducer(_ReducerBase):
     def gather_state(self):
         if self.opt is not None:
             for buf in [self.opt.exp_avg, self.opt.exp_avg_sq] + list(self.opt.ema):
-                self._gather(buf)
+                self._gather(buf, verify=True)            # (checkpoint cadence; the per-step parameter gather is not checked)
 
     def _gather_params(self):
         """All-gather of the parameter parts each rank has just updated (in place in the flat parameter buffer)."""
         self._gather(self.model._pflat)
 
-    def _gather(self, p):
+    def _gather(self, p, verify: bool = False):
         if self.world == 1 and not self.force_collective:
             return
-        works = []
+        works, sums = [], []
         for lo, hi in self.slices:
             n = (hi - lo) // self.world
             mine = p[lo + self.rank * n: lo + (self.rank + 1) * n]
+            if verify and self.world > 1:
+                sums.append(_range_checksum(mine))
             if self._native_rs or self.world == 1:
                 works.append(dist.all_gather_into_tensor(p[lo:hi], mine, group=self.group, async_op=True))
             elif _host_staged(self.group, p):
@@ -305,6 +334,9 @@ class Zero1Reducer(_ReducerBase):
                 works.append(dist.all_gather(list(p[lo:hi].chunk(self.world)), mine.clone(), group=self.group, async_op=True))
         for w in works:
             w.wait()
+        if verify and self.world > 1:
+            for (lo, hi), before in zip(self.slices, sums):
+                _verify_gather(p[lo:hi], (hi - lo) // self.world, self.world, before, self.group)
 
 
 def make_reducer(model, mode: str | None = None, group=None):

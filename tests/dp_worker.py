@@ -6,7 +6,8 @@ Every rank builds the same seeded model, takes ITS shard of a fixed global batch
 seed), runs STEPS optimiser steps through the reducer MODE ("allreduce" | "zero1") and writes its final flat parameter buffer,
 the reduced gradient buffer of the last step and (after gather_state) the Adam / EMA state to OUT_DIR/rank{r}.pt.
 With WORLD_SIZE=1 the same script is the single-process run on the whole batch.  Collectives run on gloo when
-MAPDIT_DIST_BACKEND=gloo (ranks share one GPU on a one-GPU box)."""
+MAPDIT_DIST_BACKEND=gloo (ranks share one GPU on a one-GPU box); with MAPDIT_DP_DEVICE_PER_RANK=1 every rank takes GPU LOCAL_RANK
+(RCCL over xGMI: tests/test_train_gpu.py::test_two_gpu_rccl_data_parallel, on boxes with more than one GPU)."""
 import os
 import sys
 
@@ -24,8 +25,9 @@ def main():
     from mapdit_amd.optim import FusedAdamEMA
     from mapdit_amd.src.models import DIT_MODELS
     rank, world, _ = parallel.init_from_env()
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    local = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MAPDIT_DP_DEVICE_PER_RANK") else 0     # RCCL: one GPU per rank
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
     if os.environ.get("MAPDIT_TEST_POISON"):               # tools/determinism_check.py: stale allocator memory of a known pattern
         junk = torch.full((1 << 28,), int(os.environ["MAPDIT_TEST_POISON"]), dtype=torch.uint8, device=dev)
         del junk

@@ -203,7 +203,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
 
 
-def _run_dp(tmp_path, tag, world, mode, precision, steps=3):
+def _run_dp(tmp_path, tag, world, mode, precision, steps=3, rccl=False):
     import socket
     import subprocess
     import sys
@@ -211,6 +211,8 @@ def _run_dp(tmp_path, tag, world, mode, precision, steps=3):
     out = tmp_path / tag
     out.mkdir()
     env = dict(os.environ, MAPDIT_DIST_BACKEND="gloo")
+    if rccl:                                               # one GPU per rank, RCCL: the product's multi-GPU path
+        env.update(MAPDIT_DIST_BACKEND="nccl", MAPDIT_DP_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     worker = os.path.join(root, "tests", "dp_worker.py")
     if world == 1:
         cmd = [sys.executable, worker, str(out), mode, precision, str(steps)]
@@ -268,6 +270,25 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
         e = rel_err(ar[0][k].numpy(), single3[k].numpy())
         print(f"{precision}: 2-rank all-reduce vs single process after 3 steps, {k}: {e:.2e}")
         assert e < tol, (k, e)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL with more than one rank")
+def test_two_gpu_rccl_data_parallel(tmp_path):
+    """The same two-rank run with ONE GPU PER RANK and RCCL collectives (the in-place all_gather_into_tensor /
+    reduce_scatter_tensor forms of parallel.py, which a one-GPU box can only exercise with one rank): replicas bit-identical, ZeRO-1
+    equal to the replicated optimiser, gathered EMA / optimiser state verified by the owners' checksums (parallel._verify_gather),
+    and the result equal to the single process on the whole batch."""
+    ar = _run_dp(tmp_path, "ar", 2, "allreduce", "bf16", rccl=True)
+    z1 = _run_dp(tmp_path, "z1", 2, "zero1", "bf16", rccl=True)
+    for k in ("p", "g", "m", "v", "e0", "e1"):
+        assert torch.equal(ar[0][k], ar[1][k]), f"allreduce replicas differ in {k}"
+        assert torch.equal(z1[0][k], z1[1][k]), f"zero1 replicas differ in {k}"
+    for k in ("p", "m", "v", "e0", "e1"):      # (RCCL's ring all-reduce and reduce-scatter may add in different orders: not bit for bit)
+        assert rel_err(z1[0][k].numpy(), ar[0][k].numpy()) < 1e-5, k
+    single1 = _run_dp(tmp_path, "w1s1", 1, "allreduce", "bf16", steps=1)[0]
+    ar1 = _run_dp(tmp_path, "ars1", 2, "allreduce", "bf16", steps=1, rccl=True)[0]
+    for k in ("g", "p", "m", "e0"):
+        assert rel_err(ar1[k].numpy(), single1[k].numpy()) < 2e-5, k
 
 
 def test_ema_class_matches_fused_optimizer(tmp_path):
