@@ -176,7 +176,13 @@ template <class Epi> constexpr int kDirectOuts = 0;
 // (An `sc1` write-through store, which does not keep the line in L2 at all, was 5 % faster still but let a following kernel
 // read stale contents of a reused buffer now and then, even behind s_waitcnt vmcnt(0): not used.)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-__device__ __forceinline__ void store16_stream(void* p, u32x4_t v) { __builtin_nontemporal_store(v, (u32x4_t*)p); }
+#ifndef MAPDIT_STORE_MODE
+#define MAPDIT_STORE_MODE 0        // A/B builds: 1 = plain stores instead of non-temporal ones
+#endif
+__device__ __forceinline__ void store16_stream(void* p, u32x4_t v) {
+    if (MAPDIT_STORE_MODE == 1) *(u32x4_t*)p = v;
+    else __builtin_nontemporal_store(v, (u32x4_t*)p);
+}
 __device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
     u32x4_t u;
     u.x = pack16(v[0], v[1]); u.y = pack16(v[2], v[3]); u.z = pack16(v[4], v[5]); u.w = pack16(v[6], v[7]);

@@ -57,11 +57,14 @@ struct RmbP {
     float* part;
 };
 
-template <bool ROT>     // ROT: the rotation form (compile-time: the AdaLN form's loop carries no trace of it)
+// ROT: the rotation form (compile-time: the AdaLN form's loop carries no trace of it).  CL: column lanes of 4 columns each; a
+// block covers 4 CL columns and 256 / CL rows per step (CL = 64: 1-KiB fp32 row segments, when D is a multiple of 256).
+template <bool ROT, int CL>
 __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
-    __shared__ float red[8][32][13];
-    const int n = blockIdx.x, cb0 = blockIdx.y * 128;
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    constexpr int RG = 256 / CL;
+    __shared__ float red[RG][CL][13];
+    const int n = blockIdx.x, cb0 = blockIdx.y * (4 * CL);
+    const int cl = threadIdx.x & (CL - 1), rg = threadIdx.x / CL;
     const int d = cb0 + cl * 4;
     float g = 0.f, den = 1.f;
     if (p.dxm && !ROT) { g = *p.gain; den = mp_den(g); }
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0}, a_g[4] = {0, 0, 0, 0}, a_gain = 0.f;
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, guv[4] = {gu.x, gu.y, gu.z, gu.w};
     const int rows_z = p.T / gridDim.z, t_beg = blockIdx.z * rows_z;
-    for (int t = t_beg + rg; t < t_beg + rows_z; t += 8) {
+    for (int t = t_beg + rg; t < t_beg + rows_z; t += RG) {
         const size_t off = ((size_t)n * p.T + t) * p.D + d;
         float dx[4] = {0, 0, 0, 0};
         if (p.dxo) {
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
         for (int j = 0; j < 13; ++j) {
             float a = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a += red[r][cl][j];
+            for (int r = 0; r < RG; ++r) a += red[r][cl][j];
             s[j] = a;
         }
         const bool split = gridDim.z > 1;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
             *(float4*)(split ? pz + p.D + d : p.dshift + (size_t)n * p.ldd + d) = make_float4(s[4], s[5], s[6], s[7]);
             float gsum = s[12];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
+            for (int o = CL / 2; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 64);
             if (cl == 0) p.dgain_part[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y] = gsum * p.gscale;
         }
         if (p.y_up) *(float4*)(split ? pz + 2 * p.D + d : p.dg_up + (size_t)n * p.ldd_up + d) = make_float4(s[8], s[9], s[10], s[11]);
@@ -412,10 +415,18 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
             Z *= 2;
     }
     p.part = Z > 1 ? a->part_scratch : nullptr;
-    if (p.rot) hipLaunchKernelGGL(resid_mod_bwd_kernel<true>, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(resid_mod_bwd_kernel<false>, dim3(a->n_samples, a->D / 128, Z), dim3(256), 0, (hipStream_t)stream, p);
+#ifndef MAPDIT_RMB_WIDE
+#define MAPDIT_RMB_WIDE 1
+#endif
+    const bool wide = MAPDIT_RMB_WIDE && Z == 1 && a->D % 256 == 0;          // 256 columns per block: 1-KiB row segments
+    const int cblocks = wide ? a->D / 256 : a->D / 128;
+    if (wide) {
+        if (p.rot) hipLaunchKernelGGL((resid_mod_bwd_kernel<true, 64>), dim3(a->n_samples, cblocks, 1), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((resid_mod_bwd_kernel<false, 64>), dim3(a->n_samples, cblocks, 1), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (p.rot) hipLaunchKernelGGL((resid_mod_bwd_kernel<true, 32>), dim3(a->n_samples, cblocks, Z), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((resid_mod_bwd_kernel<false, 32>), dim3(a->n_samples, cblocks, Z), dim3(256), 0, (hipStream_t)stream, p);
     MD_LAUNCH_CHECK();
-    const int npart = a->n_samples * (a->D / 128) * Z;
+    const int npart = a->n_samples * cblocks * Z;
     const bool own_gain = a->dgain_out != nullptr && a->dxm != nullptr;
     if (Z > 1) {
         hipLaunchKernelGGL(rmb_finish_kernel, dim3(cdiv((long)a->n_samples * a->D, 256) + (own_gain ? 1 : 0)), dim3(256), 0,
