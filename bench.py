@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)          # ~10 s of host work at ~1 s per DiT-B/2 batch-8 step with the swept thread count
     ap.add_argument("--cpu-c1-steps", type=int, default=10)
     args = ap.parse_args()
 
