@@ -99,6 +99,22 @@ def test_attention_full_size_normalisation_and_backward_linearity(L):
     for a, b in zip(*outs):
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0
         assert torch.equal(2 * a, b)
+    # the one-launch streaming backward (what the engine runs: 12 heads per persistent workgroup at this size), same properties:
+    # doubling dO doubles dqkv bit for bit, a repeated launch gives the same bits, and it agrees with the two-pass result
+    scales = torch.stack([8.0 / (q.norm(dim=1) + 1e-4), 8.0 / (k.norm(dim=1) + 1e-4)]).contiguous()
+    fused = []
+    for scale in (1.0, 2.0, 1.0):
+        d = (dO.float() * scale).bfloat16()
+        delta = torch.empty(rows, device=DEV)
+        dqkv = torch.empty(B * T, 3 * HEADS * 64, device=DEV, dtype=torch.bfloat16)
+        L.lib().attn_cos_bwd_fused(qn.data_ptr(), kn.data_ptr(), v2.data_ptr(), d.data_ptr(), o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                   scales.data_ptr(), dqkv.data_ptr(), B, T, HEADS, 64, st())
+        torch.cuda.synchronize()
+        fused.append(dqkv.float())
+    assert torch.isfinite(fused[0]).all() and torch.equal(2 * fused[0], fused[1]) and torch.equal(fused[0], fused[2])
+    dv_two_pass = outs[0][2].view(B, HEADS, T, 64).transpose(1, 2).reshape(B * T, HEADS * 64)
+    dv_fused = fused[0].view(B * T, 3, HEADS * 64)[:, 2]
+    assert float((dv_fused - dv_two_pass).norm() / dv_two_pass.norm()) < 6e-3
 
 
 @pytest.fixture(scope="module")
