@@ -660,10 +660,12 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
 //     the cosine scales of q^, k^ (3 KiB per head) and this wave's V fragments (registers) follow in later intervals.
 //   * the dS^T -> dQ hand-over of the one-head kernel runs across head boundaries (tile counter t = 8 * head + query tile).
 //   * dK, dV leave in the interval after a head's last barrier through the wave's own 32 rows of the dS^T image that all waves
-//     have just finished reading (2,304 bytes, private until the wave writes its next dS^T slice): the k^ Jacobian is applied in
-//     the accumulator layout (x^ by eight transposing reads of the K image, the row dot product by five xor-shuffles), then four
+//     have just finished reading (2 KiB, private until the wave writes its next dS^T slice): the k^ Jacobian is applied in the
+//     accumulator layout (x^ by eight transposing reads of the K image, the row dot product by DPP sums over 32 lanes), then four
 //     32 x 32 pieces go through the slice and leave as 16-byte stores.
-// One barrier per query tile, no other synchronisation; every wave runs the same number of intervals.
+// One barrier per query tile, no other synchronisation; every wave runs the same number of intervals.  Launch: one workgroup per CU
+// (or per head if there are fewer), 512 threads, 150 KB of LDS; no workgroup depends on another, so the grid need not be co-resident.
+
 // Sum over aligned groups of 2^n lanes by DPP (no index register, no LDS traffic; ds_swizzle for the 16 <-> 16 step): every lane of
 // a group ends with the group's sum.
 template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
         const float* sks = sk_s + (j & 1) * T + k0;
         const float* kcs = kc_s + (j & 1) * T + k0;
         const int lane = opaque(tid) & 63, r = lane & 31, h2 = lane >> 5, gi = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-        char* slice = dsb_ + ((t + 1) & 1) * DS_BYTES + k0 * DS_LD;
+        char* slice = dsb_ + ((t + 1) & 1) * DS_BYTES + k0 * DS_LD;        // this wave's 32 rows: raw use, no swizzle
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float x0[4], x1[4];
