@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Training trajectories of the two engine precisions on identical seeds: the bf16 fast path against bf16x3 (which follows
-the reference's fp32 run to ~5e-6 over optimiser steps, tests/test_train_gpu.py).  Same model init, data, timesteps,
+"""Training trajectories of the engine precisions on identical seeds: the bf16 and fp16-operand fast paths against bf16x3 (which
+follows the reference's fp32 run to ~5e-6 over optimiser steps, tests/test_train_gpu.py).  Same model init, data, timesteps,
 label drops and schedule as map-dit_amd/train.py; prints the per-step losses of both runs and their relative gap.
 
     python tools/precision_trajectory.py --model DiT-S/2 --batch 64 --steps 200
@@ -51,16 +51,18 @@ def main():
     args = ap.parse_args()
     fast, w_fast = run(args, "bf16")
     again, _ = run(args, "bf16")
+    half, w_half = run(args, "f16")
     exact, w_exact = run(args, "bf16x3")
-    print(f"{args.model}, batch {args.batch}, {args.steps} steps, lr {args.lr}: per-step mean loss, bf16 | bf16x3 | relative gap")
+    print(f"{args.model}, batch {args.batch}, {args.steps} steps, lr {args.lr}: per-step mean loss, bf16 | f16 | bf16x3 | relative gaps to bf16x3")
     for i in list(range(0, min(10, args.steps))) + list(range(10, args.steps, max(args.steps // 20, 1))):
-        print(f"  step {i + 1:5d}  {fast[i]:.6f}  {exact[i]:.6f}  {abs(fast[i] - exact[i]) / exact[i]:.2e}")
-    rel = ((fast - exact).abs() / exact)
+        print(f"  step {i + 1:5d}  {fast[i]:.6f}  {half[i]:.6f}  {exact[i]:.6f}  {abs(fast[i] - exact[i]) / exact[i]:.2e}  {abs(half[i] - exact[i]) / exact[i]:.2e}")
     k = max(args.steps // 10, 1)
-    print(f"max gap first 10 steps {rel[:10].max():.2e}; all steps {rel.max():.2e}; mean of last {k}: "
-          f"bf16 {fast[-k:].mean():.5f} bf16x3 {exact[-k:].mean():.5f}")
+    for name, run_, w in (("bf16", fast, w_fast), ("f16", half, w_half)):
+        rel = ((run_ - exact).abs() / exact)
+        print(f"{name}: max gap first 10 steps {rel[:10].max():.2e}; all steps {rel.max():.2e}; mean of last {k}: {run_[-k:].mean():.5f} "
+              f"(bf16x3 {exact[-k:].mean():.5f}); all losses finite = {bool(torch.isfinite(run_).all())}; "
+              f"weights after {args.steps} steps: |w - w_bf16x3| / |w_bf16x3| = {(w - w_exact).norm() / w_exact.norm():.3e}")
     print(f"bf16 run repeated: bit-identical losses = {bool(torch.equal(fast, again))}")
-    print(f"weights after {args.steps} steps: |w_bf16 - w_bf16x3| / |w_bf16x3| = {(w_fast - w_exact).norm() / w_exact.norm():.3e}")
 
 
 if __name__ == "__main__":
