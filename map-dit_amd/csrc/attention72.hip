@@ -141,27 +141,61 @@ template <int T> struct Geo {
 };
 
 // ---- forward -----------------------------------------------------------------------------------------------
+// Round 3: K and V both stay ROW-MAJOR in LDS as plain copies of the head's [T][72] data (144-byte rows, no padding: 36 dwords per
+// row put the 16 rows of every ds_read_b128 lane group on distinct banks; 2 x 36 KiB at T = 256, two workgroups per CU), and the
+// transposed operand of O = P V comes from transposing reads (ds_read_b64_tr_b16: 2-way conflicts on part of the lanes with this
+// stride, which the 11 MFMAs per key tile hide).  Before, V went through a transposed image built with 2-byte LDS stores while
+// staging, 95 KiB per workgroup: 250 us per launch on 4,096 heads against 92 us for 3,072 heads of 64 columns.
+// Columns 72..79 of the fifth k-step of S: the K side reads whatever follows the row (the next row's first chunk: finite), the Q
+// side (registers, frag_global) is zero there.  Output columns 72..95 are computed from what follows a V row and never stored.
+constexpr int RS2 = 2 * HD;                    // 144: row stride of the plain row-major tiles
+__device__ __forceinline__ bf16x8_t frag_rows2(const char* tile, int row0, int ks, int lane) {
+    return *(const bf16x8_t*)(tile + (row0 + (lane & 31)) * RS2 + ((2 * ks + (lane >> 5)) << 4));
+}
+// B-operand fragment in the k order of pack8() from the row-major tile: element j of lane (r, h) is
+// [k = kbase + 8 (j >> 2) + 4 h + (j & 3)][d = d0 + r]  (16 lanes fetch a 4-row x 16-column block, each gets one column of it)
+__device__ __forceinline__ bf16x8_t frag_tr_rows2(const char* tile, int d0, int kbase, int lane) {
+    const int i = lane & 15, grp = lane >> 4;
+    const int col = d0 + 16 * (grp & 1) + 4 * (i & 3);
+    const int row0 = kbase + 4 * (grp >> 1) + (i >> 2);
+    typedef __attribute__((address_space(3))) bf16x4_t lds_v4;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + row0 * RS2 + col * 2));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + (row0 + 8) * RS2 + col * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 template <int T>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                 float* __restrict__ lse, int H, float scale) {
     using G = Geo<T>;
-    constexpr int SM = T * RS + IMG_ROWS * G::VLD;
+    constexpr int TILE = T * RS2 + 64;                 // (+ 64: the reads past the last row stay inside the array)
+    constexpr int SM = 2 * TILE;
     __shared__ __attribute__((aligned(16))) char smem[SM > G::NW * WT_BYTES ? SM : G::NW * WT_BYTES];
     char* ks_ = smem;
-    char* vts_ = smem + T * RS;
+    char* vs_ = smem + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const size_t bh = blockIdx.x;
     const int q0 = wave * 32;
-    Staged<T, G::NTH> sk_, sv_;
-    sk_.load(kn + bh * T * HD, HD, tid);
-    sv_.load(v + bh * T * HD, HD, tid);
+    // the head's K and V are contiguous [T][72] blocks: chunk i of the block goes to byte 16 i of its tile
+    constexpr int CHUNKS = T * CH, PER = (CHUNKS + G::NTH - 1) / G::NTH;
+    uint4 kc[PER], vc[PER];
+    const uint4* ksrc = (const uint4*)(kn + bh * T * HD);
+    const uint4* vsrc = (const uint4*)(v + bh * T * HD);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * G::NTH;
+        if (i < CHUNKS) { kc[k] = ksrc[i]; vc[k] = vsrc[i]; }
+    }
     bf16x8_t qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(qn + (bh * T + q0 + r) * HD, ks, h2);
-    sk_.template store<T>(ks_, nullptr, 0, tid);
-    sv_.template store<T>(nullptr, vts_, 0, tid);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * G::NTH;
+        if (i < CHUNKS) { *(uint4*)(ks_ + i * 16) = kc[k]; *(uint4*)(vs_ + i * 16) = vc[k]; }
+    }
+    if (tid < 4) { *(uint4*)(ks_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(vs_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); }
     __syncthreads();
 
     f32x16_t oa[DT] = {};
@@ -170,7 +204,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a);
+        for (int ks = 0; ks < KS; ++ks) a = MFMA32(frag_rows2(ks_, 32 * kt, ks, lane), qf[ks], a);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
 #pragma unroll
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
             const bf16x8_t pa = pack8(a, 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                oa[dt] = MFMA32(pa, frag_tr<T>(vts_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt]);
+                oa[dt] = MFMA32(pa, frag_tr_rows2(vs_, 32 * dt, 32 * kt + 16 * s2, lane), oa[dt]);
         }
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     float rs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) rs[i] = __shfl(inv_l, acc_row(i, lane), 64);
-    __syncthreads();                                   // K / V images are dead: reuse them as store buffers
+    __syncthreads();                                   // K / V tiles are dead: reuse them as store buffers
     store_wave_tile(smem + wave * WT_BYTES, oa, rs, o + ((size_t)b * T + q0) * D + hh * HD, D, lane);
     if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
 }
