@@ -62,12 +62,16 @@ enum {
                                 * holds the operands (its dxm field is ignored: the accumulator takes its place).  Needs
                                 * T = rmb->T in {64, 128, 256} (256 % T == 0: a sample's rows lie in ONE 256-row tile, whose
                                 * 64-row blocks belong to one sample each), M >= 512, N = D >= 256.  dgain_part receives ceil(M/256) * ceil(D/256) partials.          */
-    MAPDIT_EPI_QKV_HEADS = 6   /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
+    MAPDIT_EPI_QKV_HEADS = 6,  /* the QKV projection's consumer fused in (attention.py:38-43): column n of the [M, 3D] result
                                 * is (which, head, d) = (n / D, n % D / 64, n % 64); q and k rows are cosine-normalised per
                                 * head, x * s with s = 8 / (|x| + 1e-4) from the fp32 accumulators, and everything is written
                                 * head-major: out = q^, out2 = k^, out3 = v as bf16 [M/rows_per_sample * H][rows_per_sample][64],
                                 * out4 = s as fp32 [2][M/rows_per_sample * H][rows_per_sample] (q then k; the backward's
                                 * normalisation Jacobian needs nothing else).  head_dim 64 only; N = 3D, D % 64 == 0.       */
+    MAPDIT_EPI_QKV_HEADS_RAW = 10 /* the head split alone, for any head_dim = ld2 that is a multiple of 8 (72: DiT-XL): out = q,
+                                * out2 = k, out3 = v, UNNORMALISED, bf16 [M/rows_per_sample * H][rows_per_sample][head_dim].
+                                * Inference path of head_dim 72 (heads do not line up with the GEMM tiles, so the epilogue
+                                * cannot form per-head norms): mapdit_attn_cos_fwd_rawqk normalises while it stages q and k. */
 };
 
 typedef struct {
@@ -235,6 +239,11 @@ int mapdit_qkv_merge_bwd(const uint16_t* qkv, int B, int T, int H, int head_dim,
 /* o [B*T, H*hd] = softmax(qn kn^T / sqrt(hd)) v ; lse [B*H][T] */
 int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
                         int T, int H, int head_dim, void* stream);
+/* The same forward on UNNORMALISED q, k (head-major, as MAPDIT_EPI_QKV_HEADS_RAW writes them): each row is scaled by
+ * sqrt(head_dim) / (|row| + 1e-4) and rounded to the operand format while it is staged (reference attention.py:38-43 = normalize of
+ * q, k, then SDPA).  Nothing is kept for a backward pass: inference only.  head_dim 72, T in {64, 128, 256}. */
+int mapdit_attn_cos_fwd_rawqk(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                              int head_dim, void* stream);
 /* backward; also writes delta [B*H][T] = rowsum(dO * O) */
 int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                         const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
@@ -426,6 +435,8 @@ int mapdit_qkv_merge_bwd_f16(const uint16_t* qkv, int B, int T, int H, int head_
                              const uint16_t* dkn, const uint16_t* dv, uint16_t* dqkv, void* stream);
 int mapdit_attn_cos_fwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
                             int T, int H, int head_dim, void* stream);
+int mapdit_attn_cos_fwd_rawqk_f16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                                  int head_dim, void* stream);
 int mapdit_attn_cos_bwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                             const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                             int head_dim, void* stream);

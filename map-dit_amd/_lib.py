@@ -56,7 +56,7 @@ PRECISIONS = {"bf16": 0, "bf16x3": 1, "f16": 2}
 
 
 NT, NN, TN = 0, 1, 2
-EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS, EPI_SILU2_GRAD, EPI_MUL_AUX, EPI_RMB = range(10)
+EPI_STORE_BF16, EPI_STORE_F32, EPI_SILU2, EPI_RESID, EPI_DSILU, EPI_SILU2_COND, EPI_QKV_HEADS, EPI_SILU2_GRAD, EPI_MUL_AUX, EPI_RMB, EPI_QKV_HEADS_RAW = range(11)
 PROF_FC1_FWD = 0
 PEEK_IDS = {name: i for i, name in enumerate(
     ["four", "temb", "c", "mod_all", "x0", "xmodf", "lin", "xm", "qkv", "qn", "kn", "v", "o", "xm2", "hact", "xmid", "xout"])}
@@ -87,6 +87,7 @@ _SIGS = {
     "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_attn_cos_fwd_rawqk": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_cos_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
     "mapdit_attn_cos_bwd_fused": [vp] * 9 + [ci, ci, ci, ci, vp],
     "mapdit_qkv_split_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
@@ -123,7 +124,7 @@ _SIGS = {
 }
 # IEEE fp16 operand forms: same signatures (mapdit.h, "16-bit operand format")
 for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rot_modulate_fwd", "qkv_split",
-           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
+           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
            "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
     _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]
 for _b, _h in (("gemm_bf16", "gemm_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),

@@ -163,7 +163,9 @@ __device__ __forceinline__ bf16x8_t frag_tr_rows2(const char* tile, int d0, int 
     const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tile + (row0 + 8) * RS2 + col * 2));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-template <int T>
+// RAW: q, k arrive unnormalised (MAPDIT_EPI_QKV_HEADS_RAW) and are scaled by sqrt(72) / (|row| + eps) here, as qkv_split72 would have:
+// the query rows in registers (a row's chunks sit in lanes r and r + 32), the key rows by one thread per row once the K tile is in LDS.
+template <int T, bool RAW>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                 float* __restrict__ lse, int H, float scale) {
@@ -190,6 +192,19 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     bf16x8_t qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(qn + (bh * T + q0 + r) * HD, ks, h2);
+    if (RAW) {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float x = up16((bf16_t)qf[ks][e]); ss += x * x; }      // (the zero fill adds nothing)
+        ss += __shfl_xor(ss, 32, 64);
+        const float sc = sqrtf((float)HD) / (sqrtf(ss) + NORM_EPS);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (short)cvt16(up16((bf16_t)qf[ks][e]) * sc);
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = tid + k * G::NTH;
@@ -197,6 +212,29 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     }
     if (tid < 4) { *(uint4*)(ks_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(vs_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); }
     __syncthreads();
+    if (RAW) {
+        if (tid < T) {                                     // one key row per thread (rows 36 dwords apart: conflict-free 16-byte accesses)
+            char* row = ks_ + tid * RS2;
+            uint4 c9[CH];
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                c9[c] = *(const uint4*)(row + c * 16);
+                const uint32_t w[4] = {c9[c].x, c9[c].y, c9[c].z, c9[c].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float a = lo16(w[e]), b2 = hi16(w[e]); ss += a * a + b2 * b2; }
+            }
+            const float sc = sqrtf((float)HD) / (sqrtf(ss) + NORM_EPS);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                uint4 u = c9[c];
+                u.x = pack16(lo16(u.x) * sc, hi16(u.x) * sc); u.y = pack16(lo16(u.y) * sc, hi16(u.y) * sc);
+                u.z = pack16(lo16(u.z) * sc, hi16(u.z) * sc); u.w = pack16(lo16(u.w) * sc, hi16(u.w) * sc);
+                *(uint4*)(row + c * 16) = u;
+            }
+        }
+        __syncthreads();
+    }
 
     f32x16_t oa[DT] = {};
     float lsum = 0.f;
@@ -505,7 +543,18 @@ int MD_SYM(attn72_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v
                       void* stream) {
     const float scale = 1.f / sqrtf((float)HD);
     hipStream_t st = (hipStream_t)stream;
-    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, o, lse, H, scale));
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, false>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, o, lse, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int MD_SYM(attn_cos_fwd_rawqk)(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T,
+                                         int H, int head_dim, void* stream) {
+    MD_CHECK(q && k && v && o && lse && B > 0 && H > 0, "attn_cos_fwd_rawqk: null/empty argument");
+    MD_CHECK(head_dim == HD, "attn_cos_fwd_rawqk: head_dim=%d unsupported (72)", head_dim);
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, true>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, q, k, v, o, lse, H, scale));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

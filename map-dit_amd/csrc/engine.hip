@@ -933,7 +933,20 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         float* xout = e->X[save ? 2 * i + 2 : (2 * i + 2) % 3];
         const float* gmlp = gain_of(pidx_block(i, MAPDIT_B_GAIN_MLP));
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
-        if (e->generic_attn) {
+        // inference at head_dim 72 (DiT-XL sampling): the GEMM epilogue writes q, k, v head-major and the attention kernel normalises
+        // q, k while it stages them - no split / normalise pass over the QKV result (219 us of a 2.4 ms block at 256 x 256 tokens)
+        static const bool raw72_on = [] { const char* a = getenv("MAPDIT_ATTN72"); const char* r = getenv("MAPDIT_ATTN72_RAW");
+                                          return !(a && a[0] == '0') && !(r && r[0] == '0'); }();
+        const bool raw72 = raw72_on && !save && e->hd == 72 && (T == 64 || T == 128 || T == 256);
+        if (raw72) {
+            mapdit_epilogue_t ep;
+            memset(&ep, 0, sizeof(ep));
+            ep.kind = MAPDIT_EPI_QKV_HEADS_RAW;
+            ep.out = b.qn; ep.out2 = b.kn; ep.out3 = b.v;
+            ep.rows_per_sample = T; ep.ld2 = e->hd;
+            ep.alpha = 1.f;
+            TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
+        } else if (e->generic_attn) {
             TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, epi_bf16(b.qkv, 3 * D), st));
             TRY(DT_FN(e, mapdit_qkv_split)(b.qkv, N, T, H, e->hd, b.qn, b.kn, b.v, st));
         } else {   // head split + cosine normalisation of q, k in the GEMM epilogue (attention.py:38-43)
@@ -945,7 +958,8 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
             ep.alpha = 1.f;
             TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
         }
-        TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        else TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above

@@ -551,6 +551,32 @@ struct EpiQkvHeads {
     }
 };
 
+// The head split alone (any head_dim that is a multiple of 8, e.g. 72): column n of the [M, 3D] result is (which, head, d) =
+// (n / D, n % D / hd, n % hd) and goes, unnormalised, to out[which] [M / T * H][T][hd].  For inference with head_dim 72, whose
+// heads do not line up with the 256-column tiles (no per-head sums in the epilogue): the attention kernel normalises q and k while
+// it stages them (mapdit_attn_cos_fwd_rawqk), and the separate split / normalise pass over the QKV result disappears.
+struct EpiHeadsRaw {
+    bf16_t *q, *k, *v; int T, H, hd;
+    int tshift;
+    typedef EpiNoAux Aux;
+    struct Tile { bf16_t* dst; int h; };
+    __device__ __forceinline__ Tile tile_begin(int, int, int n) const {
+        const int D = hd * H, which = n / D, c = n - which * D;
+        Tile t;
+        t.h = c / hd;
+        t.dst = (which == 0 ? q : which == 1 ? k : v) + (c - t.h * hd);
+        return t;
+    }
+    __device__ __forceinline__ Aux load(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int, const float* a, int, const Aux&, const Tile& tc) const {
+        const int b = tshift >= 0 ? m >> tshift : m / T, t = m - b * T;
+        store8_bf16(tc.dst + (((size_t)b * H + tc.h) * T + t) * hd, a);
+    }
+    __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
+        apply(m, n, a, 0, Aux(), tile_begin(m, m, n));
+    }
+};
+
 // ---- the MFMA kernel -------------------------------------------------------------------------------------
 template <int AK, int BK, class Epi, bool KTAIL = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
@@ -1868,6 +1894,14 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
                           EpiQkvHeads{(bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, (float*)e->out4, e->rows_per_sample, H,
                                       (long)M * H,
                                       (e->rows_per_sample & (e->rows_per_sample - 1)) == 0 ? __builtin_ctz(e->rows_per_sample) : -1}, st);
+        }
+        case MAPDIT_EPI_QKV_HEADS_RAW: {
+            const int hd = e->ld2, T = e->rows_per_sample;
+            MD_CHECK(e->out && e->out2 && e->out3 && T > 0 && hd > 0 && hd % 8 == 0, "gemm: QKV_HEADS_RAW needs out, out2, out3, rows_per_sample, ld2 = head_dim (multiple of 8)");
+            MD_CHECK(N % (3 * hd) == 0 && M % T == 0, "gemm: QKV_HEADS_RAW needs N = 3 * head_dim * heads, M = samples * rows_per_sample");
+            return launch(layout, M, N, K, A, lda, B, ldb,
+                          EpiHeadsRaw{(bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, T, N / (3 * hd), hd,
+                                      (T & (T - 1)) == 0 ? __builtin_ctz(T) : -1}, st);
         }
     }
     mapdit_set_error("gemm: unknown epilogue kind %d", e->kind);

@@ -596,6 +596,45 @@ def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
         lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 72, st())
 
 
+@pytest.mark.parametrize("B,T,H,K", [(2, 256, 3, 128), (3, 64, 2, 192), (1, 128, 16, 256)])
+def test_head_dim_72_inference_path_without_the_split_pass(L, B, T, H, K):
+    """Inference at head_dim 72 (DiT-XL sampling): the QKV GEMM writes q, k, v head-major and unnormalised (MAPDIT_EPI_QKV_HEADS_RAW)
+    and mapdit_attn_cos_fwd_rawqk normalises q, k while staging them - against the training-path chain (plain QKV store,
+    mapdit_qkv_split, mapdit_attn_cos_fwd) on the same operands and against the oracle ops."""
+    from oracle.dit_oracle import normalize
+    hd, D, M = 72, H * 72, B * T
+    x = bf16_exact(M, K, seed=40, scale=0.25)
+    w = bf16_exact(3 * D, K, seed=41, scale=0.25)
+    lib = L.lib()
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
+    xd, wd = to_bf(x), to_bf(w)
+    # reference chain of the library
+    qkv = mk(M, 3 * D)
+    run_gemm(L, 0, xd, wd, L.EPI_STORE_BF16, M, 3 * D, K, out=p(qkv), ldo=3 * D, alpha=1.0)
+    qn, kn, v = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    lib.qkv_split(p(qkv), B, T, H, hd, p(qn), p(kn), p(v), st())
+    o1, lse1 = mk(M, D), torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd(p(qn), p(kn), p(v), p(o1), p(lse1), B, T, H, hd, st())
+    # fused chain
+    qr, kr, vr = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    run_gemm(L, 0, xd, wd, L.EPI_QKV_HEADS_RAW, M, 3 * D, K, out=p(qr), out2=p(kr), out3=p(vr), rows_per_sample=T, ld2=hd, alpha=1.0)
+    o2, lse2 = mk(M, D), torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd_rawqk(p(qr), p(kr), p(vr), p(o2), p(lse2), B, T, H, hd, st())
+    torch.cuda.synchronize()
+    heads = lambda z: z.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).reshape(3, B * H, T, hd)
+    raw = heads(qkv)
+    assert torch.equal(qr, raw[0]) and torch.equal(kr, raw[1]) and torch.equal(vr, raw[2]) and torch.equal(vr, v)   # the split is exact
+    assert rel_err(o2.float().cpu().numpy(), o1.float().cpu().numpy()) < 4e-3      # same roundings, other summation order of the norms
+    assert rel_err(lse2.cpu().numpy(), lse1.cpu().numpy()) < 1e-3
+    qkv_ref = x @ w.t()
+    q, k, vv = qkv_ref.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, hd).transpose(1, 2)
+    att = torch.softmax(normalize(sp(q)) @ normalize(sp(k)).transpose(-1, -2) / hd ** 0.5, dim=-1) @ sp(vv)
+    assert rel_err(o2.float().cpu().numpy(), att.transpose(1, 2).reshape(M, D).numpy()) < 1.2e-2
+    with pytest.raises(L.MapditError):
+        lib.attn_cos_fwd_rawqk(p(qr), p(kr), p(vr), p(o2), p(lse2), B, T, H, 64, st())
+
+
 @pytest.mark.parametrize("B,H", [(30, 12), (64, 12), (23, 13)])
 def test_streaming_attention_backward_many_heads(L, B, H):
     """The one-launch attention backward of 256-token heads keeps one workgroup per CU and walks several heads per workgroup (K
