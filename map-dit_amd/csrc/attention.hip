@@ -666,22 +666,6 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
 // One barrier per query tile, no other synchronisation; every wave runs the same number of intervals.  Launch: one workgroup per CU
 // (or per head if there are fewer), 512 threads, 150 KB of LDS; no workgroup depends on another, so the grid need not be co-resident.
 
-// Sum over aligned groups of 2^n lanes by DPP (no index register, no LDS traffic; ds_swizzle for the 16 <-> 16 step): every lane of
-// a group ends with the group's sum.
-template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float sum8(float d) {
-    d += dpp_f<0xB1>(d);                                    // quad_perm [1,0,3,2]
-    d += dpp_f<0x4E>(d);                                    // quad_perm [2,3,0,1]
-    d += dpp_f<0x141>(d);                                   // row_half_mirror
-    return d;
-}
-__device__ __forceinline__ float sum16(float d) { d = sum8(d); return d + dpp_f<0x140>(d); }          // row_mirror
-__device__ __forceinline__ float sum32(float d) {
-    d = sum16(d);
-    return d + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, d), 0x401F));   // lane ^ 16
-}
 // A value the optimiser cannot prove loop-invariant: address arithmetic derived from it stays inside the loop body instead of being
 // hoisted into registers that live across the whole kernel (hipcc hoisted ~30 such values here and spilled them to scratch - and
 // a scratch reload waits for vmcnt(0), i.e. for every prefetch in flight).

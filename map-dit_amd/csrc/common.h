@@ -90,6 +90,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over aligned groups of 2^n lanes by DPP (no index register, no LDS traffic; ds_swizzle for the 16 <-> 16 step): every lane of
+// a group ends with the group's sum.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum8(float d) {
+    d += dpp_f<0xB1>(d);                                    // quad_perm [1,0,3,2]
+    d += dpp_f<0x4E>(d);                                    // quad_perm [2,3,0,1]
+    d += dpp_f<0x141>(d);                                   // row_half_mirror
+    return d;
+}
+__device__ __forceinline__ float sum16(float d) { d = sum8(d); return d + dpp_f<0x140>(d); }          // row_mirror
+__device__ __forceinline__ float sum32(float d) {
+    d = sum16(d);
+    return d + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, d), 0x401F));   // lane ^ 16
+}
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): these run in GEMM epilogues, where the VALU
 // time of the activation is not hidden behind anything, and their results are rounded to bf16 anyway.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }

@@ -531,9 +531,7 @@ struct EpiQkvHeads {
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
-            ss += __shfl_xor(ss, 4, 64);
+            ss = sum8(ss);                                    // DPP, the same additions in the same order as the xor butterfly (same bits)
             // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences (~30 instructions per chunk): the scale is rounded
             // into bf16 products anyway, and the backward reads this very value back
             const float sc = 8.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(ss) + NORM_EPS);
