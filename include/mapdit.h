@@ -32,7 +32,8 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
+int mapdit_abi_version(void);   /* 4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
+                                 * mapdit_engine_loss_scale, loss_scale must be a power of two.  3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
                                  * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -156,6 +157,17 @@ typedef struct {
 int mapdit_adam_ema_step_scalars(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
                                  float* ema_b, long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2,
                                  float eps, void* stream);
+/* Non-finite gradient guard of the fp16 engine (the reference trains in fp32, train.py:222-223, and cannot overflow; fp16 activation
+ * gradients beyond 65504 become inf).  `status` is two device ints {last bad step, number of bad steps}, zeroed by the caller once.
+ * mapdit_grad_nonfinite_check scans n gradients and, if any is inf / NaN, records `step` (> 0) in status[0] and counts it in status[1]
+ * (once per step, whatever the number of launches: sub-ranges of one step pass the same step number).  mapdit_adam_ema_step_guarded is
+ * mapdit_adam_ema_step_scalars that returns without touching parameters, moments or EMA copies when status[0] == step: the decision
+ * is taken on the device, nothing is read back in the training loop (the host polls status[1] at logging cadence and lowers the
+ * loss scale: mapdit_engine_set_loss_scale). */
+int mapdit_grad_nonfinite_check(const float* grads, long n, int* status, int step, void* stream);
+int mapdit_adam_ema_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a, float* ema_b,
+                                 long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2, float eps,
+                                 const int* status, int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Token-stream kernels of the DiT block (src/utils.py:11-16, src/blocks/dit_block.py:33-36).
@@ -334,7 +346,8 @@ typedef struct {
                      * the residual / modulate backward (mapdit_rot_coef_fwd above).  Not with MAPDIT_PREC_BF16X3. */
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
-                       * divided by it again before it is written.  0 = chosen per backward from the batch:
+                       * divided by it again before it is written.  A finite power of two (anything else is refused: the division
+                       * must be exact), or 0 = chosen per backward from the batch:
                        * 2^(floor(log2(N * C * S * S)) - 5), i.e. |dout| ~ 1/(N C S S) of a mean-reduced loss becomes ~1/32. */
 } mapdit_config_t;
 /* MAPDIT_PREC_F16: the MAPDIT_PREC_BF16 engine with IEEE fp16 in place of bf16 for every GEMM / attention operand (weight images,
@@ -373,6 +386,10 @@ int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* stream);
  * stage k in 1..depth = block depth-k, stage depth+1 = patch embedding + conditioning path.  Stages must be run in
  * order; when a call returns, the gradients owned by its stages are final (enqueued on `stream`). */
 int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* dout, int stage_from, int stage_to, void* stream);
+/* MAPDIT_PREC_F16: change the loss scale of the following backward passes (0 = automatic, else a finite power of two), and read
+ * the one the most recent backward ran with (1 for the other precisions). */
+int mapdit_engine_set_loss_scale(mapdit_engine_t* e, float loss_scale);
+int mapdit_engine_loss_scale(mapdit_engine_t* e, float* out);
 
 /* Measurement hook: bracket every launch of one kernel family with HIP events on the launch stream.
  * MAPDIT_PROF_FC1_FWD = the block-MLP fc1 GEMM (gemm NT + SILU2 epilogue, [N*T, 4D] = [N*T, D] x [4D, D]^T). */

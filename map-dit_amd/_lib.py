@@ -74,6 +74,8 @@ _SIGS = {
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],
+    "mapdit_adam_ema_step_guarded": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp, ci, vp],
+    "mapdit_grad_nonfinite_check": [vp, cl, vp, ci, vp],
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
@@ -118,6 +120,8 @@ _SIGS = {
     "mapdit_engine_forward": [vp, vp, vp, vp, ci, ci, vp, vp],
     "mapdit_engine_backward": [vp, vp, vp],
     "mapdit_engine_backward_stages": [vp, vp, ci, ci, vp],
+    "mapdit_engine_set_loss_scale": [vp, cf],
+    "mapdit_engine_loss_scale": [vp, C.POINTER(cf)],
     "mapdit_engine_profile_begin": [vp, ci, ci],
     "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
     "mapdit_engine_peek": [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(ci), C.POINTER(ci)],

@@ -304,12 +304,21 @@ size_t carve(mapdit_engine* e, void* base) {
     return (cv.off + 255) & ~(size_t)255;
 }
 
+// 0 (automatic) or a finite power of two: gradients are divided by it again, which must be exact
+bool loss_scale_ok(float s) {
+    if (s == 0.f) return true;
+    if (!(s > 0.f) || !isfinite(s)) return false;
+    int ex;
+    return frexpf(s, &ex) == 0.5f;
+}
+
 int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c, "engine: null config");
     MD_CHECK(c->depth > 0 && c->hidden > 0 && c->max_batch > 0, "engine: empty config");
     MD_CHECK(c->precision == MAPDIT_PREC_BF16 || c->precision == MAPDIT_PREC_BF16X3 || c->precision == MAPDIT_PREC_F16,
              "engine: unknown precision %d", c->precision);
     MD_CHECK(c->loss_scale >= 0.f && (c->loss_scale == 0.f || c->precision == MAPDIT_PREC_F16), "engine: loss_scale is an fp16 setting (>= 0)");
+    MD_CHECK(loss_scale_ok(c->loss_scale), "engine: loss_scale=%g must be 0 (automatic) or a finite power of two", (double)c->loss_scale);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
@@ -1029,6 +1038,21 @@ extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void*
 extern "C" int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* st) {
     MD_CHECK(e, "engine_backward: null argument");
     return mapdit_engine_backward_stages(e, dout, 0, e->cfg.depth + 1, st);
+}
+
+extern "C" int mapdit_engine_set_loss_scale(mapdit_engine_t* e, float loss_scale) {
+    MD_CHECK(e, "engine_set_loss_scale: null argument");
+    MD_CHECK(e->f16 || loss_scale == 0.f, "engine_set_loss_scale: loss_scale is an fp16 setting");
+    MD_CHECK(loss_scale_ok(loss_scale), "engine_set_loss_scale: loss_scale=%g must be 0 (automatic) or a finite power of two", (double)loss_scale);
+    MD_CHECK(e->next_stage == 0, "engine_set_loss_scale: a staged backward is in progress");
+    e->cfg.loss_scale = loss_scale;
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_engine_loss_scale(mapdit_engine_t* e, float* out) {
+    MD_CHECK(e && out, "engine_loss_scale: null argument");
+    *out = e->lscale;
+    return MAPDIT_OK;
 }
 
 // Stage 0 = final layer, stage k (1..L) = block L-k, stage L+1 = patch embedding + conditioning path.  After stage

@@ -1399,6 +1399,203 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }
 }
 
+// ---- round 4: the same K loop with a WAVE-PRIVATE epilogue and the next tile's prologue under it -----------------------------
+// Where a 256x256x768 tile's time went in the kernel above: fill 4.3 k cycles + K loop 34.4 k + epilogue
+// 9.2 k (bf16 store) ... 22 k (SiLU + derivative), the matrix pipe idle outside the K loop.  Two things change here, the K loop
+// (two phases per K-tile, two staggered wave groups) does not:
+//  * The epilogue is wave-private.  Every wave turns its own 128 x 64 result into whole 8-column row chunks through its own 4 KiB
+//    of LDS (the 32 KiB the 128 KiB of staging leave free), one 16-row accumulator tile at a time: 4 ds_write_b128 in the
+//    accumulator layout, 4 ds_read_b128 as row chunks (unit ^ (row & 7): both conflict-free), two chunks per lane, eight lanes per
+//    128-byte (bf16) / 256-byte (fp32) row segment.  No workgroup barrier between K loop and K loop: the eight waves drift apart
+//    and one wave's LDS traffic overlaps another's VALU work and stores (the shared fp32 image needed four barriers per tile and
+//    made all waves write, then all waves compute).  Stream operands (RESID: xin, MUL_AUX / DSILU: the saved factor) are loaded two
+//    accumulator tiles ahead of their use.
+//  * The staging buffers are free as soon as the K loop is done, so the NEXT tile's prologue (14 LDS-DMA pieces per wave: K-tile 0
+//    and three quarters of K-tile 1) is issued BEFORE the epilogue and lands under it: the next K loop starts without a fill.
+//    vmcnt counts LDS-DMA and the epilogue's stores together, in order: the next K loop's first wait is vmcnt(0).
+// Same accumulation order and the same epilogue functors as gemm_mfma256_kernel: results are the same bits.
+struct TileCoord { int m0, n0, z, tile, kbeg, nk; };
+__device__ __forceinline__ TileCoord tile_coord(const GemmP& p, const int bid, const int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    TileCoord c;
+    c.z = wg / p.tiles;
+    c.tile = wg - c.z * p.tiles;
+    const int tiles_m = p.tiles / p.tiles_n;
+    const int bsz = tiles_m * p.band;
+    const int bidx = c.tile / bsz, rem = c.tile - bidx * bsz;
+    const int bw = (bidx + 1) * p.band <= p.tiles_n ? p.band : p.tiles_n - bidx * p.band;   // last band may be narrower
+    c.m0 = (rem / bw) * BM2;
+    c.n0 = (bidx * p.band + rem % bw) * BN2;
+    const int nkt = (p.K + BKT - 1) / BKT, kbase = nkt / p.split_k, krem = nkt % p.split_k;
+    c.kbeg = (c.z * kbase + (c.z < krem ? c.z : krem)) * BKT;
+    c.nk = kbase + (c.z < krem ? 1 : 0);
+    return c;
+}
+
+constexpr int WPRIV_BYTES = 4096;                          // per-wave epilogue bounce: 16 rows x 64 fp32
+constexpr int SMEM_W_BYTES = 2 * KBUF_BYTES + 8 * WPRIV_BYTES;   // 163,840 B: all of the CU's LDS
+
+// prologue of a tile's K loop, in steady-state issue order: A0 B0 B1 A1 of K-tile 0, then A0 B0 B1 of K-tile 1
+template <int AK, int BK, bool KTAIL>
+__device__ __forceinline__ void g256_prologue(const GemmP& p, const TileCoord& c, char* smem, int wave, int lane) {
+    stage_half<AK, 0, KTAIL>(p.A, p.lda, c.m0, p.M, c.kbeg, p.K, 0, smem + OFF_A0, wave, lane);
+    stage_half<BK, 1, KTAIL>(p.B, p.ldb, c.n0, p.N, c.kbeg, p.K, 0, smem + OFF_B0, wave, lane);
+    stage_half<BK, 1, KTAIL>(p.B, p.ldb, c.n0, p.N, c.kbeg, p.K, 1, smem + OFF_B1, wave, lane);
+    stage_half<AK, 0, KTAIL>(p.A, p.lda, c.m0, p.M, c.kbeg, p.K, 1, smem + OFF_A1, wave, lane);
+    if (c.nk > 1) {
+        char* b1 = smem + KBUF_BYTES;
+        stage_half<AK, 0, KTAIL>(p.A, p.lda, c.m0, p.M, c.kbeg + BKT, p.K, 0, b1 + OFF_A0, wave, lane);
+        stage_half<BK, 1, KTAIL>(p.B, p.ldb, c.n0, p.N, c.kbeg + BKT, p.K, 0, b1 + OFF_B0, wave, lane);
+        stage_half<BK, 1, KTAIL>(p.B, p.ldb, c.n0, p.N, c.kbeg + BKT, p.K, 1, b1 + OFF_B1, wave, lane);
+    }
+}
+
+#ifndef MAPDIT_EPI_PREFETCH
+#define MAPDIT_EPI_PREFETCH 2          // accumulator tiles between the load of an epilogue's stream operand and its use
+#endif
+template <class Epi>
+__device__ __forceinline__ void g256w_epilogue(const GemmP& p, const Epi& epi, const TileCoord& c, f32x4_t (&acc)[8][4],
+                                               char* priv, const int wave, const int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int cch = lane & 7, rsub = lane >> 3;              // column chunk of the wave's 64 columns; row within an 8-row group
+    const int wrow = lane & 15, wq = lane >> 4;              // accumulator layout: row of the 16-row tile, 4-column group
+    const int gn = c.n0 + wn * 64 + cch * 8;
+    const bool col_ok = gn < p.N;
+    typename Epi::Tile tctx;
+    if (col_ok) tctx = epi.tile_begin(c.m0, (c.m0 + BM2 <= p.M ? c.m0 + BM2 : p.M) - 1, gn);
+    f32x4_t* b = (f32x4_t*)priv;
+    constexpr int PD = MAPDIT_EPI_PREFETCH;
+    typename Epi::Aux aux[8][2];
+    const int mw = c.m0 + wm * 128 + rsub;
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int gm = mw + (r >> 2) * 64 + (r & 3) * 16 + 8 * s;
+            if (gm < p.M && col_ok) aux[r][s] = epi.load(gm, gn);
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r + PD < 8) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int gm = mw + ((r + PD) >> 2) * 64 + ((r + PD) & 3) * 16 + 8 * s;
+                if (gm < p.M && col_ok) aux[r + PD][s] = epi.load(gm, gn);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[wrow * 16 + ((4 * j + wq) ^ (wrow & 7))] = acc[r][j];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = rsub + 8 * s;
+            const int gm = mw + (r >> 2) * 64 + (r & 3) * 16 + 8 * s;
+            float v[8];
+            *(f32x4_t*)(v) = b[rr * 16 + ((2 * cch) ^ (rr & 7))];
+            *(f32x4_t*)(v + 4) = b[rr * 16 + ((2 * cch + 1) ^ (rr & 7))];
+            if (gm < p.M && col_ok) epi.apply(gm, gn, v, c.z, aux[r][s], tctx);
+        }
+    }
+}
+
+template <int AK, int BK, class Epi, bool KTAIL = false>
+__global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_W_BYTES];
+    const int total = p.tiles * p.split_k;
+    int v = blockIdx.x;
+    if (v >= total) return;
+    constexpr bool TR_ASM2 = AK == OP_KMAJ;                // transposing reads: asm for TN; NN keeps the builtin (see read_frag)
+    TileCoord c = tile_coord(p, v, total);
+    {
+        const int tid0 = threadIdx.x;
+        g256_prologue<AK, BK, KTAIL>(p, c, smem, __builtin_amdgcn_readfirstlane(tid0 >> 6), tid0 & 63);
+    }
+    bool first = true;
+    for (;;) {
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));                     // per tile: nothing derived from the thread index is kept across tiles
+        const int tid = tid_, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 2, wn = wave & 3;           // wm doubles as the stagger group (waves 4-7 run behind)
+        const int m0 = c.m0, n0 = c.n0, kbeg = c.kbeg, nk = c.nk;
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];           // B half 0 stays in registers for both phases
+        auto load_a = [&](const char* slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK, TR_ASM2>(slot, wm * 64 + i * 16, ks, lane);
+        };
+        // the first tile's prologue was issued just above: A0, B0, B1 of K-tile 0 have landed once the 8 youngest pieces are all
+        // that is in flight.  Later tiles: their prologue went out before the previous epilogue, whose stores sit behind it in the
+        // same in-order counter - wait for everything (the stores were issued all along the epilogue; only the last are pending).
+        if (first && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 1) {                                     // stagger: the second wave group runs one interval behind
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nk; ++t) {
+            char* cur = smem + (t & 1) * KBUF_BYTES;
+            char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
+            const int k1 = kbeg + (t + 1) * BKT, k2 = kbeg + (t + 2) * BKT;
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            load_a(cur + OFF_A0);
+            G256_LOAD_B(fb0, cur + OFF_B0);
+            G256_LOAD_B(fb1, cur + OFF_B1);
+            if (has1) {
+                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k1, p.K, 1, nxt + OFF_A1, wave, lane);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_END_LOAD();
+            G256_MFMA(0, 0, fb0);
+            G256_MFMA(0, 1, fb1);
+            G256_END_MFMA();
+            load_a(cur + OFF_A1);
+            if (has2) {
+                stage_half<AK, 0, KTAIL>(p.A, p.lda, m0, p.M, k2, p.K, 0, cur + OFF_A0, wave, lane);
+                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 0, cur + OFF_B0, wave, lane);
+                stage_half<BK, 1, KTAIL>(p.B, p.ldb, n0, p.N, k2, p.K, 1, cur + OFF_B1, wave, lane);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (has1) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G256_END_LOAD();
+            G256_MFMA(1, 1, fb1);
+            G256_MFMA(1, 0, fb0);
+            G256_END_MFMA();
+        }
+        if (wm == 0) {                                     // rebalance the barrier count of the two groups
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // Every fragment read of this tile was drained (lgkmcnt(0)) before the last LOAD interval's barrier, and both wave groups
+        // have passed the barriers above: the staging buffers are free for the next tile's first K-tiles.
+        const int vn = v + (int)gridDim.x;
+        TileCoord cn = c;
+        if (vn < total) {
+            cn = tile_coord(p, vn, total);
+            g256_prologue<AK, BK, KTAIL>(p, cn, smem, wave, lane);
+        }
+        g256w_epilogue<Epi>(p, epi, c, acc, smem + 2 * KBUF_BYTES + wave * WPRIV_BYTES, wave, lane);
+        if (vn >= total) break;
+        v = vn;
+        c = cn;
+        first = false;
+    }
+}
+
 // ---- the one-wave-per-SIMD kernel: 256x256x64 tile, 4 waves (2 M x 2 N), 128x128 per wave ----------------------------
 // MEASURED AND REJECTED (round 3, profiles/r03_gemm_w4_experiment.log): bit-correct on all layouts, 7-10 % SLOWER than the 8-wave
 // kernel on every shape of the block (NN K = 3072: 1,174 vs 1,268 TFLOP/s; NT K = 768: 967 vs 1,077).  The ablation builds say why:
@@ -1641,7 +1838,7 @@ extern "C" void mapdit_debug_set_stamps_block(long long* p, int block) {      //
 // (One instance in the library: the bf16 build of this file owns it, the fp16 build refers to it.)
 struct GemmEnv {
     int tile = 0;        // MAPDIT_GEMM_TILE   = 128 | 256: force the tile edge
-    int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule
+    int phases = 2;      // MAPDIT_GEMM_PHASES = 4: the quadrant-per-phase schedule; 7: the round-3 kernel (shared-image epilogue, no prefetch across tiles)
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
     int old_tile_rule = 0;   // MAPDIT_GEMM_TILE_RULE=old
     int persist = 256;       // MAPDIT_GEMM_PERSIST = workgroups of the persistent 256^2 launch (0: one workgroup per tile)
@@ -1649,7 +1846,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -1665,7 +1862,7 @@ GemmEnv& mapdit_gemm_env_ref() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : phases == 7 ? 7 : 2;
     e.band = band;
 }
 
@@ -1757,6 +1954,22 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
 #endif
         using T2 = std::integral_constant<int, 2>;
         bool done = false;
+        if constexpr (!kReduce<Epi>) {
+            // default: the round-4 kernel (wave-private epilogue, next tile's prologue under it); phases = 7 or 4 select the older one
+            if (p.phases == 2) {
+                auto gow = [&](auto tail) {
+                    constexpr bool TAIL = decltype(tail)::value;
+                    if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_ROW, OP_ROW, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                    else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_ROW, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                    else hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_KMAJ, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                };
+                if constexpr (kHasTail<Epi>) {
+                    if (ktail) { gow(std::true_type()); done = true; }
+                }
+                if (!done) { gow(std::false_type()); done = true; }
+            }
+        }
+        if (p.phases == 7) p.phases = 2;
 #ifdef MAPDIT_GEMM_EXPERIMENTS
         if constexpr (!kReduce<Epi>) {
             if (p.phases == 5 && !ktail) {                 // the 4-wave kernel (one wave per SIMD): a rejected experiment, see its comment
@@ -1768,7 +1981,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         }
 #endif
         if constexpr (kHasTail<Epi>) {
-            if (ktail) {
+            if (ktail && !done) {
 #ifdef MAPDIT_GEMM_EXPERIMENTS
                 if (p.phases == 1) go(std::true_type(), T1()); else if (p.phases == 3) go(std::true_type(), T3()); else
 #endif
@@ -1822,7 +2035,7 @@ void mapdit_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mapdit_last_error(void) { return g_err; }
-extern "C" int mapdit_abi_version(void) { return 3; }
+extern "C" int mapdit_abi_version(void) { return 4; }
 #endif
 
 extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
@@ -1874,6 +2087,7 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             MD_CHECK(a->x && a->shift && a->scale && a->gain && a->dshift && a->dscale && a->dgain_part && (a->dx || a->dx_bf),
                      "gemm: RMB needs x, shift, scale, gain, dshift, dscale, dgain_part and dx or dx_bf");
             MD_CHECK(!a->y_up || (a->g_up && a->dy_up && a->dg_up), "gemm: RMB residual backward needs g_up, dy_up, dg_up");
+            MD_CHECK(!a->rot, "gemm: the RMB epilogue computes the AdaLN form only (rot != 0: use mapdit_resid_mod_bwd after a plain dX GEMM)");
             // a sample's rows must lie inside ONE 256-row tile: the per-sample column sums are stored once per tile (T = 192, 512, ...
             // would have two tiles overwrite each other's partial sums)
             MD_CHECK(a->T > 0 && a->T % 64 == 0 && 256 % a->T == 0 && M % a->T == 0 && N == a->D,

@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
                                                      float* __restrict__ m, float* __restrict__ v,
                                                      float* __restrict__ e1, float* __restrict__ e2, long n,
                                                      const float* __restrict__ hp, mapdit_adam_scalars_t hs, float b1,
-                                                     float b2, float eps) {
+                                                     float b2, float eps, const int* __restrict__ status = nullptr, int step = 0) {
+    // non-finite gradient guard: the check kernel recorded this step as bad - leave parameters, moments and EMA copies alone
+    if (status && status[0] == step) return;
     // hyper-parameters of the step: by value (kernel arguments, nothing crosses PCIe) or, for a caller that replays one captured
     // launch with changing values, from a 5-float device buffer
     const float step_size = hp ? hp[0] : hs.step_size, inv_sqrt_bc2 = hp ? hp[1] : hs.inv_sqrt_bc2, eb1 = hp ? hp[2] : hs.ema_beta_a,
@@ -233,6 +235,23 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
             E.x += eb2 * (pp[0] - E.x); E.y += eb2 * (pp[1] - E.y); E.z += eb2 * (pp[2] - E.z); E.w += eb2 * (pp[3] - E.w);
             *(float4*)(e2 + i) = E;
         }
+    }
+}
+
+// Non-finite gradient guard (fp16 engine): any inf / NaN among the n gradients records `step` in status[0]; the first thread to do
+// so for this step also counts it in status[1].  Atomics run in the overflow case only (a finite step issues none).
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, long n, int* __restrict__ status, int step) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    bool bad = false;
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *(const float4*)(g + i);
+        // x - x is 0 for every finite x and NaN for inf / NaN
+        const float d = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad |= !(d == 0.f);
+    }
+    if (bad) {
+        if (atomicExch(&status[0], step) != step) atomicAdd(&status[1], 1);
     }
 }
 
@@ -281,7 +300,7 @@ extern "C" int mapdit_adam_ema_step(float* params, const float* grads, float* ex
     const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
     mapdit_adam_scalars_t none = {0.f, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, ema_a, ema_b, n, hyper, none, beta1, beta2, eps);
+                       exp_avg_sq, ema_a, ema_b, n, hyper, none, beta1, beta2, eps, (const int*)nullptr, 0);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
@@ -295,7 +314,29 @@ extern "C" int mapdit_adam_ema_step_scalars(float* params, const float* grads, f
     MD_CHECK(n % 4 == 0, "adam_ema_step_scalars: n=%ld must be a multiple of 4 (pad the flat buffer)", n);
     const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, ema_a, ema_b, n, (const float*)nullptr, *hyper, beta1, beta2, eps);
+                       exp_avg_sq, ema_a, ema_b, n, (const float*)nullptr, *hyper, beta1, beta2, eps, (const int*)nullptr, 0);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_adam_ema_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a,
+                                            float* ema_b, long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2,
+                                            float eps, const int* status, int step, void* stream) {
+    MD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && n > 0, "adam_ema_step_guarded: null/empty argument");
+    MD_CHECK(n % 4 == 0, "adam_ema_step_guarded: n=%ld must be a multiple of 4 (pad the flat buffer)", n);
+    MD_CHECK(status && step > 0, "adam_ema_step_guarded: needs the status words and a step number > 0");
+    const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, ema_a, ema_b, n, (const float*)nullptr, *hyper, beta1, beta2, eps, status, step);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_grad_nonfinite_check(const float* grads, long n, int* status, int step, void* stream) {
+    MD_CHECK(grads && status && n > 0 && step > 0, "grad_nonfinite_check: null/empty argument (step must be > 0)");
+    MD_CHECK(n % 4 == 0 && ((uintptr_t)grads & 15) == 0, "grad_nonfinite_check: n=%ld must be a multiple of 4 and the buffer 16-byte aligned", n);
+    const int grid = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grads, n, status, step);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

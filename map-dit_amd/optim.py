@@ -44,7 +44,7 @@ class FusedAdamEMA:
     """Adam + LR schedule + two EMA copies over the model's flat parameter / gradient buffers (one kernel launch)."""
 
     def __init__(self, model, lr: float = 1e-2, betas=(0.9, 0.99), eps: float = 1e-8, ema_stds=(0.05, 0.1),
-                 lr_lambda=None, grad_scale: float = 1.0):
+                 lr_lambda=None, grad_scale: float = 1.0, nonfinite_guard=None):
         assert len(ema_stds) in (0, 2), "the fused kernel carries exactly two EMA copies (or none)"
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -64,6 +64,15 @@ class FusedAdamEMA:
         # copies - each rank keeps them current for its own range only (16 of the kernel's 44 bytes per parameter) and the ranges
         # are gathered when a snapshot or checkpoint needs them (parallel.OverlappedGradReducer.attach / gather_state).
         self.ema_ranges = None                       # [(lo, hi), ...] ascending: update the EMA copies only there; None = everywhere
+        # Non-finite gradient guard (mapdit.h, mapdit_grad_nonfinite_check): the reference trains in fp32 (train.py:222-223) and
+        # cannot overflow; the fp16 engine's activation gradients can (static loss scale).  With the guard a step whose gradients
+        # hold an inf / NaN is REFUSED ON THE DEVICE - parameters, moments and EMA copies stay untouched - without a read-back in
+        # the loop; poll_overflow() (logging cadence) reports refused steps and halves the model's loss scale.
+        # None = on while the model computes in "f16", off otherwise; True / False force it.
+        self.nonfinite_guard = nonfinite_guard
+        self._status = torch.zeros(2, dtype=torch.int32, device=flat.device)     # {last bad step, number of bad steps}
+        self._overflows_seen = 0
+        self.status_sync = None                      # ZeRO-1: all-reduce(MAX) of the status words so that every rank refuses together
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
@@ -86,6 +95,16 @@ class FusedAdamEMA:
         betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
         # the per-step values travel as kernel arguments: nothing is uploaded in the training loop
         hyper = L.AdamScalars(lr / (1 - b1 ** t), 1.0 / math.sqrt(1 - b2 ** t), betas[0], betas[1], self.grad_scale)
+        guard = self.nonfinite_guard
+        if guard is None:
+            guard = getattr(m, "gemm_precision", "bf16") == "f16"
+        if guard:
+            with torch.cuda.device(m._pflat.device):
+                for lo, hi in self.shards:
+                    if hi > lo:
+                        L.lib().grad_nonfinite_check(m._gflat.data_ptr() + lo * 4, hi - lo, self._status.data_ptr(), t, L.cur_stream())
+            if self.status_sync is not None:
+                self.status_sync(self._status)
         segs = []                                    # (lo, hi, with_ema)
         for lo, hi in self.shards:                   # the whole flat buffer unless a ZeRO-1 reducer handed over its partition
             if self.ema_ranges is None or not self.ema:
@@ -105,14 +124,33 @@ class FusedAdamEMA:
             off = lo * 4
             ema = self.ema if with_ema else None
             with torch.cuda.device(m._pflat.device):
-                L.lib().adam_ema_step_scalars(m._pflat.data_ptr() + off, m._gflat.data_ptr() + off, self.exp_avg.data_ptr() + off,
-                                              self.exp_avg_sq.data_ptr() + off,
-                                              ema[0].data_ptr() + off if ema else None,
-                                              ema[1].data_ptr() + off if ema else None,
-                                              hi - lo, C.byref(hyper), b1, b2, self.eps, L.cur_stream())
+                args = (m._pflat.data_ptr() + off, m._gflat.data_ptr() + off, self.exp_avg.data_ptr() + off,
+                        self.exp_avg_sq.data_ptr() + off, ema[0].data_ptr() + off if ema else None,
+                        ema[1].data_ptr() + off if ema else None, hi - lo, C.byref(hyper), b1, b2, self.eps)
+                if guard:
+                    L.lib().adam_ema_step_guarded(*args, self._status.data_ptr(), t, L.cur_stream())
+                else:
+                    L.lib().adam_ema_step_scalars(*args, L.cur_stream())
         if self.after_step is not None:
             self.after_step()                        # ZeRO-1: all-gather of the updated parameter shards
         m.mark_weights_changed()
+
+    # ---- non-finite gradient guard ------------------------------------------------------------------------------
+    def overflow_steps(self) -> int:
+        """Number of optimiser steps the guard has refused so far (synchronises: call at logging cadence)."""
+        return int(self._status[1].item())
+
+    def poll_overflow(self, halve_loss_scale: bool = True) -> int:
+        """Steps refused since the previous poll.  If there were any and `halve_loss_scale`, the model's fp16 loss scale is halved
+        (once per poll) so that the following backward passes stay in range.  Synchronises the stream."""
+        total = self.overflow_steps()
+        new = total - self._overflows_seen
+        self._overflows_seen = total
+        if new > 0 and halve_loss_scale and getattr(self.model, "gemm_precision", "") == "f16":
+            cur = self.model.effective_loss_scale()
+            if cur > 1.0:
+                self.model.loss_scale = cur / 2.0
+        return new
 
     # ---- checkpoint interchange with the reference (train.py:125-132 stores torch.optim.Adam.state_dict()) -------
     def _slots(self):

@@ -216,10 +216,17 @@ def _verify_gather(whole, per, world, mine_before, group):
         dist.all_gather(parts, mine_before.cpu(), group=group)
         pub = torch.stack(parts).to(whole.device)
     got = torch.stack([_range_checksum(whole[r * per:(r + 1) * per]) for r in range(world)])
-    if not torch.allclose(got, pub, rtol=1e-12, atol=0.0):
-        bad = [r for r in range(world) if not torch.allclose(got[r], pub[r], rtol=1e-12, atol=0.0)]
-        raise RuntimeError(f"gather_state: ranges of ranks {bad} arrived with a different checksum than their owners computed "
-                           f"(rank {dist.get_rank(group)}): the gathered state is not to be trusted")
+    # The verdict is collective: a corruption seen by one receiver only must stop EVERY rank here - a rank that raised alone would
+    # leave the others waiting in their next collective until the RCCL timeout, with the real error lost.  bad[r] = 1 where this
+    # rank's copy of range r disagrees with its owner's checksum; MAX over ranks.
+    bad = torch.tensor([0.0 if torch.allclose(got[r], pub[r], rtol=1e-12, atol=0.0) else 1.0 for r in range(world)])
+    if dist.get_backend(group) == "nccl" and whole.is_cuda:
+        bad = bad.to(whole.device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if float(bad.max()) > 0:
+        ranges = [r for r in range(world) if float(bad[r]) > 0]
+        raise RuntimeError(f"gather_state: ranges of ranks {ranges} arrived on some rank with a different checksum than their owners "
+                           f"computed (raised on every rank; this is rank {dist.get_rank(group)}): the gathered state is not to be trusted")
 
 
 class _ReducerBase:
@@ -284,6 +291,18 @@ class Zero1Reducer(_ReducerBase):
         if self.world > 1 or self.force_collective:
             opt.shards = self.parts()
             opt.after_step = self._gather_params
+            if self.world > 1:
+                # non-finite guard: a rank checks the gradients of its own parts only - every rank must refuse the step together
+                # (status[0] = last bad step: MAX makes it the current step everywhere if any rank flagged it)
+                opt.status_sync = self._sync_status
+
+    def _sync_status(self, status):
+        if _host_staged(self.group, status):
+            h = status.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            status.copy_(h)
+        else:
+            dist.all_reduce(status, op=dist.ReduceOp.MAX, group=self.group)
 
     def _on_stage(self, stage: int):
         if self.world == 1 and not self.force_collective:

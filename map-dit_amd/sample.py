@@ -28,7 +28,7 @@ def build_parser():
     p.add_argument("--ckpt", type=str, default=None, help="Checkpoint to load instead of EMA (should not include .pt extension).")
     p.add_argument("--vae-path", type=str, default=None, help="local copy of stabilityai/sd-vae-ft-mse (no network here)")
     p.add_argument("--no-graph", action="store_true", help="eager p_sample_loop instead of the captured hipGraph")
-    p.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="bf16")
+    p.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="f16")
     return p
 
 

@@ -192,7 +192,7 @@ class _Runtime:
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
                             mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
                             precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)),
-                            loss_scale=float(getattr(model, "loss_scale", 0.0)) if precision == "f16" else 0.0)
+                            loss_scale=float(getattr(model, "_loss_scale", 0.0)) if precision == "f16" else 0.0)
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
             raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
@@ -309,10 +309,11 @@ class DiT(nn.Module):
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, learn_sigma=learn_sigma)
 
         self._rt = {}                 # {train (bool) | (precision, train): _Runtime}
-        # "bf16" (default) | "f16": the same engine with IEEE fp16 operands - same speed, forward logits within 1e-3 of the fp32
-        # reference (bf16: ~6e-3) | "bf16x3": fp32-accurate forward and backward (several times slower).  See mapdit.h.
-        self.gemm_precision = "bf16"
-        self.loss_scale = 0.0         # "f16" only: static power-of-two loss scale of the backward (0 = chosen from the batch size)
+        # "f16" (default): IEEE fp16 GEMM / attention operands, fp32 accumulation - forward logits within 1e-3 of the fp32 reference
+        # (BASELINE.json's tolerance) | "bf16": the same engine with bf16 operands - 2 % faster, ~6e-3 | "bf16x3": fp32-accurate
+        # forward and backward (several times slower).  See mapdit.h.
+        self.gemm_precision = "f16"
+        self._loss_scale = 0.0        # "f16" only: power-of-two loss scale of the backward (0 = chosen from the batch size)
         self._pflat = None            # flat fp32 storage behind every parameter (views)
         self._gflat = None            # flat gradient buffer, p.grad are views of it
         self._gviews = None
@@ -399,7 +400,7 @@ class DiT(nn.Module):
             raise L.MapditError("MaP-DiT runs on the MI355X only: move the module to a cuda device (there is no CPU path)")
         if self._pflat.dtype != torch.float32:
             raise L.MapditError("master parameters must be fp32 (bf16 / fp16 are the engine's internal GEMM operand types)")
-        precision = getattr(self, "gemm_precision", "bf16")
+        precision = getattr(self, "gemm_precision", "f16")
         if precision not in L.PRECISIONS:
             raise L.MapditError(f"gemm_precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
         slot = train if precision == "bf16" else (precision, train)
@@ -412,10 +413,36 @@ class DiT(nn.Module):
         rt.bind(self)
         return rt
 
+    # "f16" only: the power of two the backward multiplies the incoming gradient by (mapdit_config_t.loss_scale); 0 = chosen per
+    # backward from the batch size.  Assigning it reaches the engines that already exist (mapdit_engine_set_loss_scale).
+    @property
+    def loss_scale(self) -> float:
+        return self._loss_scale
+
+    @loss_scale.setter
+    def loss_scale(self, value):
+        value = float(value)
+        m, e = math.frexp(value) if value > 0 and math.isfinite(value) else (0.0, 0)
+        if not (value == 0.0 or m == 0.5):
+            raise L.MapditError(f"loss_scale must be 0 (automatic) or a finite power of two, got {value!r}")
+        self._loss_scale = value
+        for slot, rt in getattr(self, "_rt", {}).items():
+            if rt.precision == "f16" and rt.train:
+                rt.lib.engine_set_loss_scale(rt.handle, value)
+
+    def effective_loss_scale(self) -> float:
+        """The loss scale the most recent fp16 backward ran with (the automatic choice resolved); 1.0 before any backward."""
+        rt = self._rt.get(("f16", True))
+        if rt is None:
+            return self._loss_scale or 1.0
+        out = C.c_float()
+        rt.lib.engine_loss_scale(rt.handle, C.byref(out))
+        return float(out.value)
+
     def _peek(self, what: str, block: int = 0) -> torch.Tensor:
         """Diagnostics (mapdit_engine_peek): a copy of an intermediate of the last training-mode forward, as a 2-d
         [rows, ld] tensor (fp32 or bf16).  Names: _lib.PEEK_IDS."""
-        precision = getattr(self, "gemm_precision", "bf16")
+        precision = getattr(self, "gemm_precision", "f16")
         rt = self._rt.get(True if precision == "bf16" else (precision, True))
         if rt is None:
             raise L.MapditError("_peek needs a training-mode forward first")
@@ -515,6 +542,7 @@ class DiT(nn.Module):
         for p_new, p_old in zip(new.parameters(), self.parameters()):
             p_new.requires_grad_(p_old.requires_grad)
         new.train(self.training)
+        new.gemm_precision, new._loss_scale = self.gemm_precision, self._loss_scale
         return new
 
     def __getstate__(self):

@@ -87,10 +87,11 @@ def build_parser():
     p.add_argument("--num-lin-warmup", type=int, default=None)
     p.add_argument("--start-decay", type=int, default=None)
     p.add_argument("--ema-snapshot-every", type=int, default=None)
-    p.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="bf16",
-                   help="GEMM operand precision: bf16 (fast path), f16 (the same engine with IEEE fp16 operands: same speed, logits within "
-                        "1e-3 of the fp32 reference; static loss scale) or bf16x3 (fp32-accurate forward and backward, the reference's "
-                        "numerics to ~1e-5, several times slower)")
+    p.add_argument("--precision", choices=["bf16", "f16", "bf16x3"], default="f16",
+                   help="GEMM operand precision: f16 (default: IEEE fp16 operands, logits within 1e-3 of the fp32 reference; power-of-two "
+                        "loss scale, steps with non-finite gradients are refused and the scale halved), bf16 (the same engine with bf16 "
+                        "operands: 2 %% faster, ~6e-3) or bf16x3 (fp32-accurate forward and backward, the reference's numerics to ~1e-5, "
+                        "several times slower)")
     p.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
                    help="data-parallel gradient exchange: per-stage all-reduce overlapped with backward (default), or "
                         "reduce-scatter + sharded optimiser + all-gather")
@@ -191,6 +192,10 @@ def main(argv=None):
         train_steps += 1
         if train_steps % args.log_every == 0:
             model.check_device_errors()          # an out-of-range label / timestep raises here (the reference: IndexError)
+            refused = opt.poll_overflow()        # fp16: steps refused for non-finite gradients since the last log line
+            if refused:
+                log(f"(step={train_steps:07d}) {refused} optimiser step(s) refused: non-finite gradients; fp16 loss scale now "
+                    f"{model.loss_scale or model.effective_loss_scale():g}")
             avg = running / log_steps
             if world > 1:
                 torch.distributed.all_reduce(avg)

@@ -136,6 +136,80 @@ def test_f16_rejects_negative_loss_scale_and_bf16_loss_scale():
     assert lib.engine_workspace_bytes(C.byref(cfg), 1) > 0
 
 
+def test_f16_is_the_default_precision_and_loss_scale_must_be_a_power_of_two():
+    from mapdit_amd import _lib as L
+    from mapdit_amd.src.dit import DiT
+    import ctypes as C
+    m = DiT(depth=1, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
+    assert m.gemm_precision == "f16"
+    with pytest.raises(L.MapditError):
+        m.loss_scale = 1000.0
+    with pytest.raises(L.MapditError):
+        m.loss_scale = float("inf")
+    m.loss_scale = 1024.0
+    cfg = L.Config(depth=2, hidden=128, patch=2, input_size=16, in_channels=4, num_heads=2, mlp_hidden=512, table_rows=11,
+                   max_batch=2, precision=L.PRECISIONS["f16"], loss_scale=1000.0)
+    assert L.lib().engine_workspace_bytes(C.byref(cfg), 1) == 0 and b"power of two" in L.lib().last_error()
+
+
+def test_f16_overflowing_step_is_refused_and_loss_scale_halved():
+    """The non-finite gradient guard (mapdit_grad_nonfinite_check / mapdit_adam_ema_step_guarded): a backward whose incoming
+    gradient overflows fp16 (dout ~ 1e6 times the loss scale) leaves inf / NaN in the parameter gradients; the optimiser step is
+    refused ON THE DEVICE - weights, Adam moments and both EMA copies keep their bits - poll_overflow() reports it and halves the
+    loss scale (which reaches the live engine), and the next ordinary step is applied.  Also: a loss scale assigned after the
+    first backward is honoured (the runtime is not rebuilt)."""
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.optim import FusedAdamEMA
+    g = load_golden("tiny_a")
+    m, cfg, _ = build(g, train=True)
+    x, t, y_eff, noise = dev(g, "x", "t", "y_eff", "noise")
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    opt = FusedAdamEMA(m, lr=1e-2)
+    diff = create_diffusion("")
+
+    def step(blow_up):
+        out = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)["loss"].mean()
+        opt.zero_grad()
+        (out * (1e12 if blow_up else 1.0)).backward()
+        opt.step()
+        torch.cuda.synchronize()
+
+    step(False)                                       # an ordinary step first: moments and EMA copies are non-trivial
+    assert opt.poll_overflow() == 0
+    scale0 = m.effective_loss_scale()
+    assert scale0 > 1.0
+    # forced weight normalisation rewrites the masters in the forward: compare state across the OPTIMISER step only
+    state = lambda: [b.clone() for b in (opt.exp_avg, opt.exp_avg_sq, opt.ema[0], opt.ema[1])]
+    before = state()
+    out = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)["loss"].mean()
+    opt.zero_grad()
+    (out * 1e12).backward()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(m._gflat).all(), "the injected gradient did not overflow: the test does not test the guard"
+    w_before = m._pflat.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m._pflat, w_before), "a refused step must not touch the weights"
+    for a, b in zip(before, state()):
+        assert torch.equal(a, b), "a refused step must not touch Adam moments or EMA copies"
+    assert opt.poll_overflow() == 1
+    assert m.loss_scale == scale0 / 2 and opt.overflow_steps() == 1
+    step(False)                                       # the next ordinary step is applied, on the halved scale
+    assert m.effective_loss_scale() == scale0 / 2
+    assert not torch.equal(m._pflat, w_before) and torch.isfinite(m._pflat).all()
+    assert opt.poll_overflow() == 0 and opt.overflow_steps() == 1
+    for b in state():
+        assert torch.isfinite(b).all()
+    # the guard off (what round 3 shipped): the same overflow poisons the state - shown once so that the test above means something
+    opt2 = FusedAdamEMA(m, lr=1e-2, nonfinite_guard=False)
+    out = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)["loss"].mean()
+    opt2.zero_grad()
+    (out * 1e12).backward()
+    opt2.step()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(opt2.exp_avg).all()
+
+
 @pytest.mark.parametrize("name", ["tiny_a", "s2_n2"])
 def test_f16_forward_stage_by_stage_against_emulating_oracle(name):
     """Every intermediate the fp16 engine keeps (mapdit_engine_peek; fp16 tensors report dtype 2) against the oracle rounding

@@ -33,6 +33,7 @@ def build(g, train=False):
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV)
     m.train(train)
+    m.gemm_precision = "bf16"        # this file's limits are the bf16 engine's (the default engine, "f16", is held to 1e-3 in test_f16_gpu.py)
     return m, cfg, sd
 
 
