@@ -247,10 +247,11 @@ template <int TAG> struct EpiSilu2 {
 };
 // SILU2 with the derivative factor instead of the pre-activation as its first output (one exp and one rcp serve both), and
 // the backward epilogue that goes with it: a plain product, no transcendental in the dX GEMM's epilogue.
-struct EpiSilu2Grad {
+// HAS_D: the derivative factor is written too (training); a template flag so that the per-chunk code has no branch in it
+template <bool HAS_D> struct EpiSilu2GradT {
     bf16_t* dact; bf16_t* act; int ldo;
     EPI_TRIVIAL_STEPS
-    __device__ __forceinline__ int n_direct() const { return dact ? 2 : 1; }
+    __device__ __forceinline__ int n_direct() const { return HAS_D ? 2 : 1; }
     __device__ __forceinline__ bf16_t* dst(int w) const { return w == 0 ? act : dact; }
     __device__ __forceinline__ void pw(const f32x4_t& v, u32x2_t* o, int nout) const {
         float a[4], d[4];
@@ -270,7 +271,7 @@ struct EpiSilu2Grad {
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         typedef __attribute__((ext_vector_type(2))) float f2;
         float a[8], d[8];
-        if (dact) {
+        if constexpr (HAS_D) {
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 const f2 x = {v[i], v[i + 1]};
@@ -1451,49 +1452,89 @@ __device__ __forceinline__ void g256_prologue(const GemmP& p, const TileCoord& c
     }
 }
 
-#ifndef MAPDIT_EPI_PREFETCH
-#define MAPDIT_EPI_PREFETCH 2          // accumulator tiles between the load of an epilogue's stream operand and its use
-#endif
-template <class Epi>
+// Per epilogue: accumulator tiles between the load of its stream operand and the use (kEpiPrefetch), and whether the LDS round trip of
+// tile r+1 is issued ahead of the arithmetic of tile r (kEpiPipeline: a second set of chunk registers).  RESID keeps 24 registers
+// of per-column operands and 8 per chunk of residual stream: both at 2 / true spill (216 bytes of scratch per lane).
+template <class Epi> constexpr bool kWaveEpilogue = true;          // launch(): take the round-4 kernel for this epilogue
+template <class Epi> constexpr bool kWaveEpilogueAnyK = true;      // ... whatever K is (false: only up to K = 1024 per workgroup)
+template <> constexpr bool kWaveEpilogue<EpiResid> = false;
+template <> constexpr bool kWaveEpilogue<EpiStoreF32> = false;
+template <> constexpr bool kWaveEpilogueAnyK<EpiStoreBf16> = false;
+template <class Epi> constexpr int kEpiPrefetch = 2;
+template <class Epi> constexpr bool kEpiPipeline = true;
+template <> constexpr int kEpiPrefetch<EpiResid> = 1;
+template <> constexpr bool kEpiPipeline<EpiResid> = false;
+// INTERIOR: the tile lies inside the result (every hot shape: M, N multiples of 256) - no predicate anywhere, so the whole
+// epilogue is one basic block and the LDS round trip of accumulator tile r+1 is issued before the arithmetic of tile r (LDS
+// operations of one wave execute in order: the reads of tile r are ahead of the writes of tile r+1 in the queue, one 4 KiB buffer
+// serves both).
+template <class Epi, bool INTERIOR>
 __device__ __forceinline__ void g256w_epilogue(const GemmP& p, const Epi& epi, const TileCoord& c, f32x4_t (&acc)[8][4],
                                                char* priv, const int wave, const int lane) {
     const int wm = wave >> 2, wn = wave & 3;
     const int cch = lane & 7, rsub = lane >> 3;              // column chunk of the wave's 64 columns; row within an 8-row group
     const int wrow = lane & 15, wq = lane >> 4;              // accumulator layout: row of the 16-row tile, 4-column group
     const int gn = c.n0 + wn * 64 + cch * 8;
-    const bool col_ok = gn < p.N;
+    const bool col_ok = INTERIOR || gn < p.N;
     typename Epi::Tile tctx;
     if (col_ok) tctx = epi.tile_begin(c.m0, (c.m0 + BM2 <= p.M ? c.m0 + BM2 : p.M) - 1, gn);
     f32x4_t* b = (f32x4_t*)priv;
-    constexpr int PD = MAPDIT_EPI_PREFETCH;
+    constexpr int PD = kEpiPrefetch<Epi>;
+    constexpr bool PIPE = kEpiPipeline<Epi>;
     typename Epi::Aux aux[8][2];
     const int mw = c.m0 + wm * 128 + rsub;
+    auto row_of = [&](int r, int s) { return mw + (r >> 2) * 64 + (r & 3) * 16 + 8 * s; };
+    // LDS addresses of this lane: 4 writes (accumulator layout) and 2 x 2 reads (row chunks), the same for every accumulator tile
+    int woff[4], roff[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = wrow * 16 + ((4 * j + wq) ^ (wrow & 7));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int rr = rsub + 8 * s;
+        roff[s][0] = rr * 16 + ((2 * cch) ^ (rr & 7));
+        roff[s][1] = rr * 16 + ((2 * cch + 1) ^ (rr & 7));
+    }
 #pragma unroll
     for (int r = 0; r < PD; ++r)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int gm = mw + (r >> 2) * 64 + (r & 3) * 16 + 8 * s;
-            if (gm < p.M && col_ok) aux[r][s] = epi.load(gm, gn);
-        }
+        for (int s = 0; s < 2; ++s)
+            if (INTERIOR || (row_of(r, s) < p.M && col_ok)) aux[r][s] = epi.load(row_of(r, s), gn);
+    f32x4_t cur[2][2], nxt[2][2];
+    if (PIPE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[woff[j]] = acc[0][j];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { cur[s][0] = b[roff[s][0]]; cur[s][1] = b[roff[s][1]]; }
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if (r + PD < 8) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int gm = mw + ((r + PD) >> 2) * 64 + ((r + PD) & 3) * 16 + 8 * s;
-                if (gm < p.M && col_ok) aux[r + PD][s] = epi.load(gm, gn);
-            }
+            for (int s = 0; s < 2; ++s)
+                if (INTERIOR || (row_of(r + PD, s) < p.M && col_ok)) aux[r + PD][s] = epi.load(row_of(r + PD, s), gn);
+        }
+        if (PIPE && r + 1 < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[woff[j]] = acc[r + 1][j];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { nxt[s][0] = b[roff[s][0]]; nxt[s][1] = b[roff[s][1]]; }
+        }
+        if (!PIPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[woff[j]] = acc[r][j];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { cur[s][0] = b[roff[s][0]]; cur[s][1] = b[roff[s][1]]; }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[wrow * 16 + ((4 * j + wq) ^ (wrow & 7))] = acc[r][j];
-#pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int rr = rsub + 8 * s;
-            const int gm = mw + (r >> 2) * 64 + (r & 3) * 16 + 8 * s;
             float v[8];
-            *(f32x4_t*)(v) = b[rr * 16 + ((2 * cch) ^ (rr & 7))];
-            *(f32x4_t*)(v + 4) = b[rr * 16 + ((2 * cch + 1) ^ (rr & 7))];
-            if (gm < p.M && col_ok) epi.apply(gm, gn, v, c.z, aux[r][s], tctx);
+            *(f32x4_t*)(v) = cur[s][0];
+            *(f32x4_t*)(v + 4) = cur[s][1];
+            if (INTERIOR || (row_of(r, s) < p.M && col_ok)) epi.apply(row_of(r, s), gn, v, c.z, aux[r][s], tctx);
+        }
+        if (PIPE) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; }
         }
     }
 }
@@ -1511,6 +1552,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
         g256_prologue<AK, BK, KTAIL>(p, c, smem, __builtin_amdgcn_readfirstlane(tid0 >> 6), tid0 & 63);
     }
     bool first = true;
+#ifdef MAPDIT_GEMM_STAMPS
+    // per-workgroup phase sums (waves 0 and 4): cycles in {wait for the prologue + barrier, K loop, issue of the next prologue,
+    // epilogue}, tiles done; written once at the end: g_wg_times[bid][8 * (wave / 4) + 0..4]   (tools/gemm_phases.py)
+    long long ph_[4] = {0, 0, 0, 0};
+    int ph_tiles_ = 0;
+#define GW_STAMP(VAR) __builtin_amdgcn_sched_barrier(0); const long long VAR = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define GW_STAMP(VAR)
+#endif
     for (;;) {
         int tid_ = threadIdx.x;
         asm volatile("" : "+v"(tid_));                     // per tile: nothing derived from the thread index is kept across tiles
@@ -1533,6 +1583,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
         // the first tile's prologue was issued just above: A0, B0, B1 of K-tile 0 have landed once the 8 youngest pieces are all
         // that is in flight.  Later tiles: their prologue went out before the previous epilogue, whose stores sit behind it in the
         // same in-order counter - wait for everything (the stores were issued all along the epilogue; only the last are pending).
+        GW_STAMP(ts0_);
         if (first && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1542,6 +1593,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        GW_STAMP(ts1_);
         for (int t = 0; t < nk; ++t) {
             char* cur = smem + (t & 1) * KBUF_BYTES;
             char* nxt = smem + ((t + 1) & 1) * KBUF_BYTES;
@@ -1582,13 +1634,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
         }
         // Every fragment read of this tile was drained (lgkmcnt(0)) before the last LOAD interval's barrier, and both wave groups
         // have passed the barriers above: the staging buffers are free for the next tile's first K-tiles.
+        GW_STAMP(ts2_);
         const int vn = v + (int)gridDim.x;
         TileCoord cn = c;
         if (vn < total) {
             cn = tile_coord(p, vn, total);
             g256_prologue<AK, BK, KTAIL>(p, cn, smem, wave, lane);
         }
-        g256w_epilogue<Epi>(p, epi, c, acc, smem + 2 * KBUF_BYTES + wave * WPRIV_BYTES, wave, lane);
+        GW_STAMP(ts3_);
+        if (c.m0 + BM2 <= p.M && c.n0 + BN2 <= p.N)
+            g256w_epilogue<Epi, true>(p, epi, c, acc, smem + 2 * KBUF_BYTES + wave * WPRIV_BYTES, wave, lane);
+        else
+            g256w_epilogue<Epi, false>(p, epi, c, acc, smem + 2 * KBUF_BYTES + wave * WPRIV_BYTES, wave, lane);
+#ifdef MAPDIT_GEMM_STAMPS
+        {
+            GW_STAMP(ts4_);
+            ph_[0] += ts1_ - ts0_; ph_[1] += ts2_ - ts1_; ph_[2] += ts3_ - ts2_; ph_[3] += ts4_ - ts3_;
+            ++ph_tiles_;
+            if ((vn >= total) && g_wg_times && (wave & 3) == 0 && lane == 0) {
+                long long* r_ = g_wg_times + 16 * (long long)blockIdx.x + 8 * (wave >> 2);
+                r_[0] = ph_[0]; r_[1] = ph_[1]; r_[2] = ph_[2]; r_[3] = ph_[3]; r_[4] = ph_tiles_;
+            }
+        }
+#endif
         if (vn >= total) break;
         v = vn;
         c = cn;
@@ -1846,7 +1914,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -1862,7 +1930,7 @@ GemmEnv& mapdit_gemm_env_ref() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : phases == 7 ? 7 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : phases == 7 ? 7 : phases == 6 ? 6 : 2;
     e.band = band;
 }
 
@@ -1955,8 +2023,15 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         using T2 = std::integral_constant<int, 2>;
         bool done = false;
         if constexpr (!kReduce<Epi>) {
-            // default: the round-4 kernel (wave-private epilogue, next tile's prologue under it); phases = 7 or 4 select the older one
-            if (p.phases == 2) {
+            // default: the round-4 kernel (wave-private epilogue, next tile's prologue under it) where it measured faster - the
+            // epilogues that are arithmetic (SiLU, per-head normalisation, the saved-factor product): +2 ... +11 % - and the plain bf16
+            // store at short K (fill hidden: +1.5 %).  RESID stays on the shared-image kernel: its 32 bytes per chunk of residual
+            // stream need all 16 chunks of a thread in flight, which only fits in registers once the accumulators are dead (wave-
+            // private: 60 k cycles of epilogue per tile against ~15 k; tools/gemm_phases.py).  phases = 7 or 4 select the older kernel,
+            // 6 forces the round-4 one for every epilogue.
+            const bool use_w = p.phases == 6 || (p.phases == 2 && kWaveEpilogue<Epi> && (kWaveEpilogueAnyK<Epi> || K / split_k <= 1024));
+            if (use_w) {
+                p.phases = 2;
                 auto gow = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
                     if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_ROW, OP_ROW, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
@@ -1969,7 +2044,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
                 if (!done) { gow(std::false_type()); done = true; }
             }
         }
-        if (p.phases == 7) p.phases = 2;
+        if (p.phases == 7 || p.phases == 6) p.phases = 2;
 #ifdef MAPDIT_GEMM_EXPERIMENTS
         if constexpr (!kReduce<Epi>) {
             if (p.phases == 5 && !ktail) {                 // the 4-wave kernel (one wave per SIMD): a rejected experiment, see its comment
@@ -2074,7 +2149,8 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
                                    e->ld2, e->rot2}, st);
         case MAPDIT_EPI_SILU2_GRAD:
             MD_CHECK(e->out2, "gemm: SILU2_GRAD needs out2");
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2Grad{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+            if (e->out) return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<true>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<false>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
         case MAPDIT_EPI_MUL_AUX:
             MD_CHECK(e->aux, "gemm: MUL_AUX needs aux");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiMulAux{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);

@@ -162,16 +162,37 @@ def f16_round(x: Tensor) -> Tensor:
     return x.half().to(x.dtype)
 
 
+class _RoundFwdBwd(torch.autograd.Function):
+    """y = rnd(x) in the forward, dx = rnd(dy * scale) / scale in the backward: a tensor that the engine would STORE in 16 bits in
+    both directions (a residual-stream checkpoint and the gradient that flows back through it, the latter under the loss scale)."""
+
+    @staticmethod
+    def forward(ctx, x, rnd, scale):
+        ctx.rnd, ctx.scale = rnd, scale
+        return rnd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ctx.rnd(dy * ctx.scale) / ctx.scale, None, None
+
+
 class EnginePlan:
     """The bf16 engine's precision plan as a per-site rounding policy: bf16 GEMM / attention operands on the token path, an
     fp32-accurate conditioning path (timestep MLP, modulation linears, MPScale linears: the engine runs those [samples, D]
-    products on two-term split operands).  ``EnginePlan(f16_round)``: the same plan for the fp16 engine."""
+    products on two-term split operands).  ``EnginePlan(f16_round)``: the same plan for the fp16 engine.
+    ``residual16`` (round 4, a measurement: tools/precision_residual16.py): the residual-stream checkpoints X[0..2L] - fp32 in the
+    engine - rounded like the operands, forward and (under ``grad_scale``) backward: site "res"."""
     COND = ("t0", "t2", "mod", "fmod", "scale")
 
-    def __init__(self, rnd=bf16_round):
+    def __init__(self, rnd=bf16_round, residual16: bool = False, grad_scale: float = 1.0):
         self.rnd = rnd
+        self.residual16, self.grad_scale = residual16, grad_scale
 
     def at(self, site: str):
+        if site == "res":
+            if not self.residual16:
+                return _ident
+            return lambda v: _RoundFwdBwd.apply(v, self.rnd, self.grad_scale)
         return _ident if site[:2] in ("x:", "w:") and site[2:] in self.COND else self.rnd
 
 
@@ -183,7 +204,9 @@ def _at(rnd, site: str):
     """A rounding policy may differ per site (tools/precision_rank.py ranks the engine's bf16 roundings with one): an object with
     ``at(site) -> callable``; a plain callable applies everywhere.  Sites: "w:<layer>", "x:<layer>" (GEMM operands; layer in qkv,
     proj, fc1, fc2, mod, t0, t2, flin, fmod, scale), "v", "qk" (the normalised q, k), "p" (exp(logits))."""
-    return rnd.at(site) if hasattr(rnd, "at") else rnd
+    if hasattr(rnd, "at"):
+        return rnd.at(site)
+    return _ident if site == "res" else rnd          # (a plain callable rounds GEMM / attention operands only)
 
 
 _LAYER_OF = {"t_embedder.mlp.net.0": "t0", "t_embedder.mlp.net.2": "t2", "attn.qkv_proj": "qkv", "attn.out_proj": "proj",
@@ -350,6 +373,13 @@ def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None) -> Tens
     return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
 
 
+class _WithFull:
+    """A residual checkpoint as stored (``stored``) together with the unrounded value its producer held (``full``)."""
+
+    def __init__(self, stored, full):
+        self.stored, self.full = stored, full
+
+
 def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
@@ -364,15 +394,21 @@ def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
         mod_a = lambda v: modulate(v, sh_a, sc_a, sd[p + "gain_msa"])
         mod_m = lambda v: modulate(v, sh_m, sc_m, sd[p + "gain_mlp"])
-    xm = mod_a(x)
+    # x: the stored checkpoint (site "res": identity in every shipped plan); x_full: the value the epilogue that produced it still
+    # holds in fp32 - the next branch's modulate is fused into that epilogue and sees the unrounded value
+    x_full = x.full if isinstance(x, _WithFull) else x
+    x = x.stored if isinstance(x, _WithFull) else x
+    xm = mod_a(x_full)
     _rec(trace, p + "xm", _at(rnd, "x:qkv")(xm))
-    x = mp_sum(x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace), RESIDUAL_T)
+    x_full = mp_sum(x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace), RESIDUAL_T)
+    x = _at(rnd, "res")(x_full)
     _rec(trace, p + "xmid", x)
-    xm2 = mod_m(x)
+    xm2 = mod_m(x_full)
     _rec(trace, p + "xm2", _at(rnd, "x:fc1")(xm2))
-    x = mp_sum(x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace), RESIDUAL_T)
+    x_full = mp_sum(x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace), RESIDUAL_T)
+    x = _at(rnd, "res")(x_full)
     _rec(trace, p + "xout", x)
-    return x
+    return _WithFull(x, x_full) if x is not x_full else x
 
 
 def mp_scale(c: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
@@ -426,8 +462,14 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: 
     c = mp_sum(temb, yemb, EMBED_T)
     _rec(trace, "temb", temb); _rec(trace, "c", c)
 
+    h0 = h
+    h = _at(rnd, "res")(h0)
+    if h is not h0:
+        h = _WithFull(h, h0)
     for i in range(cfg.depth):
         h = dit_block(h, c, sd, i, cfg, train, rnd, trace)
+    if isinstance(h, _WithFull):
+        h = h.full                                               # the final modulate is fused into the last block's epilogue too
 
     if cfg.learn_sigma:
         mean, sigma = final_layer(h, c, sd, cfg, train, rnd, trace)

@@ -122,6 +122,9 @@ def b2():
     from mapdit_amd.src.models import DIT_MODELS
     torch.manual_seed(0)
     m = DIT_MODELS["DiT-B/2"](in_channels=4, input_size=32, num_classes=1000).to(DEV)
+    # bf16: fp32's exponent range.  (The tests below back-propagate SUMS of per-sample losses, 256 x the mean the automatic fp16 loss
+    # scale is chosen for: in "f16" that overflows - which is what the optimiser's non-finite guard exists for, test_f16_gpu.py.)
+    m.gemm_precision = "bf16"
     g = torch.Generator(device=DEV).manual_seed(1)
     x = torch.randn(256, 4, 32, 32, device=DEV, generator=g)
     y = torch.randint(0, 1000, (256,), device=DEV, generator=g)

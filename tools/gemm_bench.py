@@ -79,7 +79,7 @@ def main():
         ("fc1  dW  TN split", 2, 4 * D, D, M, dh, 4 * D, x, D, None),
         ("proj dW  TN split", 2, D, D, M, dy, D, x, D, None),
     ]
-    variants = [("128", 128, 4), ("256/2ph", 256, 2)]
+    variants = [("128", 128, 4), ("256/r3", 256, 7), ("256/w", 256, 2)]
     if args.cases:
         cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     print(f"{'case':20s} {'kernel':>8s} {'ms':>8s} {'TFLOP/s':>9s}")

@@ -25,10 +25,12 @@ def main():
     ap.add_argument("--n", type=int, default=128, help="images per batch (the CFG batch is 2n rows)")
     ap.add_argument("--steps", type=int, default=50, help="timed denoise steps (of the 250-step schedule)")
     ap.add_argument("--cfg-scale", type=float, default=1.5)
+    ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000).to(dev).eval().requires_grad_(False)
+    model.gemm_precision = args.precision
     d = create_diffusion("250")
     n = args.n
     z = torch.randn(n, 4, 32, 32, device=dev)
@@ -63,7 +65,7 @@ def main():
     print(json.dumps({"metric": f"p_sample_loop denoise step, {args.model}, cfg {args.cfg_scale}, batch 2x{n}",
                       "ms_per_step_eager": 1e3 * eager, "ms_per_step_hipgraph": 1e3 * graphed,
                       "steps_per_s_hipgraph": 1 / graphed, "images_per_s_250_steps": n / (250 * graphed),
-                      "fwd_tflops_per_s": 2 * n * f_fwd / graphed / 1e12, "dtype": "bf16"}))
+                      "fwd_tflops_per_s": 2 * n * f_fwd / graphed / 1e12, "dtype": args.precision}))
 
 
 if __name__ == "__main__":
