@@ -256,6 +256,12 @@ int mapdit_attn_cos_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* 
  * q, k, then SDPA).  Nothing is kept for a backward pass: inference only.  head_dim 72, T in {64, 128, 256}. */
 int mapdit_attn_cos_fwd_rawqk(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
                               int head_dim, void* stream);
+/* The training form of it (abi 4): q and k are overwritten IN PLACE by their normalised rows and the scales sqrt(head_dim) /
+ * (|row| + 1e-4) are kept in scales [2][B*H][T] (q rows, then k rows) - what mapdit_attn_cos_bwd_fused needs.  With it the head_dim-72
+ * models (DiT-XL) train without a split / normalise pass over the QKV result and without a merge pass over its gradient, like the
+ * head_dim-64 models do through MAPDIT_EPI_QKV_HEADS (reference attention.py:37-47 and its autograd). */
+int mapdit_attn_cos_fwd_rawqk_save(uint16_t* q, uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, float* scales, int B, int T,
+                                   int H, int head_dim, void* stream);
 /* backward; also writes delta [B*H][T] = rowsum(dO * O) */
 int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                         const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
@@ -454,6 +460,8 @@ int mapdit_attn_cos_fwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16
                             int T, int H, int head_dim, void* stream);
 int mapdit_attn_cos_fwd_rawqk_f16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
                                   int head_dim, void* stream);
+int mapdit_attn_cos_fwd_rawqk_save_f16(uint16_t* q, uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, float* scales, int B, int T,
+                                       int H, int head_dim, void* stream);
 int mapdit_attn_cos_bwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                             const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                             int head_dim, void* stream);

@@ -90,6 +90,7 @@ _SIGS = {
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_cos_fwd_rawqk": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_attn_cos_fwd_rawqk_save": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_cos_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
     "mapdit_attn_cos_bwd_fused": [vp] * 9 + [ci, ci, ci, ci, vp],
     "mapdit_qkv_split_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
@@ -128,7 +129,7 @@ _SIGS = {
 }
 # IEEE fp16 operand forms: same signatures (mapdit.h, "16-bit operand format")
 for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rot_modulate_fwd", "qkv_split",
-           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
+           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_fwd_rawqk_save", "attn_cos_bwd", "attn_cos_bwd_fused", "qkv_split_generic", "qkv_merge_bwd_generic",
            "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
     _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]
 for _b, _h in (("gemm_bf16", "gemm_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),

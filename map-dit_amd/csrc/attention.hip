@@ -1080,6 +1080,8 @@ static bool mfma_shape(int T, int head_dim) { return head_dim == 64 && (T == 64 
 int MD_SYM(attn72_fwd)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
 int MD_SYM(attn72_bwd)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
                       uint16_t*, uint16_t*, uint16_t*, int, int, int, void*);
+int MD_SYM(attn72_bwd_fused)(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, const float*, float*,
+                            const float*, uint16_t*, int, int, int, void*);
 static bool mfma72_shape(int T, int head_dim) {
     if (head_dim != 72 || !(T == 64 || T == 128 || T == 256)) return false;
     static const bool enabled = [] { const char* e = getenv("MAPDIT_ATTN72"); return !(e && e[0] == '0'); }();   // read once
@@ -1120,7 +1122,8 @@ extern "C" int MD_SYM(attn_cos_bwd_fused)(const uint16_t* qn, const uint16_t* kn
                                          const uint16_t* O, const float* lse, float* delta, const float* scales,
                                          uint16_t* dqkv, int B, int T, int H, int head_dim, void* stream) {
     MD_CHECK(qn && kn && v && dO && O && lse && delta && scales && dqkv, "attn_cos_bwd_fused: null argument");
-    MD_CHECK(mfma_shape(T, head_dim), "attn_cos_bwd_fused: head_dim=%d, T=%d unsupported (64; 64, 128 or a multiple of 256)", head_dim, T);
+    if (mfma72_shape(T, head_dim)) return MD_SYM(attn72_bwd_fused)(qn, kn, v, dO, O, lse, delta, scales, dqkv, B, T, H, stream);
+    MD_CHECK(mfma_shape(T, head_dim), "attn_cos_bwd_fused: head_dim=%d, T=%d unsupported (64 with 64, 128 or a multiple of 256 tokens; 72 with 64, 128, 256)", head_dim, T);
     const float scale = 0.125f;
     const float* sq = scales;
     const float* sk = scales + (size_t)B * H * T;

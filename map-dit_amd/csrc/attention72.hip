@@ -15,6 +15,9 @@
 MD_NS_OPEN
 
 constexpr int HD = 72, CH = 9;                 // valid columns, 16-byte chunks per row
+// 16-byte staging registers: an ext-vector type, not HIP's uint4 (a struct that hipcc keeps in scratch when an array of it lives
+// across a loop: 176 bytes per lane in the forward kernel and 96 in the dQ pass until round 4)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4v;
 constexpr int KS = 5, DT = 3;                  // k-steps over the head dim (80), 32-column output tiles (96)
 constexpr int RS = 176;                        // row stride of row-major LDS tiles (bytes)
 constexpr int IMG_ROWS = 96;                   // rows a transposed image is read at (72 written)
@@ -55,14 +58,14 @@ __device__ __forceinline__ bf16x8_t frag_global(const bf16_t* __restrict__ row, 
 template <int T, int NTHREADS> struct Staged {
     static constexpr int TOTAL = T * CH;
     static constexpr int N = (TOTAL + NTHREADS - 1) / NTHREADS;
-    uint4 v[N];
+    u32x4v v[N];
     __device__ __forceinline__ void load(const bf16_t* __restrict__ src, long ld, int tid) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const int i = tid + k * NTHREADS;
             if (i < TOTAL) {
                 const int row = i / CH, c = i - row * CH;
-                v[k] = *(const uint4*)(src + (size_t)row * ld + c * 8);
+                v[k] = *(const u32x4v*)(src + (size_t)row * ld + c * 8);
             }
         }
     }
@@ -76,7 +79,7 @@ template <int T, int NTHREADS> struct Staged {
             if (i < TOTAL) {
                 const int row = i / CH, c = i - row * CH;
                 if (rows_tile) {
-                    *(uint4*)(rows_tile + row * RS + c * 16) = v[k];
+                    *(u32x4v*)(rows_tile + row * RS + c * 16) = v[k];
                     if (c == CH - 1) *(uint4*)(rows_tile + row * RS + CH * 16) = make_uint4(0, 0, 0, 0);   // columns 72..79
                 }
                 if (img && row >= row_base && row < row_base + TC) {
@@ -130,6 +133,69 @@ __device__ __forceinline__ void store_wave_tile(char* wbuf, const f32x16_t (&acc
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same exit for a gradient tile g = dL/dx^ of cosine-normalised rows x^ = x s, s = sqrt(72) / (|x| + eps) (as store_wave_tile_jac
+// of attention.hip does for head_dim 64): dx = s g - x^ (g . x^) / (sqrt(72) |x|), |x| = sqrt(72) / s - eps.  The tile is parked in
+// LDS in fp32; lane (r, h) forms the row dot product of row r over its chunks 2 ks + h against the x^ fragments it already holds in
+// registers (xf: the MFMA operand of the pass, lane (r, h) <-> row r, columns 16 ks + 8 h ..), the two halves meet by one shuffle;
+// the finished rows go out as 16-byte chunks through the bf16 buffer of store_wave_tile.  srow = s of row r (lanes r and r + 32).
+constexpr int WJ_LD = 76;                      // floats per parked row
+constexpr int WJ_BYTES = 32 * WJ_LD * 4;       // 9,728 B per wave
+__device__ __forceinline__ void store_wave_tile_jac72(char* wbuf, const f32x16_t (&acc)[DT], bf16_t* gdst, size_t ld,
+                                                      const bf16x8_t (&xf)[KS], float srow, int lane) {
+    const int r = lane & 31, h2 = lane >> 5;
+    float* wf = (float*)wbuf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float* row = wf + acc_row(i, lane) * WJ_LD;
+        row[r] = acc[0][i];
+        row[32 + r] = acc[1][i];
+        if (r < HD - 64) row[64 + r] = acc[2][i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float g[KS][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 2 * ks + h2;
+        if (c < CH) {
+            const f32x4_t a = *(const f32x4_t*)(wf + r * WJ_LD + c * 8), b = *(const f32x4_t*)(wf + r * WJ_LD + c * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[ks][e] = a[e]; g[ks][4 + e] = b[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += g[ks][e] * up16((bf16_t)xf[ks][e]);
+        }
+    }
+    dot += __shfl_xor(dot, 32, 64);
+    const float rt = sqrtf((float)HD);
+    const float n = rt / srow - NORM_EPS;
+    const float cc = dot / (rt * fmaxf(n, 1e-30f));
+    __builtin_amdgcn_wave_barrier();                   // every lane has read its fp32 chunks: the bf16 rows may overwrite them
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 2 * ks + h2;
+        if (c < CH) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = srow * g[ks][e] - up16((bf16_t)xf[ks][e]) * cc;
+            char* dst = wbuf + r * WT_LD + c * 16;
+            *(uint2*)dst = make_uint2(pack16(o[0], o[1]), pack16(o[2], o[3]));
+            *(uint2*)(dst + 8) = make_uint2(pack16(o[4], o[5]), pack16(o[6], o[7]));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int id = lane + 64 * k;
+        if (id < 32 * CH) {
+            const int row = id / CH, c = id - row * CH;
+            const uint2 lo = *(const uint2*)(wbuf + row * WT_LD + c * 16);
+            const uint2 hi = *(const uint2*)(wbuf + row * WT_LD + c * 16 + 8);
+            *(uint4*)(gdst + (size_t)row * ld + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int T> struct Geo {
     static constexpr int NW = T / 32;          // waves = 32-row owner groups; one workgroup per head
     static constexpr int NTH = NW * 64;
@@ -165,10 +231,14 @@ __device__ __forceinline__ bf16x8_t frag_tr_rows2(const char* tile, int d0, int 
 }
 // RAW: q, k arrive unnormalised (MAPDIT_EPI_QKV_HEADS_RAW) and are scaled by sqrt(72) / (|row| + eps) here, as qkv_split72 would have:
 // the query rows in registers (a row's chunks sit in lanes r and r + 32), the key rows by one thread per row once the K tile is in LDS.
-template <int T, bool RAW>
-__global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
+// SAVE (round 4, training): the normalised rows go back IN PLACE over the raw ones (a query row belongs to exactly one wave, a head's
+// key rows to exactly one workgroup) together with their scales s = sqrt(72) / (|row| + eps) [2][B*H][T]: what the backward needs
+// (mapdit_attn_cos_bwd_fused, head_dim 72).  The separate split / normalise pass over a [M, 3D] QKV result is gone in training too.
+template <int T, bool RAW, bool SAVE = false>
+__global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* qn, const bf16_t* kn,
                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
-                                                                float* __restrict__ lse, int H, float scale) {
+                                                                float* __restrict__ lse, int H, float scale, float* __restrict__ sq_out = nullptr,
+                                                                float* __restrict__ sk_out = nullptr) {
     using G = Geo<T>;
     constexpr int TILE = T * RS2 + 64;                 // (+ 64: the reads past the last row stay inside the array)
     constexpr int SM = 2 * TILE;
@@ -181,9 +251,9 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
     const int q0 = wave * 32;
     // the head's K and V are contiguous [T][72] blocks: chunk i of the block goes to byte 16 i of its tile
     constexpr int CHUNKS = T * CH, PER = (CHUNKS + G::NTH - 1) / G::NTH;
-    uint4 kc[PER], vc[PER];
-    const uint4* ksrc = (const uint4*)(kn + bh * T * HD);
-    const uint4* vsrc = (const uint4*)(v + bh * T * HD);
+    u32x4v kc[PER], vc[PER];
+    const u32x4v* ksrc = (const u32x4v*)(kn + bh * T * HD);
+    const u32x4v* vsrc = (const u32x4v*)(v + bh * T * HD);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = tid + k * G::NTH;
@@ -204,22 +274,29 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) qf[ks][e] = (short)cvt16(up16((bf16_t)qf[ks][e]) * sc);
+        if (SAVE) {
+            bf16_t* qrow = const_cast<bf16_t*>(qn) + (bh * T + q0 + r) * HD;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (16 * ks + 8 * h2 < HD) *(bf16x8_t*)(qrow + 16 * ks + 8 * h2) = qf[ks];
+            if (h2 == 0) sq_out[bh * T + q0 + r] = sc;
+        }
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = tid + k * G::NTH;
-        if (i < CHUNKS) { *(uint4*)(ks_ + i * 16) = kc[k]; *(uint4*)(vs_ + i * 16) = vc[k]; }
+        if (i < CHUNKS) { *(u32x4v*)(ks_ + i * 16) = kc[k]; *(u32x4v*)(vs_ + i * 16) = vc[k]; }
     }
     if (tid < 4) { *(uint4*)(ks_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); *(uint4*)(vs_ + T * RS2 + tid * 16) = make_uint4(0, 0, 0, 0); }
     __syncthreads();
     if (RAW) {
         if (tid < T) {                                     // one key row per thread (rows 36 dwords apart: conflict-free 16-byte accesses)
             char* row = ks_ + tid * RS2;
-            uint4 c9[CH];
+            u32x4v c9[CH];
             float ss = 0.f;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                c9[c] = *(const uint4*)(row + c * 16);
+                c9[c] = *(const u32x4v*)(row + c * 16);
                 const uint32_t w[4] = {c9[c].x, c9[c].y, c9[c].z, c9[c].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float a = lo16(w[e]), b2 = hi16(w[e]); ss += a * a + b2 * b2; }
@@ -227,13 +304,22 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* _
             const float sc = sqrtf((float)HD) / (sqrtf(ss) + NORM_EPS);
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                uint4 u = c9[c];
+                u32x4v u = c9[c];
                 u.x = pack16(lo16(u.x) * sc, hi16(u.x) * sc); u.y = pack16(lo16(u.y) * sc, hi16(u.y) * sc);
                 u.z = pack16(lo16(u.z) * sc, hi16(u.z) * sc); u.w = pack16(lo16(u.w) * sc, hi16(u.w) * sc);
-                *(uint4*)(row + c * 16) = u;
+                *(u32x4v*)(row + c * 16) = u;
             }
+            if (SAVE) sk_out[bh * T + tid] = sc;
         }
         __syncthreads();
+        if (SAVE) {                                        // the normalised key rows, chunk i of the tile to chunk i of the head's block
+            uint4* kdst = (uint4*)(const_cast<bf16_t*>(kn) + bh * T * HD);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = tid + k * G::NTH;
+                if (i < CHUNKS) kdst[i] = *(const uint4*)(ks_ + i * 16);
+            }
+        }
     }
 
     f32x16_t oa[DT] = {};
@@ -271,9 +357,12 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t
                                                                    const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                    const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                                    float* __restrict__ delta, bf16_t* __restrict__ dqn, int H,
-                                                                   float scale) {
+                                                                   float scale, const float* __restrict__ sq = nullptr,
+                                                                   bf16_t* __restrict__ dqkv = nullptr) {
+    // dqkv != nullptr (round 4): the q section of dqkv [B*T][3 H*72] with the normalisation Jacobian applied - no dqn tensor, no merge pass
     using G = Geo<T>;
     constexpr int SM = 2 * T * RS + IMG_ROWS * G::VLD;
+    static_assert(SM >= G::NW * WJ_BYTES, "LDS: the parked fp32 tiles of the Jacobian exit");
     __shared__ __attribute__((aligned(16))) char smem[SM > G::NW * WT_BYTES ? SM : G::NW * WT_BYTES];
     char* ks_ = smem;
     char* vs_ = smem + T * RS;
@@ -331,7 +420,12 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dq_kernel(const bf16_t
 #pragma unroll
     for (int i = 0; i < 16; ++i) one[i] = 1.f;
     __syncthreads();                                   // every wave is done with the K / V images: reuse them as store buffers
-    store_wave_tile(smem + wave * WT_BYTES, dq, one, dqn + (bh * T + q0) * HD, HD, lane);
+    if (dqkv) {
+        const float s_row = sq[bh * T + q0 + r];
+        store_wave_tile_jac72(smem + wave * WJ_BYTES, dq, dqkv + ((size_t)b * T + q0) * (3 * D) + hh * HD, 3 * D, qf, s_row, lane);
+    } else {
+        store_wave_tile(smem + wave * WT_BYTES, dq, one, dqn + (bh * T + q0) * HD, HD, lane);
+    }
 }
 
 // ---- backward, pass B: dK^, dV (wave owns 32 keys) ---------------------------------------------------------------
@@ -340,9 +434,11 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dkv_kernel(const bf16_
                                                                     const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                                     bf16_t* __restrict__ dkn, bf16_t* __restrict__ dv, int H,
-                                                                    float scale) {
+                                                                    float scale, const float* __restrict__ sk = nullptr,
+                                                                    bf16_t* __restrict__ dqkv = nullptr) {
     using G = Geo<T>;
     constexpr int IMG = IMG_ROWS * G::VLDH;
+    static_assert(2 * T * RS + 2 * IMG >= G::NW * WJ_BYTES, "LDS: the parked fp32 tiles of the Jacobian exit");
     __shared__ __attribute__((aligned(16))) char smem[2 * T * RS + 2 * IMG + 2 * T * 4];
     char* qs_ = smem;
     char* dos_ = smem + T * RS;
@@ -409,6 +505,13 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_bwd_dkv_kernel(const bf16_
 #pragma unroll
     for (int i = 0; i < 16; ++i) one[i] = 1.f;
     __syncthreads();                                   // Q / dO tiles are dead: reuse them as store buffers
+    if (dqkv) {                                        // k section with the Jacobian of k^, v section as is: [B*T][3 H*72]
+        const float s_row = sk[bh * T + k0 + r];
+        bf16_t* dst = dqkv + ((size_t)b * T + k0) * (3 * D) + D + hh * HD;
+        store_wave_tile_jac72(smem + wave * WJ_BYTES, dk, dst, 3 * D, kf, s_row, lane);
+        store_wave_tile(smem + wave * WJ_BYTES, dvv, one, dst + D, 3 * D, lane);
+        return;
+    }
     char* wbuf = smem + wave * WT_BYTES;
     store_wave_tile(wbuf, dk, one, dkn + (bh * T + k0) * HD, HD, lane);
     store_wave_tile(wbuf, dvv, one, dv + (bh * T + k0) * HD, HD, lane);
@@ -555,6 +658,37 @@ extern "C" int MD_SYM(attn_cos_fwd_rawqk)(const uint16_t* q, const uint16_t* k, 
     const float scale = 1.f / sqrtf((float)HD);
     hipStream_t st = (hipStream_t)stream;
     ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, true>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, q, k, v, o, lse, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+// Training forward on raw head-major q, k (MAPDIT_EPI_QKV_HEADS_RAW): normalises them in place and keeps the scales [2][B*H][T].
+extern "C" int MD_SYM(attn_cos_fwd_rawqk_save)(uint16_t* q, uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, float* scales, int B,
+                                              int T, int H, int head_dim, void* stream) {
+    MD_CHECK(q && k && v && o && lse && scales && B > 0 && H > 0, "attn_cos_fwd_rawqk_save: null/empty argument");
+    MD_CHECK(head_dim == HD, "attn_cos_fwd_rawqk_save: head_dim=%d unsupported (72)", head_dim);
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    float* sq = scales;
+    float* sk = scales + (size_t)B * H * T;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, true, true>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, q, k, v, o, lse, H, scale,
+                                          sq, sk));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+// The two backward passes with the normalisation Jacobian and the head merge inside: dqkv [B*T][3 H*72] (mapdit_attn_cos_bwd_fused).
+int MD_SYM(attn72_bwd_fused)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
+                            const float* lse, float* delta, const float* scales, uint16_t* dqkv, int B, int T, int H, void* stream) {
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    const float* sq = scales;
+    const float* sk = scales + (size_t)B * H * T;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_bwd_dq_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, dO, O, lse,
+                                          delta, (bf16_t*)nullptr, H, scale, sq, dqkv));
+    MD_LAUNCH_CHECK();
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_bwd_dkv_kernel<TT>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, dO, lse,
+                                          delta, (bf16_t*)nullptr, (bf16_t*)nullptr, H, scale, sk, dqkv));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -57,6 +57,11 @@ struct mapdit_engine {
     float *rotA = nullptr, *rotB = nullptr, *rot_dA = nullptr, *rot_dB = nullptr, *zero_gain = nullptr;
     int ldc = 0;                          // = L*2*D
     bool generic_attn = false;
+    // head_dim 72 with 64 / 128 / 256 tokens (the DiT-XL family): q, k, v leave the QKV GEMM head-major and unnormalised and the
+    // attention kernels normalise them while staging (inference: mapdit_attn_cos_fwd_rawqk; training: ..._save keeps the normalised
+    // rows and their scales, and mapdit_attn_cos_bwd_fused applies the Jacobian and writes dqkv).  MAPDIT_ATTN72=0 / MAPDIT_ATTN72_RAW=0
+    // fall back to the split / merge kernels around the attention (A/B runs).
+    bool raw72 = false;
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
     float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
     int last_N = 0;
@@ -173,7 +178,7 @@ size_t carve(mapdit_engine* e, void* base) {
         BlockBufs& b = e->blk[i];
         b.xm = cv.take<bf16_t>(M * D);
         b.qkv = e->generic_attn ? cv.take<bf16_t>(M * 3 * D) : nullptr;      // the fused QKV epilogue never writes qkv
-        b.qks = e->generic_attn ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
+        b.qks = (e->generic_attn && !e->raw72) ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
         b.qn = cv.take<bf16_t>(M * D);
         b.kn = cv.take<bf16_t>(M * D);
         b.v = cv.take<bf16_t>(M * D);
@@ -351,6 +356,12 @@ void init_dims(mapdit_engine* e) {
     // MFMA attention kernels: head_dim 64 and 64/128/256 tokens; everything else (XL: 72, patch-8: 16 tokens) takes the
     // generic fp32 path of attention_generic.hip
     e->generic_attn = !(e->hd == 64 && (e->T == 64 || e->T == 128 || (e->T >= 256 && e->T % 256 == 0)));
+    {
+        const char* a = getenv("MAPDIT_ATTN72");
+        const char* r = getenv("MAPDIT_ATTN72_RAW");
+        e->raw72 = !(a && a[0] == '0') && !(r && r[0] == '0') && e->hd == 72 && (e->T == 64 || e->T == 128 || e->T == 256) &&
+                   e->cfg.precision != MAPDIT_PREC_BF16X3;
+    }
     e->M_max = c.max_batch * e->T;
     const int D = c.hidden;
     e->rot = c.rotation != 0;
@@ -944,9 +955,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         // attention branch (dit_block.py:35); b.xm = modulate(xin, shift_msa, scale_msa, gain_msa) is already there
         // inference at head_dim 72 (DiT-XL sampling): the GEMM epilogue writes q, k, v head-major and the attention kernel normalises
         // q, k while it stages them - no split / normalise pass over the QKV result (219 us of a 2.4 ms block at 256 x 256 tokens)
-        static const bool raw72_on = [] { const char* a = getenv("MAPDIT_ATTN72"); const char* r = getenv("MAPDIT_ATTN72_RAW");
-                                          return !(a && a[0] == '0') && !(r && r[0] == '0'); }();
-        const bool raw72 = raw72_on && !save && e->hd == 72 && (T == 64 || T == 128 || T == 256);
+        const bool raw72 = e->raw72;
         if (raw72) {
             mapdit_epilogue_t ep;
             memset(&ep, 0, sizeof(ep));
@@ -967,7 +976,8 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
             ep.alpha = 1.f;
             TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
         }
-        if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        if (raw72 && save) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk_save)(b.qn, b.kn, b.v, b.o, b.lse, b.qks, N, T, H, e->hd, st));
+        else if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         else TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
                  epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
@@ -1019,7 +1029,7 @@ extern "C" int mapdit_engine_peek(mapdit_engine_t* e, int what, int block, void*
         case MAPDIT_PEEK_G_LIN: p = e->lin; l = 2 * e->P; n = M * l; dt = 0; break;
         case MAPDIT_PEEK_B_XM: p = b->xm; n = M * D; break;
         case MAPDIT_PEEK_B_QKV:
-            MD_CHECK(b->qkv, "engine_peek: the fused QKV epilogue writes q^, k^, v only (qkv exists on the generic attention path)");
+            MD_CHECK(b->qkv && !e->raw72, "engine_peek: the fused QKV epilogue writes q^, k^, v only (qkv exists on the generic attention path)");
             p = b->qkv; n = M * 3 * D; l = 3 * (int)D; break;
         case MAPDIT_PEEK_B_QN: p = b->qn; n = M * D; l = e->hd; break;
         case MAPDIT_PEEK_B_KN: p = b->kn; n = M * D; l = e->hd; break;
@@ -1146,7 +1156,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm16(e, MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
-        if (e->generic_attn) {
+        if (e->generic_attn && !e->raw72) {
             TRY(DT_FN(e, mapdit_attn_cos_bwd)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
             TRY(DT_FN(e, mapdit_qkv_merge_bwd)(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
         } else {   // normalisation Jacobian + head merge inside the attention backward passes

@@ -592,8 +592,8 @@ def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
     lib.qkv_merge_bwd(p(qkvd), B, T, H, 64, p(dqn), p(dkn), p(dv), p(dqkv2), st())
     torch.cuda.synchronize()
     assert rel_err(dqkv.float().cpu().numpy(), dqkv2.float().cpu().numpy()) < 1e-2
-    with pytest.raises(L.MapditError):                                   # head_dim 72 has no fused path
-        lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 72, st())
+    with pytest.raises(L.MapditError):                                   # head_dim 80 has no fused path (64 and 72 do)
+        lib.attn_cos_bwd_fused(p(qn_d), p(kn_d), p(v_d), p(dOd), p(o_d), p(lse), p(delta), p(scales), p(dqkv), B, T, H, 80, st())
 
 
 @pytest.mark.parametrize("B,T,H,K", [(2, 256, 3, 128), (3, 64, 2, 192), (1, 128, 16, 256)])
@@ -633,6 +633,66 @@ def test_head_dim_72_inference_path_without_the_split_pass(L, B, T, H, K):
     assert rel_err(o2.float().cpu().numpy(), att.transpose(1, 2).reshape(M, D).numpy()) < 1.2e-2
     with pytest.raises(L.MapditError):
         lib.attn_cos_fwd_rawqk(p(qr), p(kr), p(vr), p(o2), p(lse2), B, T, H, 64, st())
+
+
+@pytest.mark.parametrize("B,T,H,K", [(2, 256, 3, 128), (3, 64, 2, 192), (1, 128, 16, 256)])
+def test_head_dim_72_training_path_without_split_and_merge_passes(L, B, T, H, K):
+    """Training at head_dim 72 (round 4): raw head-major q, k, v from the QKV GEMM, mapdit_attn_cos_fwd_rawqk_save normalises q, k IN
+    PLACE and keeps their scales, mapdit_attn_cos_bwd_fused (head_dim 72) applies the normalisation Jacobian and writes dqkv [M, 3D]
+    directly - against the chain it replaces (plain QKV store, mapdit_qkv_split, mapdit_attn_cos_fwd, mapdit_attn_cos_bwd,
+    mapdit_qkv_merge_bwd) on the same operands, and against autograd over the oracle ops."""
+    from oracle.dit_oracle import normalize
+    hd, D, M = 72, H * 72, B * T
+    x = bf16_exact(M, K, seed=50, scale=0.25)
+    w = bf16_exact(3 * D, K, seed=51, scale=0.25)
+    dO = bf16_exact(M, D, seed=52)
+    lib = L.lib()
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
+    xd, wd, dOd = to_bf(x), to_bf(w), to_bf(dO)
+    # the chain it replaces
+    qkv = mk(M, 3 * D)
+    run_gemm(L, 0, xd, wd, L.EPI_STORE_BF16, M, 3 * D, K, out=p(qkv), ldo=3 * D, alpha=1.0)
+    qn, kn, v = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    lib.qkv_split(p(qkv), B, T, H, hd, p(qn), p(kn), p(v), st())
+    o1, lse1 = mk(M, D), torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_fwd(p(qn), p(kn), p(v), p(o1), p(lse1), B, T, H, hd, st())
+    dqn, dkn, dv = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    delta1 = torch.zeros(B * H, T, device=DEV)
+    lib.attn_cos_bwd(p(qn), p(kn), p(v), p(dOd), p(o1), p(lse1), p(delta1), p(dqn), p(dkn), p(dv), B, T, H, hd, st())
+    dqkv1 = mk(M, 3 * D)
+    lib.qkv_merge_bwd(p(qkv), B, T, H, hd, p(dqn), p(dkn), p(dv), p(dqkv1), st())
+    # the fused chain
+    qr, kr, vr = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    run_gemm(L, 0, xd, wd, L.EPI_QKV_HEADS_RAW, M, 3 * D, K, out=p(qr), out2=p(kr), out3=p(vr), rows_per_sample=T, ld2=hd, alpha=1.0)
+    o2, lse2 = mk(M, D), torch.zeros(B * H, T, device=DEV)
+    scales = torch.zeros(2, B * H, T, device=DEV)
+    lib.attn_cos_fwd_rawqk_save(p(qr), p(kr), p(vr), p(o2), p(lse2), p(scales), B, T, H, hd, st())
+    delta2 = torch.zeros(B * H, T, device=DEV)
+    dqkv2 = torch.full((M, 3 * D), float("nan"), device=DEV).to(MODE["dt"])                     # every element must be written
+    lib.attn_cos_bwd_fused(p(qr), p(kr), p(vr), p(dOd), p(o2), p(lse2), p(delta2), p(scales), p(dqkv2), B, T, H, hd, st())
+    torch.cuda.synchronize()
+    # forward: the rows written back in place are the split kernel's normalised rows (same roundings, other summation order of the norm)
+    assert rel_err(qr.float().cpu().numpy(), qn.float().cpu().numpy()) < 2e-3
+    assert rel_err(kr.float().cpu().numpy(), kn.float().cpu().numpy()) < 2e-3
+    assert torch.equal(vr, v)
+    assert rel_err(o2.float().cpu().numpy(), o1.float().cpu().numpy()) < 4e-3
+    qkv_ref = (x @ w.t()).requires_grad_(True)
+    q, k, vv = qkv_ref.view(B, T, 3 * D).chunk(3, dim=-1)
+    sp = lambda z: z.reshape(B, T, H, hd).transpose(1, 2)
+    s_ref = torch.stack([hd ** 0.5 / (torch.linalg.vector_norm(sp(z).detach(), dim=-1) + 1e-4) for z in (q, k)]).reshape(2, B * H, T)
+    assert rel_err(scales.cpu().numpy(), s_ref.numpy()) < 3e-3                  # (of the 16-bit q, k the GEMM stored)
+    att = torch.softmax(normalize(sp(q)) @ normalize(sp(k)).transpose(-1, -2) / hd ** 0.5, dim=-1) @ sp(vv)
+    att.transpose(1, 2).reshape(M, D).backward(dO)
+    # backward: against the chain it replaces and against autograd
+    assert torch.isfinite(dqkv2.float()).all()
+    assert rel_err(delta2.cpu().numpy(), delta1.cpu().numpy()) < 5e-3
+    assert rel_err(dqkv2.float().cpu().numpy(), dqkv1.float().cpu().numpy()) < 1e-2
+    got, ref = dqkv2.float().cpu().view(M, 3, D), qkv_ref.grad.view(M, 3, D)
+    assert rel_err(got[:, 2].numpy(), ref[:, 2].numpy()) < 1.5e-2     # dV
+    assert rel_err(got[:, 0].numpy(), ref[:, 0].numpy()) < 3e-2       # dQ through the cosine-norm Jacobian
+    assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
+    with pytest.raises(L.MapditError):
+        lib.attn_cos_fwd_rawqk_save(p(qr), p(kr), p(vr), p(o2), p(lse2), p(scales), B, T, H, 64, st())
 
 
 @pytest.mark.parametrize("B,H", [(30, 12), (64, 12), (23, 13)])
