@@ -267,29 +267,28 @@ template <bool HAS_D> struct EpiSilu2GradT {
     // One v_exp + one v_rcp per element serve both outputs; everything else runs on two elements per instruction (v_pk_mul /
     // v_pk_add / v_pk_fma_f32 from the float2 arithmetic below): this epilogue is VALU-issue-bound - the matrix pipe idles while it
     // runs - and the transcendentals are quarter rate, so the packed forms take ~1/3 off its instruction stream.
-    //   s = 1 / (1 + e^-v);  sc = s / 0.596;  act = v sc;  dact = d/dv [v s / 0.596] = sc + act (1 - s)
+    //   s = 1 / (1 + e^-v);  sc = s / 0.596 = 1 / (0.596 e^-v + 0.596);  act = v sc;  dact = d/dv [v s / 0.596] = sc + act (1 - s),
+    //   1 - s = 1 - 0.596 sc.   Per pair: mul, fma, 2 exp, 2 rcp, mul (+ 2 fma for the factor): round 4 took one packed product
+    //   out of it by folding the divisor into the reciprocal's argument (the epilogue is VALU-bound: tools/gemm_phases.py).
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
         typedef __attribute__((ext_vector_type(2))) float f2;
         float a[8], d[8];
-        if constexpr (HAS_D) {
 #pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                const f2 x = {v[i], v[i + 1]};
-                const f2 t = x * -1.44269504088896341f;                     // e^-v = 2^(-v log2 e)
-                const f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-                const f2 q = e + 1.f;
-                const f2 sg = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
-                const f2 sc = sg * (1.f / MP_SILU_DIV);
-                const f2 ac = x * sc;
-                const f2 dd = ac * (1.f - sg) + sc;
-                a[i] = ac.x; a[i + 1] = ac.y;
+        for (int i = 0; i < 8; i += 2) {
+            const f2 x = {v[i], v[i + 1]};
+            const f2 t = x * -1.44269504088896341f;                     // e^-v = 2^(-v log2 e)
+            const f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const f2 q = e * MP_SILU_DIV + MP_SILU_DIV;
+            const f2 sc = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+            const f2 ac = x * sc;
+            a[i] = ac.x; a[i + 1] = ac.y;
+            if constexpr (HAS_D) {
+                const f2 om = sc * -MP_SILU_DIV + 1.f;                  // 1 - s
+                const f2 dd = ac * om + sc;
                 d[i] = dd.x; d[i + 1] = dd.y;
             }
-            store8_bf16(dact + (size_t)m * ldo + n, d);
-        } else {                                           // inference: no backward, no factor
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = silu_f(v[i]) * (1.f / MP_SILU_DIV);
         }
+        if constexpr (HAS_D) store8_bf16(dact + (size_t)m * ldo + n, d);
         store8_bf16(act + (size_t)m * ldo + n, a);
     }
 };
@@ -1455,6 +1454,9 @@ __device__ __forceinline__ void g256_prologue(const GemmP& p, const TileCoord& c
 // Per epilogue: accumulator tiles between the load of its stream operand and the use (kEpiPrefetch), and whether the LDS round trip of
 // tile r+1 is issued ahead of the arithmetic of tile r (kEpiPipeline: a second set of chunk registers).  RESID keeps 24 registers
 // of per-column operands and 8 per chunk of residual stream: both at 2 / true spill (216 bytes of scratch per lane).
+#ifndef MAPDIT_EPI_PD_AUX
+#define MAPDIT_EPI_PD_AUX 2
+#endif
 template <class Epi> constexpr bool kWaveEpilogue = true;          // launch(): take the round-4 kernel for this epilogue
 template <class Epi> constexpr bool kWaveEpilogueAnyK = true;      // ... whatever K is (false: only up to K = 1024 per workgroup)
 template <> constexpr bool kWaveEpilogue<EpiResid> = false;
@@ -1463,6 +1465,8 @@ template <> constexpr bool kWaveEpilogueAnyK<EpiStoreBf16> = false;
 template <class Epi> constexpr int kEpiPrefetch = 2;
 template <class Epi> constexpr bool kEpiPipeline = true;
 template <> constexpr int kEpiPrefetch<EpiResid> = 1;
+template <> constexpr int kEpiPrefetch<EpiMulAux> = MAPDIT_EPI_PD_AUX;      // (4 measured no faster than 2: 900 vs 920 TFLOP/s on fc2-dX)
+template <> constexpr int kEpiPrefetch<EpiDSilu> = MAPDIT_EPI_PD_AUX;
 template <> constexpr bool kEpiPipeline<EpiResid> = false;
 // INTERIOR: the tile lies inside the result (every hot shape: M, N multiples of 256) - no predicate anywhere, so the whole
 // epilogue is one basic block and the LDS round trip of accumulator tile r+1 is issued before the arithmetic of tile r (LDS

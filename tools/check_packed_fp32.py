@@ -6,7 +6,7 @@ packed into v_pk_mov_b32 / v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 sequences 
 (DESIGN.md section 2).  The library is built with -fno-slp-vectorize since; this script makes that a checked property instead of a
 flag somebody can drop: it disassembles every gfx950 code object of the shared library and fails if a kernel outside the allow-list
 contains a packed fp32 arithmetic instruction.  Allow-list = the one place that writes float2 math by hand, the SiLU + derivative GEMM
-epilogue (csrc/gemm.hip EpiSilu2GradT<true>: stress-tested beside a second process, tools/pk_stress.py).  Round 4: the
+epilogue (csrc/gemm.hip EpiSilu2GradT<.>: stress-tested beside a second process, tools/pk_stress.py).  Round 4: the
 exemption is matched on the exact mangled template argument inside the GEMM kernels' symbols, not on a substring, and covers
 v_pk_mul / v_pk_add / v_pk_fma_f32 only - the failing code of round 2 gathered its operands with v_pk_mov_b32 op_sel (both halves of
 a register pair from two different registers), which the hand-written epilogue never does (its pairs are consecutive accumulator
@@ -23,9 +23,9 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 PACKED = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32|v_pk_mov_b32)\b")
-# _ZN12_GLOBAL__N_1[3f16]<len>gemm_..._kernelI...NS[01]_13EpiSilu2GradTILb1EEE...: the training form (HAS_D = true) of the SiLU epilogue as
+# _ZN12_GLOBAL__N_1[3f16]<len>gemm_..._kernelI...NS[01]_13EpiSilu2GradTILb[01]EEE...: the training form (HAS_D = true) of the SiLU epilogue as
 # the epilogue template argument of one of the three MFMA GEMM kernels
-ALLOW = re.compile(r"^_ZN12_GLOBAL__N_1(?:3f16)?\d+gemm_(?:mfma(?:256w?)?|simple)_kernelI.*NS\d?_13EpiSilu2GradTILb1EEE")
+ALLOW = re.compile(r"^_ZN12_GLOBAL__N_1(?:3f16)?\d+gemm_(?:mfma(?:256w?)?|simple)_kernelI.*NS\d?_13EpiSilu2GradTILb[01]EEE")
 ALLOWED_OPS = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"}
 
 
