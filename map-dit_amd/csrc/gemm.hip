@@ -179,14 +179,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #ifndef MAPDIT_STORE_MODE
 #define MAPDIT_STORE_MODE 0        // A/B builds: 1 = plain stores instead of non-temporal ones
 #endif
-__device__ __forceinline__ void store16_stream(void* p, u32x4_t v) {
-    if (MAPDIT_STORE_MODE == 1) *(u32x4_t*)p = v;
+// keep: the tensor is the NEXT kernel's operand (e.g. the modulated activations a RESID epilogue hands to the following GEMM, a dX
+// result the residual backward reads at once): a plain store, so that it is still in the L2 / Infinity Cache when that kernel
+// starts - measured in the step: fc1 380 -> 358 us with its A operand stored that way by the preceding epilogue (round 4).
+__device__ __forceinline__ void store16_stream(void* p, u32x4_t v, bool keep = false) {
+    if (MAPDIT_STORE_MODE == 1 || keep) *(u32x4_t*)p = v;
     else __builtin_nontemporal_store(v, (u32x4_t*)p);
 }
-__device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v) {
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float* v, bool keep = false) {
     u32x4_t u;
     u.x = pack16(v[0], v[1]); u.y = pack16(v[2], v[3]); u.z = pack16(v[4], v[5]); u.w = pack16(v[6], v[7]);
-    store16_stream(p, u);
+    store16_stream(p, u, keep);
 }
 __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // read-once stream (epilogue operand): nt
     const u32x4_t u = __builtin_nontemporal_load((const u32x4_t*)p);
@@ -203,9 +206,10 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // 
     __device__ __forceinline__ Aux load(int, int) const { return Aux(); }                                      \
     __device__ __forceinline__ void apply(int m, int n, const float* v, int z, const Aux&, const Tile&) const { (*this)(m, n, v, z); }
 struct EpiStoreBf16 {
-    bf16_t* out; int ldo; float alpha;
+    bf16_t* out; int ldo; float alpha; int keep;
     EPI_TRIVIAL_STEPS
     __device__ __forceinline__ int n_direct() const { return 1; }
+    __device__ __forceinline__ bool keep_direct() const { return keep != 0; }
     __device__ __forceinline__ bf16_t* dst(int) const { return out; }
     __device__ __forceinline__ void pw(const f32x4_t& v, u32x2_t* o, int) const {
         o[0] = u32x2_t{pack16(alpha * v[0], alpha * v[1]), pack16(alpha * v[2], alpha * v[3])};
@@ -214,7 +218,7 @@ struct EpiStoreBf16 {
         float w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = alpha * v[i];
-        store8_bf16(out + (size_t)m * ldo + n, w);
+        store8_bf16(out + (size_t)m * ldo + n, w, keep);
     }
 };
 struct EpiStoreF32 {
@@ -249,7 +253,8 @@ template <int TAG> struct EpiSilu2 {
 // the backward epilogue that goes with it: a plain product, no transcendental in the dX GEMM's epilogue.
 // HAS_D: the derivative factor is written too (training); a template flag so that the per-chunk code has no branch in it
 template <bool HAS_D> struct EpiSilu2GradT {
-    bf16_t* dact; bf16_t* act; int ldo;
+    bf16_t* dact; bf16_t* act; int ldo; int keep;
+    __device__ __forceinline__ bool keep_direct() const { return false; }
     EPI_TRIVIAL_STEPS
     __device__ __forceinline__ int n_direct() const { return HAS_D ? 2 : 1; }
     __device__ __forceinline__ bf16_t* dst(int w) const { return w == 0 ? act : dact; }
@@ -289,13 +294,13 @@ template <bool HAS_D> struct EpiSilu2GradT {
             }
         }
         if constexpr (HAS_D) store8_bf16(dact + (size_t)m * ldo + n, d);
-        store8_bf16(act + (size_t)m * ldo + n, a);
+        store8_bf16(act + (size_t)m * ldo + n, a, keep != 0);
     }
 };
 template <> constexpr int kDirectOuts<EpiStoreBf16> = 1;
 // (EpiSilu2Grad has the pointwise form too, but measured slower this way: fc1 853 -> 809 TFLOP/s; it stays on the fp32 image)
 struct EpiMulAux {
-    bf16_t* out; const bf16_t* aux; int ldo;
+    bf16_t* out; const bf16_t* aux; int ldo; int keep;
     struct Aux { u32x4_t h; };
     typedef EpiNoTile Tile;
     __device__ __forceinline__ Tile tile_begin(int, int, int) const { return Tile(); }
@@ -310,7 +315,7 @@ struct EpiMulAux {
         w[2] = v[2] * lo16(u.y); w[3] = v[3] * hi16(u.y);
         w[4] = v[4] * lo16(u.z); w[5] = v[5] * hi16(u.z);
         w[6] = v[6] * lo16(u.w); w[7] = v[7] * hi16(u.w);
-        store8_bf16(out + (size_t)m * ldo + n, w);
+        store8_bf16(out + (size_t)m * ldo + n, w, keep != 0);
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const { apply(m, n, v, 0, load(m, n), Tile()); }
 };
@@ -321,6 +326,7 @@ struct EpiResid {
     // rot != 0: the next branch's modulate is the rotation form xm = bf16(xout * nscale + pairswap(xout) * nshift), nscale / nshift =
     // the A / B coefficient rows of mapdit_rot_coef_fwd (pointwise.hip; reference README.md:1-3, parity unpinned); ngain is not read
     int rot;
+    int xm_plain;       // A/B (MAPDIT_RESID_XM_PLAIN=1): xm leaves by plain stores - the next GEMM reads it at once, it should stay cached
     struct Aux { float4 x0, x1; };
     struct Tile { float4 g0, g1, c0, c1, h0, h1; float ka, kb; int smp; };     // smp < 0: rows of several samples in the tile
     __device__ __forceinline__ void per_sample(int smp, int n, Tile& t) const {
@@ -374,7 +380,7 @@ struct EpiResid {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
             }
-            store8_bf16(xm + (size_t)m * ldo + n, w);
+            store8_bf16(xm + (size_t)m * ldo + n, w, xm_plain != 0);
         }
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
@@ -506,6 +512,7 @@ template <> constexpr bool kReduce<EpiRmb> = true;
 // chunks of one 64-column head segment of a row to 8 consecutive lanes, so the per-head sum of squares is three
 // xor-shuffles.  (which, head) are uniform over those 8 lanes; the row's predicate too.
 struct EpiQkvHeads {
+    int keep;
     bf16_t *qn, *kn, *v; float* s; int T, H;          // D = 64 H
     long rows_total;                                    // samples * H * T = rows of the head-major tensors
     int tshift;                                         // log2 T when T is a power of two (every DiT configuration), else -1
@@ -542,7 +549,7 @@ struct EpiQkvHeads {
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = a[i];
         }
-        store8_bf16(tc.dst + row * 64, w);
+        store8_bf16(tc.dst + row * 64, w, keep != 0);
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* a, int = 0) const {
         apply(m, n, a, 0, Aux(), tile_begin(m, m, n));
@@ -1199,7 +1206,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                         if (w < nout) {
                             const char* src = smem + w * (ROWS * DLD) + R * DLD + dcol * 16;
                             const u32x2_t lo = *(const u32x2_t*)src, hi = *(const u32x2_t*)(src + 8);
-                            store16_stream(epi.dst(w) + (size_t)gm * epi.ldo + dgn, u32x4_t{lo.x, lo.y, hi.x, hi.y});
+                            store16_stream(epi.dst(w) + (size_t)gm * epi.ldo + dgn, u32x4_t{lo.x, lo.y, hi.x, hi.y}, epi.keep_direct());
                         }
                 }
             }
@@ -1914,8 +1921,12 @@ struct GemmEnv {
     long band = 0;       // MAPDIT_GEMM_BAND   = column tiles per band (0: derived from K)
     int old_tile_rule = 0;   // MAPDIT_GEMM_TILE_RULE=old
     int persist = 256;       // MAPDIT_GEMM_PERSIST = workgroups of the persistent 256^2 launch (0: one workgroup per tile)
+    // MAPDIT_KEEP = bit mask of epilogue outputs that leave by plain instead of non-temporal stores (they are the next kernel's
+    // operand): 1 RESID xm, 2 STORE_BF16 out, 4 QKV_HEADS q^ k^ v, 8 SILU2_GRAD act, 16 MUL_AUX out
+    int keep_mask = 1;
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
+        if (const char* e = getenv("MAPDIT_KEEP")) keep_mask = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
@@ -2007,6 +2018,13 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         // every band re-reads the A panels once more, so banding only pays with wide bands: fewer than 4 column tiles
         // per band (large K) -> one full-width band (measured: band = 1 at K = 3072 costs 25 %)
         if (!be && band < 4) band = p.tiles_n;
+        // Round 4, measured INSIDE the training step (rocprofv3 per-kernel averages, DiT-B/2 at 256 samples; an isolated launch
+        // finds its A operand in the Infinity Cache and does not show it): the K = 768 forward GEMMs whose operand was written
+        // just before run best with three column tiles per band (fc1 369 -> 360 us, QKV 230 -> 225 us; band = 1, 6, 12: 396 / 369 /
+        // 380 us): the XCD's share of the tile order (an eighth of it) then lies inside one band, and the A panels of its 32
+        // concurrent tiles (11 x 393 KB) are what the L2 keeps, the three B tiles with them.  The NN dX GEMM of the same shape
+        // (fc2-dX, 346 vs 355 us) keeps six.
+        if (!be && layout == MAPDIT_NT && split_k == 1 && K <= 768 && p.tiles_n >= 6 && p.tiles_n % 3 == 0) band = 3;
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
         int grid = p.tiles * split_k;
@@ -2130,7 +2148,7 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
     MD_CHECK(e->split_k <= 1 || e->kind == MAPDIT_EPI_STORE_F32, "gemm: split_k is only available with EPI_STORE_F32");
     switch (e->kind) {
         case MAPDIT_EPI_STORE_BF16:
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreBf16{(bf16_t*)e->out, e->ldo, e->alpha}, st);
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiStoreBf16{(bf16_t*)e->out, e->ldo, e->alpha, (gemm_env().keep_mask >> 1) & 1}, st);
         case MAPDIT_EPI_STORE_F32:
             MD_CHECK(e->split_k <= 1 || !e->accumulate, "gemm: split_k with accumulate is not supported");
             return launch(layout, M, N, K, A, lda, B, ldb,
@@ -2150,14 +2168,14 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
                                    e->rows_per_sample, e->alpha, e->beta, (bf16_t*)e->out3, e->shift2, e->scale2, e->gain2,
-                                   e->ld2, e->rot2}, st);
+                                   e->ld2, e->rot2, gemm_env().keep_mask & 1}, st);
         case MAPDIT_EPI_SILU2_GRAD:
             MD_CHECK(e->out2, "gemm: SILU2_GRAD needs out2");
-            if (e->out) return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<true>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<false>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo}, st);
+            if (e->out) return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<true>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo, (gemm_env().keep_mask >> 3) & 1}, st);
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<false>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo, (gemm_env().keep_mask >> 3) & 1}, st);
         case MAPDIT_EPI_MUL_AUX:
             MD_CHECK(e->aux, "gemm: MUL_AUX needs aux");
-            return launch(layout, M, N, K, A, lda, B, ldb, EpiMulAux{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
+            return launch(layout, M, N, K, A, lda, B, ldb, EpiMulAux{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo, (gemm_env().keep_mask >> 4) & 1}, st);
         case MAPDIT_EPI_DSILU:
             MD_CHECK(e->aux, "gemm: DSILU needs aux (pre-activation)");
             return launch(layout, M, N, K, A, lda, B, ldb, EpiDSilu{(bf16_t*)e->out, (const bf16_t*)e->aux, e->ldo}, st);
@@ -2183,7 +2201,7 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             MD_CHECK(N % 192 == 0 && M % e->rows_per_sample == 0, "gemm: QKV_HEADS needs N = 3 * 64 * heads, M = samples * rows_per_sample");
             const int H = N / 192;
             return launch(layout, M, N, K, A, lda, B, ldb,
-                          EpiQkvHeads{(bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, (float*)e->out4, e->rows_per_sample, H,
+                          EpiQkvHeads{(gemm_env().keep_mask >> 2) & 1, (bf16_t*)e->out, (bf16_t*)e->out2, (bf16_t*)e->out3, (float*)e->out4, e->rows_per_sample, H,
                                       (long)M * H,
                                       (e->rows_per_sample & (e->rows_per_sample - 1)) == 0 ? __builtin_ctz(e->rows_per_sample) : -1}, st);
         }

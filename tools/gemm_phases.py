@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--cases", default="")
     ap.add_argument("--hidden", type=int, default=768)
     ap.add_argument("--tokens", type=int, default=65536)
+    ap.add_argument("--cold", action="store_true", help="write 1 GiB elsewhere before every launch: the cache state a launch meets inside the "
+                                                        "training step (its operands were produced long ago, L2 / Infinity Cache hold other data)")
     args = ap.parse_args()
     lib = C.CDLL(os.path.join(HERE, "_stamps", "libgemm_stamps.so"))
     lib.mapdit_gemm_bf16.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(L.Epilogue), C.c_void_p]
@@ -71,13 +73,26 @@ def main():
             assert rc == 0, lib.mapdit_last_error()
         torch.cuda.synchronize()
         rec.zero_()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(10):
-            lib.mapdit_gemm_bf16(layout, m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb, C.byref(e), st)
-        ev1.record()
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / 10
+        if args.cold:
+            trash = torch.empty(1 << 28, device=dev)
+            ms = 0.0
+            for _ in range(10):
+                trash.fill_(1.0)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                lib.mapdit_gemm_bf16(layout, m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb, C.byref(e), st)
+                ev1.record()
+                torch.cuda.synchronize()
+                ms += ev0.elapsed_time(ev1) / 10
+        else:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(10):
+                lib.mapdit_gemm_bf16(layout, m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb, C.byref(e), st)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / 10
+        # (with --cold the records hold the last launch only: each launch overwrites them)
         r = rec.cpu().view(-1, 16).double()
         r = r[r[:, 4] > 0]
         tiles = r[:, 4].mean().item()
