@@ -365,9 +365,16 @@ struct EpiResid {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(cb * g[i], v[i], ca * x[i]);
-        float4* xo = (float4*)(xout + (size_t)m * ldo + n);
-        xo[0] = make_float4(o[0], o[1], o[2], o[3]);
-        xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+        // A/B (MAPDIT_KEEP bit 32, off): the residual checkpoint by non-temporal stores - fc1 3 us faster, the step 0.2 ms slower (the
+        // next branch's residual read and the residual backward find less of it cached): not used
+        if (xm_plain & 2) {
+            __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, (f32x4_t*)(xout + (size_t)m * ldo + n));
+            __builtin_nontemporal_store(f32x4_t{o[4], o[5], o[6], o[7]}, (f32x4_t*)(xout + (size_t)m * ldo + n + 4));
+        } else {
+            float4* xo = (float4*)(xout + (size_t)m * ldo + n);
+            xo[0] = make_float4(o[0], o[1], o[2], o[3]);
+            xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
         if (y) store8_bf16(y + (size_t)m * ldo + n, v);
         if (xm) {
             const float c[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
@@ -380,7 +387,7 @@ struct EpiResid {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
             }
-            store8_bf16(xm + (size_t)m * ldo + n, w, xm_plain != 0);
+            store8_bf16(xm + (size_t)m * ldo + n, w, (xm_plain & 1) != 0);
         }
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
@@ -1922,7 +1929,7 @@ struct GemmEnv {
     int old_tile_rule = 0;   // MAPDIT_GEMM_TILE_RULE=old
     int persist = 256;       // MAPDIT_GEMM_PERSIST = workgroups of the persistent 256^2 launch (0: one workgroup per tile)
     // MAPDIT_KEEP = bit mask of epilogue outputs that leave by plain instead of non-temporal stores (they are the next kernel's
-    // operand): 1 RESID xm, 2 STORE_BF16 out, 4 QKV_HEADS q^ k^ v, 8 SILU2_GRAD act, 16 MUL_AUX out
+    // operand): 1 RESID xm, 2 STORE_BF16 out, 4 QKV_HEADS q^ k^ v, 8 SILU2_GRAD act, 16 MUL_AUX out; 32: RESID xout NON-temporal
     int keep_mask = 1;
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
@@ -2168,7 +2175,7 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             return launch(layout, M, N, K, A, lda, B, ldb,
                           EpiResid{(bf16_t*)e->out, (const float*)e->aux, (float*)e->out2, e->gate, e->ldo, e->ldg,
                                    e->rows_per_sample, e->alpha, e->beta, (bf16_t*)e->out3, e->shift2, e->scale2, e->gain2,
-                                   e->ld2, e->rot2, gemm_env().keep_mask & 1}, st);
+                                   e->ld2, e->rot2, (gemm_env().keep_mask & 1) | ((gemm_env().keep_mask >> 5) & 1) << 1}, st);
         case MAPDIT_EPI_SILU2_GRAD:
             MD_CHECK(e->out2, "gemm: SILU2_GRAD needs out2");
             if (e->out) return launch(layout, M, N, K, A, lda, B, ldb, EpiSilu2GradT<true>{(bf16_t*)e->out, (bf16_t*)e->out2, e->ldo, (gemm_env().keep_mask >> 3) & 1}, st);
