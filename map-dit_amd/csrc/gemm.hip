@@ -1682,6 +1682,151 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
     }
 }
 
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+// ---- the same kernel with a THREE-deep A ring: MEASURED AND REJECTED (round 4) ------------------------------------------------------
+// Bit-identical results, 5-12 % SLOWER isolated (QKV store 1,117 -> 996, heads 1,064 -> 939, fc1 871 -> 825 TFLOP/s on one box), slower
+// inside the step (fc1 349 -> 375 us, step 43.9 -> 44.8 ms) and slower from cold caches (fc1 362 -> 397 us): what the cold K loop lacks
+// is not prefetch distance.  Compiled only with -DMAPDIT_GEMM_EXPERIMENTS (MAPDIT_GEMM_W3=1 selects it there).  The idea was:
+// Inside the training step a GEMM's A operand was written by the kernel before it and comes from HBM, next to the launch's own
+// output stream (fc1: 806 MB of stores per launch); an isolated launch finds it in the Infinity Cache.  tools/gemm_phases.py --cold
+// reproduces the difference: fc1's K loop takes 41 k cycles per tile instead of 29 k, the waits of the two-deep staging ring exposed
+// (fc1 328 -> 392 us; in the step 365 us).  The 32 KiB the staging leaves free become a third A buffer: the A panels (which stream)
+// are requested a K-tile earlier, the B panel (L2-resident) keeps two buffers.  The wave-private epilogue buffers alias the A slot the
+// next tile's prologue does not touch (K-tile 2's A goes out after the epilogue).
+//   LDS: A ring 3 x {A0 | A1} at 0 / 32 / 64 KiB, B ring 2 x {B0 | B1} at 96 / 128 KiB; A(t) -> slot t % 3, B(t) -> slot t & 1.
+//   Issue order per wave: ... A1[t+2] (phase A of K-tile t), A0[t+3] B0[t+2] B1[t+2] (phase B of t) ...; the prologue issues
+//   A0[0] A1[0] A0[1] B0[0] B1[0] A1[1] A0[2] B0[1] B1[1] in that same order.
+//   RAW  phase A waits until A1[t] has landed (read in phase B): every wave's counted vmcnt leaves exactly what was issued after it in
+//        flight (16 pieces in the steady state); phase B waits for B1[t+1], the youngest piece phase A of t+1 reads (8 in flight).
+//   WAR  A1[t+2] goes to the slot whose A1 was last read in phase B of t-1; A0[t+3] to slot t % 3, whose A0 phase A of t has just read
+//        (drained by lgkmcnt(0) before the barrier between); B0 / B1[t+2] likewise - the distances of the two-deep loop.
+constexpr int W3_ASLOT = 2 * SLOT_BYTES, W3_BBASE = 3 * W3_ASLOT, W3_BOUNCE = 2 * W3_ASLOT;
+static_assert(W3_BBASE + 2 * 2 * SLOT_BYTES == SMEM_W_BYTES && W3_BOUNCE + 8 * WPRIV_BYTES <= W3_BBASE, "LDS layout");
+__device__ __forceinline__ void wait_vm_even(int n) {      // s_waitcnt vmcnt(n) for a wave-uniform even n in 0..16 (an immediate in the ISA)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+}
+
+template <int AK, int BK, class Epi, bool KTAIL = false>
+__global__ __launch_bounds__(512, 2) void gemm_mfma256w3_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_W_BYTES];
+    const int total = p.tiles * p.split_k;
+    int v = blockIdx.x;
+    if (v >= total) return;
+    constexpr bool TR_ASM2 = AK == OP_KMAJ;
+    TileCoord c = tile_coord(p, v, total);
+    // pieces of K-tile kt (tile-local index): into A slot kt % 3 / B slot kt & 1
+    auto st_a = [&](const TileCoord& tc, int kt, int slot, int h, int wave, int lane) {
+        stage_half<AK, 0, KTAIL>(p.A, p.lda, tc.m0, p.M, tc.kbeg + kt * BKT, p.K, h, smem + slot * W3_ASLOT + h * SLOT_BYTES, wave, lane);
+    };
+    auto st_b = [&](const TileCoord& tc, int kt, int h, int wave, int lane) {
+        stage_half<BK, 1, KTAIL>(p.B, p.ldb, tc.n0, p.N, tc.kbeg + kt * BKT, p.K, h, smem + W3_BBASE + (kt & 1) * W3_ASLOT + h * SLOT_BYTES, wave, lane);
+    };
+    // the part of a tile's prologue that may go out before the previous epilogue (A slots 0, 1 and both B slots): everything but A0[2]
+    auto prologue_early = [&](const TileCoord& tc, int wave, int lane) {        // needs nk >= 4 (the launcher guarantees it)
+        st_a(tc, 0, 0, 0, wave, lane); st_a(tc, 0, 0, 1, wave, lane); st_a(tc, 1, 1, 0, wave, lane);
+        st_b(tc, 0, 0, wave, lane); st_b(tc, 0, 1, wave, lane);
+        st_a(tc, 1, 1, 1, wave, lane);
+    };
+    {
+        const int tid0 = threadIdx.x, w0 = __builtin_amdgcn_readfirstlane(tid0 >> 6), l0 = tid0 & 63;
+        prologue_early(c, w0, l0);
+        st_a(c, 2, 2, 0, w0, l0);                          // first tile: the canonical order, A0[2] ahead of B0[1] B1[1]
+        st_b(c, 1, 0, w0, l0); st_b(c, 1, 1, w0, l0);
+    }
+    bool first = true;
+    for (;;) {
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int tid = tid_, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 2, wn = wave & 3;
+        const int nk = c.nk;
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+        auto load_a = [&](const char* slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK, TR_ASM2>(slot, wm * 64 + i * 16, ks, lane);
+        };
+        if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A0 A1 A0' B0 B1 of the canonical order have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the early prologue (and the epilogue's stores behind it)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // A0[2] goes to the slot that held the epilogue buffers of ALL waves: only behind the barrier every wave reaches after its
+        // epilogue (the same holds for A1[2], issued in phase A of K-tile 0).  It is then the youngest piece instead of the seventh of
+        // the canonical order: the counted waits below stay upper bounds (phase B of K-tile 0 retires it early, nothing later is delayed).
+        if (!first) st_a(c, 2, 2, 0, wave, lane);
+        if (wm == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // pieces issued in phase A / phase B of K-tile u (u < 0: the prologue, in the canonical order)
+        auto n_a1 = [&](int u) { return u + 2 < nk ? 2 : 0; };
+        auto n_b = [&](int u) { return (u + 3 < nk ? 2 : 0) + (u + 2 < nk ? 4 : 0); };
+        int a = 0;                                                         // t % 3
+        for (int t = 0; t < nk; ++t) {
+            const int a1 = a == 2 ? 0 : a + 1, a2 = a == 0 ? 2 : a - 1;    // (t + 1) % 3, (t + 2) % 3
+            const char* As = smem + a * W3_ASLOT;
+            const char* Bs = smem + W3_BBASE + (t & 1) * W3_ASLOT;
+            load_a(As);
+            G256_LOAD_B(fb0, Bs);
+            G256_LOAD_B(fb1, Bs + SLOT_BYTES);
+            if (t + 2 < nk) st_a(c, t + 2, a2, 1, wave, lane);
+            wait_vm_even(n_b(t - 2) + n_a1(t - 1) + n_b(t - 1) + n_a1(t));       // A1[t] and everything older have landed
+            G256_END_LOAD();
+            G256_MFMA(0, 0, fb0);
+            G256_MFMA(0, 1, fb1);
+            G256_END_MFMA();
+            load_a(As + SLOT_BYTES);
+            if (t + 3 < nk) st_a(c, t + 3, a, 0, wave, lane);
+            if (t + 2 < nk) { st_b(c, t + 2, 0, wave, lane); st_b(c, t + 2, 1, wave, lane); }
+            wait_vm_even(n_a1(t) + n_b(t));                                        // B1[t+1] and everything older have landed
+            G256_END_LOAD();
+            G256_MFMA(1, 1, fb1);
+            G256_MFMA(1, 0, fb0);
+            G256_END_MFMA();
+            a = a1;
+        }
+        if (wm == 0) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int vn = v + (int)gridDim.x;
+        TileCoord cn = c;
+        if (vn < total) {
+            cn = tile_coord(p, vn, total);
+            prologue_early(cn, wave, lane);
+            st_b(cn, 1, 0, wave, lane); st_b(cn, 1, 1, wave, lane);
+        }
+        if (c.m0 + BM2 <= p.M && c.n0 + BN2 <= p.N)
+            g256w_epilogue<Epi, true>(p, epi, c, acc, smem + W3_BOUNCE + wave * WPRIV_BYTES, wave, lane);
+        else
+            g256w_epilogue<Epi, false>(p, epi, c, acc, smem + W3_BOUNCE + wave * WPRIV_BYTES, wave, lane);
+        if (vn >= total) break;
+        v = vn;
+        c = cn;
+        first = false;
+    }
+}
+
+#endif   // MAPDIT_GEMM_EXPERIMENTS (three-deep A ring)
+
 // ---- the one-wave-per-SIMD kernel: 256x256x64 tile, 4 waves (2 M x 2 N), 128x128 per wave ----------------------------
 // MEASURED AND REJECTED (round 3, profiles/r03_gemm_w4_experiment.log): bit-correct on all layouts, 7-10 % SLOWER than the 8-wave
 // kernel on every shape of the block (NN K = 3072: 1,174 vs 1,268 TFLOP/s; NT K = 768: 967 vs 1,077).  The ablation builds say why:
@@ -1931,9 +2076,11 @@ struct GemmEnv {
     // MAPDIT_KEEP = bit mask of epilogue outputs that leave by plain instead of non-temporal stores (they are the next kernel's
     // operand): 1 RESID xm, 2 STORE_BF16 out, 4 QKV_HEADS q^ k^ v, 8 SILU2_GRAD act, 16 MUL_AUX out; 32: RESID xout NON-temporal
     int keep_mask = 1;
+    int w3 = 0;              // MAPDIT_GEMM_W3 = 1 (experiment builds only): the three-deep A ring variant of the round-4 kernel
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_KEEP")) keep_mask = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_W3")) w3 = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
@@ -2059,10 +2206,21 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             // private: 60 k cycles of epilogue per tile against ~15 k; tools/gemm_phases.py).  phases = 7 or 4 select the older kernel,
             // 6 forces the round-4 one for every epilogue.
             const bool use_w = p.phases == 6 || (p.phases == 2 && kWaveEpilogue<Epi> && (kWaveEpilogueAnyK<Epi> || K / split_k <= 1024));
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+            const bool deep = gemm_env().w3 && ((K + BKT - 1) / BKT) / split_k >= 4;          // every K range has at least four K-tiles
+#endif
             if (use_w) {
                 p.phases = 2;
                 auto gow = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+                    if (deep) {
+                        if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256w3_kernel<OP_ROW, OP_ROW, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                        else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256w3_kernel<OP_ROW, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                        else hipLaunchKernelGGL((gemm_mfma256w3_kernel<OP_KMAJ, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
+                        return;
+                    }
+#endif
                     if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_ROW, OP_ROW, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
                     else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_ROW, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
                     else hipLaunchKernelGGL((gemm_mfma256w_kernel<OP_KMAJ, OP_KMAJ, Epi, TAIL>), dim3(grid), dim3(512), 0, st, p, epi);
