@@ -224,6 +224,13 @@ int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
  * ceil(D/512) * n_samples partials of the gain gradient, each multiplied by dgain_scale (0 = 1; see dgain_scale above). */
 int mapdit_rot_coef_fwd(const float* theta, const float* scale, int ldm, const float* gain, float* A, float* B, int ldc,
                         int n_samples, int D, void* stream);
+/* The coefficient rows of EVERY (block, branch) of a model in one launch (abi 4; the engine's forward: 2 L launches of the above
+ * before).  mod = the [n_samples][ld_mod] rows of all blocks' modulation outputs, slot s = 2 block + branch reads its angles at
+ * mod[n][theta_off[s] ..+D/2) and its scale at mod[n][scale_off[s] ..+D), multiplies the angles by *gains[s], and writes
+ * A / B [n][ldc] at column s * D.  n_slots <= MAPDIT_ROT_MAX_SLOTS; gains / offsets are host arrays (they travel as kernel arguments). */
+#define MAPDIT_ROT_MAX_SLOTS 80
+int mapdit_rot_coef_fwd_all(const float* mod, int ld_mod, const int* theta_off, const int* scale_off, const float* const* gains,
+                            int n_slots, float* A, float* B, int ldc, int n_samples, int D, void* stream);
 int mapdit_rot_coef_bwd(const float* dA, const float* dB, int ldc, const float* theta, const float* scale, int ldm,
                         const float* gain, float* dtheta, float* dscale, int ldd, float* dgain_part, float dgain_scale,
                         int n_samples, int D, void* stream);

@@ -80,6 +80,7 @@ _SIGS = {
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
     "mapdit_rot_coef_fwd": [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp],
+    "mapdit_rot_coef_fwd_all": [vp, ci, vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_rot_coef_bwd": [vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, cf, ci, ci, vp],
     "mapdit_rot_modulate_fwd": [vp, vp, vp, ci, vp, ci, ci, ci, vp],
     "mapdit_mpsilu_to_bf16": [vp, vp, cl, vp],

@@ -925,12 +925,22 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // rows of y[j] = A x[j] + B x[j ^ 1] (mapdit_rot_coef_fwd: one pass over [samples, L * 2 * D], one sincos per pair), read by the
     // same fused epilogues in their rot form - slot (block, branch) at column (2 * block + branch) * D.
     if (e->rot) {
-        for (int i = 0; i < L; ++i) {
-            const float* mod = e->mod_all + (size_t)i * e->MW;
-            TRY(mapdit_rot_coef_fwd(mod + e->o_sha, mod + e->o_sca, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)],
-                                    e->rotA + (size_t)(2 * i) * D, e->rotB + (size_t)(2 * i) * D, e->ldc, N, D, st));
-            TRY(mapdit_rot_coef_fwd(mod + e->o_shm, mod + e->o_scm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)],
-                                    e->rotA + (size_t)(2 * i + 1) * D, e->rotB + (size_t)(2 * i + 1) * D, e->ldc, N, D, st));
+        if (2 * L <= MAPDIT_ROT_MAX_SLOTS) {               // every (block, branch) in one launch (2 L tiny launches before: ADVICE r03)
+            int th[MAPDIT_ROT_MAX_SLOTS], sc[MAPDIT_ROT_MAX_SLOTS];
+            const float* gn[MAPDIT_ROT_MAX_SLOTS];
+            for (int i = 0; i < L; ++i) {
+                th[2 * i] = i * e->MW + e->o_sha; sc[2 * i] = i * e->MW + e->o_sca; gn[2 * i] = e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)];
+                th[2 * i + 1] = i * e->MW + e->o_shm; sc[2 * i + 1] = i * e->MW + e->o_scm; gn[2 * i + 1] = e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)];
+            }
+            TRY(mapdit_rot_coef_fwd_all(e->mod_all, ldm, th, sc, gn, 2 * L, e->rotA, e->rotB, e->ldc, N, D, st));
+        } else {
+            for (int i = 0; i < L; ++i) {
+                const float* mod = e->mod_all + (size_t)i * e->MW;
+                TRY(mapdit_rot_coef_fwd(mod + e->o_sha, mod + e->o_sca, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)],
+                                        e->rotA + (size_t)(2 * i) * D, e->rotB + (size_t)(2 * i) * D, e->ldc, N, D, st));
+                TRY(mapdit_rot_coef_fwd(mod + e->o_shm, mod + e->o_scm, ldm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)],
+                                        e->rotA + (size_t)(2 * i + 1) * D, e->rotB + (size_t)(2 * i + 1) * D, e->ldc, N, D, st));
+            }
         }
     }
     const int rot = e->rot ? 1 : 0;

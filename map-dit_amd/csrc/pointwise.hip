@@ -200,6 +200,21 @@ __global__ void rot_coef_fwd_kernel(const float* __restrict__ theta, const float
     *(float2*)(B + (size_t)b * ldc + 2 * pr) = make_float2(-sn * sc.y, sn * sc.x);
 }
 
+// every (block, branch) slot of the model in one launch: grid (pairs / 256, slots, samples)
+struct RotSlots { const float* gain[MAPDIT_ROT_MAX_SLOTS]; int theta_off[MAPDIT_ROT_MAX_SLOTS]; int scale_off[MAPDIT_ROT_MAX_SLOTS]; };
+__global__ __launch_bounds__(256) void rot_coef_fwd_all_kernel(const float* __restrict__ mod, int ldm, RotSlots sl, float* __restrict__ A,
+                                                              float* __restrict__ B, int ldc, int D) {
+    const int pr = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
+    if (pr >= (D >> 1)) return;
+    const float* row = mod + (size_t)b * ldm;
+    float sn, cs;
+    sincosf(*sl.gain[s] * row[sl.theta_off[s] + pr], &sn, &cs);
+    const float2 sc = *(const float2*)(row + sl.scale_off[s] + 2 * pr);
+    const size_t o = (size_t)b * ldc + (size_t)s * D + 2 * pr;
+    *(float2*)(A + o) = make_float2(cs * sc.x, cs * sc.y);
+    *(float2*)(B + o) = make_float2(-sn * sc.y, sn * sc.x);
+}
+
 // dtheta[n, i] = g dphi, dscale, and one partial of dgain = sum theta dphi per workgroup (summed in order by reduce_partials), from
 //   dA[n, j] = sum_t dy[j] x[j],  dB[n, j] = sum_t dy[j] x[j ^ 1]   (the rot form of resid_mod_bwd):
 //   dsc[2i] = c dA[2i] + s dB[2i+1]      dsc[2i+1] = c dA[2i+1] - s dB[2i]
@@ -460,6 +475,23 @@ extern "C" int mapdit_rot_coef_fwd(const float* theta, const float* scale, int l
              "rot_coef_fwd: even D / row strides and 8-byte aligned rows");
     hipLaunchKernelGGL(rot_coef_fwd_kernel, dim3(cdiv((long)n_samples * (D / 2), 256)), dim3(256), 0, (hipStream_t)stream, theta, scale,
                        ldm, gain, A, B, ldc, n_samples, D);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_rot_coef_fwd_all(const float* mod, int ld_mod, const int* theta_off, const int* scale_off, const float* const* gains,
+                                       int n_slots, float* A, float* B, int ldc, int n_samples, int D, void* stream) {
+    MD_CHECK(mod && theta_off && scale_off && gains && A && B && n_samples > 0 && n_slots > 0, "rot_coef_fwd_all: null/empty argument");
+    MD_CHECK(n_slots <= MAPDIT_ROT_MAX_SLOTS, "rot_coef_fwd_all: %d slots (at most %d)", n_slots, MAPDIT_ROT_MAX_SLOTS);
+    MD_CHECK(D % 2 == 0 && ld_mod % 2 == 0 && ldc % 2 == 0 && ((((uintptr_t)mod | (uintptr_t)A | (uintptr_t)B)) & 7) == 0 && n_samples <= 65535,
+             "rot_coef_fwd_all: even D / row strides, 8-byte aligned rows, at most 65535 samples");
+    RotSlots sl;
+    for (int s = 0; s < n_slots; ++s) {
+        MD_CHECK(gains[s] && scale_off[s] % 2 == 0, "rot_coef_fwd_all: slot %d: null gain or odd scale offset", s);
+        sl.gain[s] = gains[s]; sl.theta_off[s] = theta_off[s]; sl.scale_off[s] = scale_off[s];
+    }
+    hipLaunchKernelGGL(rot_coef_fwd_all_kernel, dim3(cdiv(D / 2, 256), n_slots, n_samples), dim3(256), 0, (hipStream_t)stream, mod, ld_mod,
+                       sl, A, B, ldc, D);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
