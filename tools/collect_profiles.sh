@@ -4,7 +4,7 @@
 # turns it into profiles/<tag>_*.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/${tag}_final
 mkdir -p $out
 sha256sum map-dit_amd/csrc/gemm.hip > $out/gemm_hip.sha256
@@ -15,9 +15,19 @@ python bench.py --steps 20 --warmup 5 --rotation-modulation > $out/bench_rotatio
 python bench.py --steps 20 --warmup 5 --model DiT-S/2 --no-cpu-baseline > $out/bench_S2.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --model DiT-XL/2 --batch-per-gpu 64 --no-cpu-baseline > $out/bench_XL2_b64.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --precision f16 --no-cpu-baseline > $out/bench_f16.json 2>/dev/null
+python tools/sample_bench.py --model DiT-XL/2 --n 128 --steps 20 > $out/sample_XL2_bf16.json 2>/dev/null
+python tools/sample_bench.py --model DiT-XL/2 --n 128 --steps 20 --precision f16 > $out/sample_XL2_f16.json 2>/dev/null
+python tools/sample_bench.py --model DiT-B/2 --n 64 --steps 30 --precision f16 > $out/sample_B2_f16.json 2>/dev/null
 echo "benches done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-parity --no-f16-leg > $out/bench_under_rocprof.json 2> $out/rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof32 -o bench32 -- python3 bench.py --steps 10 --warmup 3 --batch-per-gpu 32 --no-cpu-baseline --no-parity --no-f16-leg > $out/bench32_under_rocprof.json 2>> $out/rocprof.err
+for cfg in "S2 bench.py --steps 10 --warmup 3 --model DiT-S/2 --no-cpu-baseline --no-parity --no-f16-leg" \
+           "XL2_b64 bench.py --steps 6 --warmup 2 --model DiT-XL/2 --batch-per-gpu 64 --no-cpu-baseline --no-parity --no-f16-leg" \
+           "XL2_sample tools/sample_bench.py --model DiT-XL/2 --n 128 --steps 10" \
+           "B2_rotation bench.py --steps 8 --warmup 3 --rotation-modulation --no-cpu-baseline --no-f16-leg"; do
+  set -- $cfg; name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o $name -- python3 "$@" > $out/${name}_under_rocprof.json 2>> $out/rocprof.err
+done
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')

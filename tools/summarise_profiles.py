@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", TAG + "_final")
 DST = os.path.join(ROOT, "profiles")
 
@@ -20,7 +20,7 @@ def counter(tag, names):
     rows = list(csv.DictReader(open(os.path.join(SRC, f"pmc_{tag}", "fc1_counter_collection.csv"))))
     out = {}
     for n in names:
-        vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n and "gemm_mfma256_kernel" in r["Kernel_Name"]]
+        vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n and ("gemm_mfma256_kernel" in r["Kernel_Name"] or "gemm_mfma256w_kernel" in r["Kernel_Name"])]
         out[n] = sum(vals) / max(len(vals), 1)
         out[n + "_launches"] = len(vals)
     return out
@@ -38,7 +38,7 @@ M, D, H = 65536, 768, 3072
 read_b = fetch["FETCH_SIZE"] * 1024 * 2          # KiB -> bytes; gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads
 write_b = write["WRITE_SIZE"] * 1024
 d = {
-    "kernel": "gemm_mfma256_kernel<0,0,EpiSilu2Grad> NT [65536,768]x[3072,768]^T (fc1: activation + derivative factor, both bf16)",
+    "kernel": "gemm_mfma256w_kernel<0,0,EpiSilu2GradT<true>> NT [65536,768]x[3072,768]^T (fc1: activation + derivative factor, both bf16)",
     "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 tools/gemm_one.py fc1  (one pass per counter "
                "group, 5 launches each, mean; tools/collect_profiles.sh)",
     "model": "DiT-B/2", "per_gpu_batch": 256, "gemm_hip_sha256": sha,
@@ -55,10 +55,15 @@ d = {
 json.dump(d, open(os.path.join(DST, TAG + "_fc1_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: d[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "l2_hit_rate", "mfma_busy_over_sq_busy")}))
 with open(os.path.join(DST, TAG + "_bench_lines.jsonl"), "w") as f:
-    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_f16", "bench_under_rocprof"):
+    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_f16", "bench_under_rocprof",
+                 "sample_XL2_bf16", "sample_XL2_f16", "sample_B2_f16"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 10:
             line = [ln for ln in open(p) if ln.startswith("{")]
             if line:
                 f.write(json.dumps({"run": name, **json.loads(line[-1])}) + "\n")
+for name in ("S2", "XL2_b64", "XL2_sample", "B2_rotation"):              # kernel statistics of the other BASELINE configurations
+    for cand in (os.path.join(SRC, f"prof_{name}", f"{name}_kernel_stats.csv"),):
+        if os.path.exists(cand):
+            shutil.copy(cand, os.path.join(DST, f"{TAG}_kernel_stats_{name}.csv"))
 print(f"wrote profiles/{TAG}_*")
