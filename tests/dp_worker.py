@@ -34,6 +34,8 @@ def main():
     torch.manual_seed(21)
     m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7).to(dev).train()
     m.gemm_precision = precision
+    if precision == "f16":
+        m.loss_scale = 1024.0                               # (the automatic choice depends on the per-rank batch: fixed, a sample's bits do not)
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     with torch.no_grad():                                   # non-trivial gains so that every gradient path is alive
         for k, p in m.named_parameters():
@@ -46,11 +48,16 @@ def main():
     g = torch.Generator().manual_seed(22)
     n = 16
     lo, hi = parallel.shard_batch(n, rank, world)
-    for _ in range(steps):
+    # MAPDIT_TEST_OVERFLOW="rank:step": that rank's loss is blown up in that step (fp16: its gradients overflow) - the non-finite
+    # guard must refuse the step on EVERY rank
+    bad_rank, bad_step = (int(v) for v in os.environ.get("MAPDIT_TEST_OVERFLOW", "-1:-1").split(":"))
+    for it in range(steps):
         x, y = torch.randn(n, 4, 32, 32, generator=g), torch.randint(0, 7, (n,), generator=g)
         t, noise = torch.randint(0, 1000, (n,), generator=g), torch.randn(n, 4, 32, 32, generator=g)
         x, y, t, noise = (v[lo:hi].to(dev) for v in (x, y, t, noise))
         loss = diff.training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean()
+        if rank == bad_rank and it == bad_step:
+            loss = loss * 1e12
         opt.zero_grad()
         loss.backward()
         red.finish()
@@ -59,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     parts = getattr(opt, "shards", None)
     torch.save({"p": m._pflat.cpu(), "g": m._gflat.cpu() * red.grad_scale, "m": opt.exp_avg.cpu(), "v": opt.exp_avg_sq.cpu(),
-                "e0": opt.ema[0].cpu(), "e1": opt.ema[1].cpu(), "shards": parts, "loss": float(loss)},
+                "e0": opt.ema[0].cpu(), "e1": opt.ema[1].cpu(), "shards": parts, "loss": float(loss), "refused": opt.overflow_steps()},
                os.path.join(out_dir, f"rank{rank}.pt"))
     if world > 1:
         torch.distributed.barrier()

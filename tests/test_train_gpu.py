@@ -228,7 +228,24 @@ def _run_dp(tmp_path, tag, world, mode, precision, steps=3, rccl=False):
     return [torch.load(out / f"rank{i}.pt", weights_only=False) for i in range(world)]
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["allreduce", "zero1"])
+def test_two_rank_overflow_is_refused_on_every_rank(tmp_path, monkeypatch, mode):
+    """fp16 engine, two data-parallel ranks: the SECOND rank's loss is blown up in the second of three steps, its gradients overflow.
+    The non-finite guard looks at the REDUCED gradients (all-reduce: inf / NaN reaches every rank with the sum; ZeRO-1: each rank checks
+    its own parts and the verdict word is all-reduced), so both ranks must refuse that step: replicas stay bit-identical and finite,
+    one refused step on each, and the run equals a two-step run without the bad step on those weights up to the data it skipped."""
+    monkeypatch.setenv("MAPDIT_TEST_OVERFLOW", "1:1")
+    r = _run_dp(tmp_path, "ovf", 2, mode, "f16")
+    for k in ("p", "m", "v", "e0", "e1"):
+        assert torch.equal(r[0][k], r[1][k]), f"replicas differ in {k} after a refused step"
+        assert torch.isfinite(r[0][k]).all(), k
+    assert r[0]["refused"] == 1 and r[1]["refused"] == 1
+    monkeypatch.delenv("MAPDIT_TEST_OVERFLOW")
+    clean = _run_dp(tmp_path, "clean", 2, mode, "f16")
+    assert clean[0]["refused"] == 0 and not torch.equal(clean[0]["p"], r[0]["p"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16", "bf16x3"])
 def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
     """Two data-parallel ranks (different halves of a fixed global batch each; gloo collectives, both ranks on this box's one
     GPU) against ONE process on the whole batch, three optimiser steps, for both gradient exchanges:
@@ -263,7 +280,9 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
     for k in ("g", "p", "m", "e0"):
         e = rel_err(ar1[k].numpy(), single1[k].numpy())
         print(f"{precision}: 2-rank all-reduce vs single process after 1 step, {k}: {e:.2e}")
-        assert e < 2e-5, (k, e)
+        # f16: a rank's mean loss over 8 samples hands the backward twice the gradient the single process' mean over 16 does - a power
+        # of two, exact except where fp16 activation gradients go subnormal: the loss-scale invariance bound of test_f16_gpu.py (2e-4)
+        assert e < (2e-4 if precision == "f16" else 2e-5), (k, e)
     single3 = _run_dp(tmp_path, "w1s3", 1, "allreduce", precision)[0]
     tol = 2e-5 if precision == "bf16x3" else 2e-2
     for k in ("g", "p", "m", "e0"):
