@@ -45,6 +45,8 @@ struct GemmP {
     int split_k;    // K is cut into split_k equal ranges; slab z of the output holds the partial sum of range z
     int band;       // 256^2 kernel: column tiles per band of the band-major tile order (L2 residency of the B panel)
     int phases;     // 256^2 kernel: 4 = one output quadrant per phase (16 MFMAs), 2 = one half per phase (32 MFMAs)
+    int n_off;      // 128^2 kernel: column offset handed to the epilogue (the launch covers columns [n_off, n_off + N) of a wider
+                    // result whose first n_off columns another launch computes; B already points at that column block)
 };
 
 // Swizzle key of K-major row k.  One ds_read_b64_tr_b16 half-wave touches rows {8g+q, q = 0..3, g = 0..1} (then the
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
             float v[8];
             *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS_LD + col);
             *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS_LD + col + 4);
-            epi(gm, gn, v, z);
+            epi(gm, gn + p.n_off, v, z);
         }
     }
 }
@@ -2076,10 +2078,12 @@ struct GemmEnv {
     // MAPDIT_KEEP = bit mask of epilogue outputs that leave by plain instead of non-temporal stores (they are the next kernel's
     // operand): 1 RESID xm, 2 STORE_BF16 out, 4 QKV_HEADS q^ k^ v, 8 SILU2_GRAD act, 16 MUL_AUX out; 32: RESID xout NON-temporal
     int keep_mask = 1;
+    int nsplit = 1;          // MAPDIT_GEMM_NSPLIT = 0: no column split of results whose width is an odd multiple of 128
     int w3 = 0;              // MAPDIT_GEMM_W3 = 1 (experiment builds only): the three-deep A ring variant of the round-4 kernel
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_KEEP")) keep_mask = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_NSPLIT")) nsplit = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_W3")) w3 = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
@@ -2141,8 +2145,29 @@ template <> constexpr bool kHasTail<EpiStoreF32> = true;
 
 template <class Epi>
 int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, Epi epi,
-           hipStream_t st, int split_k = 1) {
+           hipStream_t st, int split_k = 1, int n_off = 0, bool force128 = false) {
     const bool a_kmaj = layout == MAPDIT_TN, b_kmaj = layout != MAPDIT_NT;
+    // Round 4: a result whose width is an odd multiple of 128 (DiT-XL: 1152) on few enough rows that the 256^2 tiles of its first
+    // N - 128 columns are ONE round of the chip (DiT-XL/2 at 64 samples: 64 x 4 = 256 tiles; with the half-empty fifth tile column it was
+    // 320 tiles, which the tile rule gave to the 128^2 kernel): two launches, the 256^2 kernel on the first N - 128 columns and the 128^2
+    // kernel on the last 128 (same epilogue object: it indexes by absolute column, the second launch hands it n + N - 128; B points at that
+    // column block).  DiT-XL/2 at 64 samples: 76.3 -> 74.5 ms.  NOT for tall results: at 65,536 rows the second launch re-streams the whole
+    // A operand for 128 columns (DiT-S/2 19.9 -> 20.1 ms, DiT-XL/2 sampling 62.8 -> 64.3 ms with the split everywhere).
+    // MAPDIT_GEMM_NSPLIT=0 switches it off (A/B).
+    if constexpr (!kReduce<Epi>) {
+        if (!force128 && n_off == 0 && split_k == 1 && gemm_env().nsplit && N % 256 == 128 && N >= 384 && K % BKT == 0 &&
+            gemm_env().tile != 128 && M >= 512 && (long)cdiv(M, 256) * ((N - 128) / 256) >= 192 &&
+            (long)cdiv(M, 256) * ((N - 128) / 256) <= 256 && !(((uintptr_t)A | (uintptr_t)B) & 15) &&
+            lda % 8 == 0 && ldb % 8 == 0) {
+            const int N1 = N - 128;
+            const bf16_t* B2 = b_kmaj ? B + N1 : B + (size_t)N1 * ldb;
+            if (!(((uintptr_t)B2) & 15)) {
+                const int rc = launch(layout, M, N1, K, A, lda, B, ldb, epi, st, 1, 0, false);
+                if (rc != MAPDIT_OK) return rc;
+                return launch(layout, M, 128, K, A, lda, B2, ldb, epi, st, 1, N1, true);
+            }
+        }
+    }
     // K % 64 != 0 (zero-sourced K tail) is compiled for the fp32-store epilogue only: that is where such shapes occur (weight
     // gradients over a batch that is not a multiple of 64, the bf16x3 path); the hot instantiations carry no tail check
     const bool ktail = K % BKT != 0;
@@ -2162,8 +2187,8 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         mapdit_set_error("gemm: split_k=%d needs the MFMA path and split_k <= ceil(K/64) (K=%d)", split_k, K);
         return MAPDIT_ERR_ARG;
     }
-    if (mfma && mapdit_gemm_tile_size_k(M, N, K, split_k > 1) == 256) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2};
+    if (mfma && !force128 && mapdit_gemm_tile_size_k(M, N, K, split_k > 1) == 256) {
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2, 0};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
         p.phases = gemm_env().phases;
         // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
@@ -2260,7 +2285,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             go(std::false_type(), T2());
         }
     } else if (mfma) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4, n_off};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;
         if constexpr (kHasTail<Epi>) {

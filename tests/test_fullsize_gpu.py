@@ -34,7 +34,11 @@ def small_ints(shape, lo, hi, seed):
                                           (1, M_FULL, D, HM),        # fc1 dX        [M,4D] x [4D,D]
                                           (1, M_FULL, HM, D),        # fc2 dX        [M,D] x [D,4D]
                                           (2, HM, D, M_FULL),        # fc1 dW        [M,4D]^T x [M,D], K = 65,536 tokens, split-K
-                                          (2, D, D, M_FULL)])        # proj dW
+                                          (2, D, D, M_FULL),         # proj dW
+                                          # widths that are odd multiples of 128 (DiT-S: 384, DiT-XL: 1152): two launches, the 256^2
+                                          # kernel on the first N - 128 columns and the 128^2 kernel on the last 128 (round 4)
+                                          (0, M_FULL, 384, 1536), (1, M_FULL, 384, 1536), (0, 16384, 1152, 1152), (1, 16384, 1152, 4608),
+                                          (0, M_FULL, 1152, 384)])
 def test_gemm_exact_on_small_integers_at_full_size(L, layout, m, n, k):
     """Operands in {-2..2} x {-1,0,1}: every product and every partial sum is an integer below 2^24, so fp32 accumulation is
     exact in ANY order and the result must equal torch's fp32 matmul bit for bit - over all 65,536 rows, every tile, every
