@@ -2124,6 +2124,9 @@ extern "C" int mapdit_gemm_tile_size_k(int M, int N, int K, int split_k_launch) 
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     if (split_k_launch) {
         if (t256 < 12) return 128;
+        // round 4: both edges odd multiples of 128 (DiT-XL's [1152, 1152] weight gradients: 25 tiles of 256^2 for 20.25 tiles of
+        // work) - below 85 % useful tile area the 128^2 kernel wins (796 vs 669 TFLOP/s; [4608, 1152] at 90 %: 910 vs 889, left alone)
+        if (!gemm_env().old_tile_rule && (double)M * N < 0.85 * (double)t256 * 65536.0) return 128;
         if (K > 0 && !gemm_env().old_tile_rule) {
             const long slabs = 256 / t256 > 0 ? 256 / t256 : 1;
             if ((K / 64) / slabs < 24) return 128;
