@@ -87,6 +87,8 @@ struct mapdit_engine {
     int ldm;                              // = L*6D
     bf16_t* xmodf;
     // backward scratch
+    bf16_t *DXa16 = nullptr, *DXb16 = nullptr;   // fp16 engine: the block-to-block gradient stream in 16 bits (dx16)
+    bool dx16 = false;
     float *G, *DXa, *DXb, *dmod, *dfmod, *dcs, *dcd, *dtable, *delta, *gain_part, *dref_part, *rmb_part = nullptr;
     bf16_t *dy, *dh, *dxm, *dO, *dqn, *dkn, *dv, *dqkv, *dlin, *da_bf, *dmod_bf, *dx0_bf, *dtemb_bf, *dh1_bf;
     size_t zero_bytes_dlin;
@@ -277,6 +279,8 @@ size_t carve(mapdit_engine* e, void* base) {
         e->G_cap = (long)gmax;
         e->DXa = cv.take<float>(M * D);
         e->DXb = cv.take<float>(M * D);
+        e->DXa16 = (bf16_t*)e->DXa;                       // (the 16-bit stream of the fp16 engine lives in the same buffers)
+        e->DXb16 = (bf16_t*)e->DXb;
         e->dmod = cv.take<float>((size_t)L * N * e->MW);
         e->dfmod = cv.take<float>((size_t)N * 2 * D);
         e->dcs = cv.take<float>((size_t)N * D);
@@ -366,6 +370,10 @@ void init_dims(mapdit_engine* e) {
     const int D = c.hidden;
     e->rot = c.rotation != 0;
     e->f16 = c.precision == MAPDIT_PREC_F16;
+    {   // fp16 engine: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream of the bf16 engine, for A/B runs)
+        const char* v = getenv("MAPDIT_DX16");
+        e->dx16 = e->f16 && !(v && v[0] == '0');
+    }
     e->MW = (e->rot ? 5 : 6) * D;
     if (e->rot) { e->o_sha = 0; e->o_sca = D / 2; e->o_ga = D / 2 + D; e->o_shm = D / 2 + 2 * D; e->o_scm = 3 * D; e->o_gm = 4 * D; }
     else { e->o_sha = 0; e->o_sca = D; e->o_ga = 2 * D; e->o_shm = 3 * D; e->o_scm = 4 * D; e->o_gm = 5 * D; }
@@ -480,7 +488,7 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
                                 e->gain_part, e->ginv, a.n_samples, D, st));
         return mapdit_reduce_partials(e->gain_part, a.n_samples * cdiv(D / 2, 256), dgain, 0, st);
     }
-    if (!no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
+    if (!no_fuse && !e->dx16 && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
         a.dxm = nullptr;
@@ -1126,7 +1134,8 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         a.ldmod = 2 * D; a.dshift = e->dfmod; a.dscale = e->dfmod + D; a.ldd = 2 * D; a.dgain_part = e->gain_part;
         a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * e->MW + e->o_gm; a.ldg_up = e->ldm; a.dy_up = e->dy;
         a.dg_up = e->dmod + (size_t)(L - 1) * e->MW + e->o_gm; a.ldd_up = e->ldm;
-        a.dx = e->DXa; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+        if (e->dx16) a.dx_bf = e->DXa16; else a.dx = e->DXa;
+        a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
         TRY(dx_resid_mod_bwd(e, M, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), a, G(MAPDIT_P_F_GAIN), st));
     }
     TRY(to16(e, e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
@@ -1154,11 +1163,13 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_FC1), e->dh, Hm, b.xm2, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXa; a.x = e->X[2 * i + 1]; a.shift = sh_m; a.scale = sc_m;
+            if (e->dx16) a.dxo_bf = e->DXa16; else a.dxo = e->DXa;
+            a.x = e->X[2 * i + 1]; a.shift = sh_m; a.scale = sc_m;
             a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldn;
             a.dshift = dmod + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
             a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
-            a.dx = e->DXb; a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+            if (e->dx16) a.dx_bf = e->DXb16; else a.dx = e->DXb;
+            a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
             const RotBwd rb{mod + e->o_shm, mod + e->o_scm, dmod + e->o_shm, dmod + e->o_scm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
             TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st,
                                  e->rot ? &rb : nullptr));
@@ -1175,14 +1186,15 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_QKV), e->dqkv, 3 * D, b.xm, D, M, 1.f, st));
         {
             mapdit_resid_mod_bwd_t a; memset(&a, 0, sizeof(a));
-            a.dxo = e->DXb; a.x = e->X[2 * i]; a.shift = sh_a; a.scale = sc_a;
+            if (e->dx16) a.dxo_bf = e->DXb16; else a.dxo = e->DXb;
+            a.x = e->X[2 * i]; a.shift = sh_a; a.scale = sc_a;
             a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]; a.ldmod = ldn;
             a.dshift = dmod + e->o_sha; a.dscale = dmod + e->o_sca; a.ldd = ldm; a.dgain_part = e->gain_part;
             if (i > 0) {
                 const BlockBufs& bp = e->blk[i - 1];
                 a.y_up = bp.y2; a.g_up = mod - e->MW + e->o_gm; a.ldg_up = ldm; a.dy_up = e->dy;     // gate_mlp of block i-1
                 a.dg_up = dmod - e->MW + e->o_gm; a.ldd_up = ldm;
-                a.dx = e->DXa;
+                if (e->dx16) a.dx_bf = e->DXa16; else a.dx = e->DXa;
             } else {
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
             }

@@ -55,6 +55,7 @@ struct RmbP {
     // gridDim.z > 1: each block handles T / gridDim.z rows and parks its column sums in `part` ([z][sample][3][D]) and its gain
     // partial in dgain_part[(z * samples + n) * D/128 + column block]; rmb_finish_kernel adds the z slices in order
     float* part;
+    const bf16_t* dxo16;              // the downstream gradient as a 16-bit tensor (instead of dxo)
 };
 
 // ROT: the rotation form (compile-time: the AdaLN form's loop carries no trace of it).  CL: column lanes of 4 columns each; a
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
         if (p.dxo) {
             float4 v = *(const float4*)(p.dxo + off);
             dx[0] = p.ca * v.x; dx[1] = p.ca * v.y; dx[2] = p.ca * v.z; dx[3] = p.ca * v.w;
+        } else if (p.dxo16) {
+            const uint2 u = *(const uint2*)(p.dxo16 + off);
+            dx[0] = p.ca * lo16(u.x); dx[1] = p.ca * hi16(u.x); dx[2] = p.ca * lo16(u.y); dx[3] = p.ca * hi16(u.y);
         }
         if (p.dxm) {
             uint2 u = *(const uint2*)(p.dxm + off);
@@ -409,7 +413,8 @@ extern "C" int MD_SYM(modulate_fwd)(const float* x, const float* shift, const fl
 extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stream) {
     MD_CHECK(a, "resid_mod_bwd: null argument");
     MD_CHECK(a->D % 128 == 0, "resid_mod_bwd: D=%d must be a multiple of 128", a->D);
-    MD_CHECK(a->dxo || a->dxm, "resid_mod_bwd: need dxo and/or dxm");
+    MD_CHECK(a->dxo || a->dxo_bf || a->dxm, "resid_mod_bwd: need dxo (or dxo_bf) and/or dxm");
+    MD_CHECK(!(a->dxo && a->dxo_bf), "resid_mod_bwd: dxo and dxo_bf are alternatives");
     MD_CHECK(!a->dxm || (a->x && a->shift && a->scale && a->gain && a->dshift && a->dscale && a->dgain_part),
              "resid_mod_bwd: modulate backward needs x, shift, scale, gain, dshift, dscale, dgain_part");
     MD_CHECK(!a->y_up || (a->g_up && a->dy_up && a->dg_up), "resid_mod_bwd: residual backward needs g_up, dy_up, dg_up");
@@ -420,6 +425,7 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
     p.ldmod = a->ldmod; p.ldg_up = a->ldg_up; p.ldd = a->ldd; p.ldd_up = a->ldd_up; p.T = a->T; p.D = a->D; p.ca = a->ca; p.cb = a->cb;
     p.gscale = a->dgain_scale != 0.f ? a->dgain_scale : 1.f;
     p.rot = a->rot;
+    p.dxo16 = (const bf16_t*)a->dxo_bf;
     // Small batches: one block per (sample, 128 columns) is too few blocks to stream at the HBM rate (32 samples x 6 = 192 blocks:
     // 60 us for 25 us of traffic).  With scratch given, the rows of a sample are cut into Z pieces (grid z), the column sums
     // parked per piece and added in order by a second small kernel; the gain partials simply become Z times as many.

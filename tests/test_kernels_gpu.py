@@ -398,6 +398,25 @@ def test_modulate_and_fused_backward(L):
     assert torch.equal(dx2, dx) and torch.equal(dy2, dy)      # per-element work does not depend on the split
     assert rel_err(dmod2.cpu().numpy(), mm.grad.numpy()) < 1e-5 and rel_err(dmod_up2.cpu().numpy(), mu.grad.numpy()) < 1e-5
     assert abs(dgain2.item() - gg.grad.item()) < 1e-4 * abs(gg.grad.item()) + 1e-5
+    # round 4: the downstream gradient as a 16-bit tensor (dxo_bf; the fp16 engine's block-to-block gradient stream).  Given the
+    # 16-bit rounding of dxo it must produce the bits the fp32 form produces from those rounded values; and the two are alternatives.
+    dxo16 = dxod.to(MODE["dt"])
+    dxr = dxo16.float().contiguous()
+    outs = []
+    for form in ("fp32 of the rounded values", "16-bit"):
+        dxf, dyf, dmf = torch.zeros_like(dx), torch.zeros_like(dy), torch.zeros_like(dmod)
+        a.part_scratch, a.part_scratch_bytes, a.gain_partials_out = None, 0, None
+        a.dxo, a.dxo_bf = (p(dxr), None) if form.startswith("fp32") else (None, p(dxo16))
+        a.dgain_part, a.dx, a.dy_up = p(part), p(dxf), p(dyf)
+        a.dshift, a.dscale = dmf.data_ptr() + 4 * 3 * D, dmf.data_ptr() + 4 * 4 * D
+        L.lib().resid_mod_bwd(C.byref(a), st())
+        torch.cuda.synchronize()
+        outs.append((dxf, dyf, dmf))
+    for u_, v_ in zip(*outs):
+        assert torch.equal(u_, v_)
+    a.dxo = p(dxr)
+    with pytest.raises(L.MapditError):
+        L.lib().resid_mod_bwd(C.byref(a), st())
 
 
 @pytest.mark.parametrize("N,T,D,K,layout,with_up,with_dxo", [(2, 256, 256, 128, 1, True, True), (8, 64, 512, 192, 1, True, True),
