@@ -213,8 +213,8 @@ typedef struct {
     float dgain_scale;
     /* optional (abi 4): the downstream gradient as a 16-bit tensor instead of dxo (exactly one of the two may be given).  With dx_bf as
      * the output this makes the gradient that travels from block to block a 16-bit stream (14 instead of 18 B/element of this pass):
-     * the fp16 engine runs it that way - its gradients carry the loss scale, and every one of them is rounded to fp16 as a GEMM operand
-     * anyway.  The bf16 engine keeps the fp32 stream (8 significant bits per residual step would not do). */
+     * the bf16 and fp16 engines run it that way (fp16: the gradients carry the loss scale) - every activation gradient is rounded to the
+     * operand format as a GEMM operand anyway; measured gradient error against the reference +1 %. */
     const uint16_t* dxo_bf;
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);

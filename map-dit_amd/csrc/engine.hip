@@ -370,9 +370,9 @@ void init_dims(mapdit_engine* e) {
     const int D = c.hidden;
     e->rot = c.rotation != 0;
     e->f16 = c.precision == MAPDIT_PREC_F16;
-    {   // fp16 engine: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream of the bf16 engine, for A/B runs)
+    {   // 16-bit engines: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream, for A/B runs; =f: fp16 engine only)
         const char* v = getenv("MAPDIT_DX16");
-        e->dx16 = e->f16 && !(v && v[0] == '0');
+        e->dx16 = c.precision != MAPDIT_PREC_BF16X3 && !(v && v[0] == '0') && (e->f16 || !(v && v[0] == 'f'));
     }
     e->MW = (e->rot ? 5 : 6) * D;
     if (e->rot) { e->o_sha = 0; e->o_sca = D / 2; e->o_ga = D / 2 + D; e->o_shm = D / 2 + 2 * D; e->o_scm = 3 * D; e->o_gm = 4 * D; }
