@@ -192,7 +192,7 @@ class _Runtime:
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
                             mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
                             precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)),
-                            loss_scale=float(getattr(model, "_loss_scale", 0.0)) if precision == "f16" else 0.0)
+                            loss_scale=float(getattr(model, "loss_scale", 0.0)) if precision == "f16" else 0.0)
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
             raise L.MapditError(f"unsupported DiT configuration: {lib.last_error().decode()}")
@@ -417,7 +417,7 @@ class DiT(nn.Module):
     # backward from the batch size.  Assigning it reaches the engines that already exist (mapdit_engine_set_loss_scale).
     @property
     def loss_scale(self) -> float:
-        return self._loss_scale
+        return self.__dict__.get("_loss_scale", self.__dict__.get("loss_scale", 0.0))      # (objects pickled before round 4 carry the plain attribute)
 
     @loss_scale.setter
     def loss_scale(self, value):
@@ -434,7 +434,7 @@ class DiT(nn.Module):
         """The loss scale the most recent fp16 backward ran with (the automatic choice resolved); 1.0 before any backward."""
         rt = self._rt.get(("f16", True))
         if rt is None:
-            return self._loss_scale or 1.0
+            return self.loss_scale or 1.0
         out = C.c_float()
         rt.lib.engine_loss_scale(rt.handle, C.byref(out))
         return float(out.value)
@@ -542,7 +542,7 @@ class DiT(nn.Module):
         for p_new, p_old in zip(new.parameters(), self.parameters()):
             p_new.requires_grad_(p_old.requires_grad)
         new.train(self.training)
-        new.gemm_precision, new._loss_scale = self.gemm_precision, self._loss_scale
+        new.gemm_precision, new._loss_scale = self.gemm_precision, self.loss_scale
         return new
 
     def __getstate__(self):
