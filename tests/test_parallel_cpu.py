@@ -69,6 +69,37 @@ def test_gloo_world2_reducer_and_dp_invariant():
     assert ret["dp_err"] < 1e-5
 
 
+def _verify_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import mapdit_amd  # noqa: F401
+    from mapdit_amd.parallel import _range_checksum, _verify_gather, init_from_env
+    init_from_env(backend="gloo")
+    per = 1000
+    whole = torch.arange(world * per, dtype=torch.float32) * 0.5
+    mine = whole[rank * per:(rank + 1) * per]
+    before = _range_checksum(mine)
+    _verify_gather(whole, per, world, before, None)                # an intact gather passes on every rank
+    if rank == 1:
+        whole[3] += 1.0                                            # rank 1's COPY of rank 0's range arrives corrupted; rank 0's copy is fine
+    try:
+        _verify_gather(whole, per, world, before, None)
+        ret[rank] = "passed"
+    except RuntimeError as e:
+        ret[rank] = str(e)
+    dist.barrier()                                                 # nobody is left hanging in a collective
+    dist.destroy_process_group()
+
+
+def test_gather_verification_raises_on_every_rank_together():
+    """parallel._verify_gather: a corruption that only ONE receiver sees must raise on EVERY rank - the verdict is
+    all-reduced - naming the bad range; otherwise the healthy ranks would run into their next collective and hang there."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_verify_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert "ranges of ranks [0]" in ret[0] and "ranges of ranks [0]" in ret[1], dict(ret)
+
+
 def test_bucket_slices_and_shards():
     import mapdit_amd  # noqa: F401
     from mapdit_amd.parallel import bucket_slices, shard_batch
