@@ -468,10 +468,15 @@ struct RotBwd {
 };
 int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy, const bf16_t* wimg, mapdit_resid_mod_bwd_t& a,
                      float* dgain, void* st, const RotBwd* rot = nullptr) {
-    // The fused form (MAPDIT_EPI_RMB) is opt-in (MAPDIT_FUSED_RMB=1): with one workgroup per CU the epilogue's ~16 B/element of
-    // residual-stream traffic is serialised with the tile's K loop, while the separate pass streams at 5.3 TB/s; measured on one box,
-    // fused vs separate: 16.97 vs 16.75 ms (64 samples), 28.48 vs 28.17 (128), equal at 256.
-    static const bool no_fuse = [] { const char* v = getenv("MAPDIT_FUSED_RMB"); return !(v && v[0] == '1'); }();
+    // The fused form (MAPDIT_EPI_RMB: the pass below as the dX GEMM's epilogue).  With fp32 gradient streams it was a wash (round 2:
+    // equal at 256 samples, 1-2 % slower at 64 / 128 - the epilogue's 16 B/element of residual-stream traffic is serialised with the
+    // tile's K loop) and stayed opt-in.  With the 16-bit stream of round 4 the fused epilogue moves 12 B/element where GEMM store +
+    // separate pass move 16, and wins at every size it applies to (bf16 step at 256 / 128 / 64 samples, same box: 45.10 -> 44.43,
+    // 25.59 -> 25.38, 15.00 -> 14.75 ms): default for the engines that run the 16-bit stream.  MAPDIT_FUSED_RMB=0 switches it off,
+    // =1 switches it on for fp32 streams up to 32,768 rows (round 2's form), =2 without the row limit.
+    static const int fuse_env = [] { const char* v = getenv("MAPDIT_FUSED_RMB"); return v ? (v[0] - '0') : -1; }();
+    const bool no_fuse = fuse_env == 0 || (fuse_env < 0 && !e->dx16);
+    const bool any_m = fuse_env == 2 || (fuse_env < 0 && e->dx16);
     const int D = e->D;
     int npart = 0;
     a.part_scratch = e->rmb_part;                       // lets small batches take the row-split form (more blocks)
@@ -488,7 +493,7 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
                                 e->gain_part, e->ginv, a.n_samples, D, st));
         return mapdit_reduce_partials(e->gain_part, a.n_samples * cdiv(D / 2, 256), dgain, 0, st);
     }
-    if (!no_fuse && !e->dx16 && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && M <= 32768 && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
+    if (!no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && (M <= 32768 || any_m) && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
         a.dxm = nullptr;

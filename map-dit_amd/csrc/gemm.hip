@@ -434,12 +434,14 @@ struct EpiDSilu {
 // A 256-row tile holds whole 64-row blocks (T % 64 == 0), each inside one sample: the per-sample column sums are sums over a
 // thread's four rows of a block, then over the 16 threads that share its columns (one xor-shuffle + eight LDS rows), then over
 // the blocks of the sample - all in a fixed order: no atomics, bit-reproducible.
-struct EpiRmb {
+// DX16 (round 4): the downstream gradient arrives as a 16-bit tensor (dxo16; the block-to-block gradient stream of the 16-bit engines)
+template <bool DX16> struct EpiRmbT {
+    const bf16_t* dxo16;
     const float* dxo; const float* x; const float* shift; const float* scale; const float* gain;
     const bf16_t* y_up; const float* g_up;
     float* dx; bf16_t* dx_bf; bf16_t* dy_up; float* dshift; float* dscale; float* dg_up; float* dgain_part;
     int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb, gscale;
-    struct Aux { float4 x0, x1, d0, d1; u32x4_t y; };
+    struct Aux { float4 x0, x1, d0, d1; u32x4_t y, d16; };
     struct Tile { float4 sc0, sc1, sh0, sh1, gu0, gu1; };
     struct Acc { float sc[8], sh[8], g[8], gain; };    // running sums of the current 64-row block (gain: of the whole tile)
     __device__ __forceinline__ void coef(float& k, float& kb, float& kd) const {
@@ -464,7 +466,10 @@ struct EpiRmb {
         const float4* xi = (const float4*)(x + (size_t)m * ldo + n);
         a.x0 = xi[0]; a.x1 = xi[1];
         a.d0 = a.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dxo) {
+        a.d16 = u32x4_t{0u, 0u, 0u, 0u};
+        if constexpr (DX16) {
+            if (dxo16) a.d16 = *(const u32x4_t*)(dxo16 + (size_t)m * ldo + n);
+        } else if (dxo) {
             const float4* di = (const float4*)(dxo + (size_t)m * ldo + n);
             a.d0 = di[0]; a.d1 = di[1];
         }
@@ -475,7 +480,11 @@ struct EpiRmb {
     __device__ __forceinline__ void apply_r(int m, int n, const float* v, const Aux& a, const Tile& t, Acc& r, float k, float kb,
                                             float kd) const {
         const float xx[8] = {a.x0.x, a.x0.y, a.x0.z, a.x0.w, a.x1.x, a.x1.y, a.x1.z, a.x1.w};
-        const float dd[8] = {a.d0.x, a.d0.y, a.d0.z, a.d0.w, a.d1.x, a.d1.y, a.d1.z, a.d1.w};
+        float dd[8] = {a.d0.x, a.d0.y, a.d0.z, a.d0.w, a.d1.x, a.d1.y, a.d1.z, a.d1.w};
+        if constexpr (DX16) {
+            dd[0] = lo16(a.d16.x); dd[1] = hi16(a.d16.x); dd[2] = lo16(a.d16.y); dd[3] = hi16(a.d16.y);
+            dd[4] = lo16(a.d16.z); dd[5] = hi16(a.d16.z); dd[6] = lo16(a.d16.w); dd[7] = hi16(a.d16.w);
+        }
         const float sc[8] = {t.sc0.x, t.sc0.y, t.sc0.z, t.sc0.w, t.sc1.x, t.sc1.y, t.sc1.z, t.sc1.w};
         const float sh[8] = {t.sh0.x, t.sh0.y, t.sh0.z, t.sh0.w, t.sh1.x, t.sh1.y, t.sh1.z, t.sh1.w};
         float o[8];
@@ -484,7 +493,7 @@ struct EpiRmb {
             // the unfused path sees this gradient as a bf16 tensor: round it the same way, so that a sample's gradients do not
             // depend on which path its batch size selects
             const float vi = up16(cvt16(v[i]));
-            o[i] = ca * dd[i] + k * sc[i] * vi;
+            o[i] = __builtin_fmaf(k * sc[i], vi, ca * dd[i]);     // (spelled out: the same rounding as resid_mod_bwd_kernel, whichever the batch size selects)
             r.sc[i] += k * xx[i] * vi;
             r.sh[i] += kb * vi;
             r.gain += vi * (sh[i] - xx[i] * sc[i]) * kd;
@@ -515,7 +524,8 @@ struct EpiRmb {
     __device__ __forceinline__ void operator()(int, int, const float*, int = 0) const {}
 };
 template <class Epi> constexpr bool kReduce = false;
-template <> constexpr bool kReduce<EpiRmb> = true;
+template <> constexpr bool kReduce<EpiRmbT<false>> = true;
+template <> constexpr bool kReduce<EpiRmbT<true>> = true;
 
 // QKV projection with the head split and the cosine normalisation of q, k fused in.  Every kernel above hands the 8
 // chunks of one 64-column head segment of a row to 8 consecutive lanes, so the per-head sum of squares is three
@@ -2384,10 +2394,16 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             MD_CHECK(a->T > 0 && a->T % 64 == 0 && 256 % a->T == 0 && M % a->T == 0 && N == a->D,
                      "gemm: RMB needs T in {64, 128, 256}, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
             MD_CHECK(a->ldmod % 4 == 0 && a->ldg_up % 4 == 0 && e->ldo % 8 == 0, "gemm: RMB row strides must be multiples of 4 / 8");
+            MD_CHECK(!(a->dxo && a->dxo_bf), "gemm: RMB: dxo and dxo_bf are alternatives");
+            if (a->dxo_bf)
+                return launch(layout, M, N, K, A, lda, B, ldb,
+                              EpiRmbT<true>{(const bf16_t*)a->dxo_bf, nullptr, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx,
+                                            (bf16_t*)a->dx_bf, (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod,
+                                            a->ldg_up, a->ldd, a->ldd_up, a->T, a->ca, a->cb, a->dgain_scale != 0.f ? a->dgain_scale : 1.f}, st);
             return launch(layout, M, N, K, A, lda, B, ldb,
-                          EpiRmb{a->dxo, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx, (bf16_t*)a->dx_bf,
-                                 (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod, a->ldg_up, a->ldd,
-                                 a->ldd_up, a->T, a->ca, a->cb, a->dgain_scale != 0.f ? a->dgain_scale : 1.f}, st);
+                          EpiRmbT<false>{nullptr, a->dxo, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx, (bf16_t*)a->dx_bf,
+                                         (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod, a->ldg_up, a->ldd,
+                                         a->ldd_up, a->T, a->ca, a->cb, a->dgain_scale != 0.f ? a->dgain_scale : 1.f}, st);
         }
         case MAPDIT_EPI_QKV_HEADS: {
             MD_CHECK(e->out2 && e->out3 && e->out4 && e->rows_per_sample > 0, "gemm: QKV_HEADS needs out2, out3, out4, rows_per_sample");

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
             } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                dx[i] += k * scv[i] * dm[i];
+                dx[i] = __builtin_fmaf(k * scv[i], dm[i], dx[i]);           // (spelled out: the same rounding as the fused GEMM epilogue, EpiRmbT)
                 a_sc[i] += k * xx[i] * dm[i];
                 a_sh[i] += kb * dm[i];
                 a_gain += dm[i] * (shv[i] - xx[i] * scv[i]) * kd;

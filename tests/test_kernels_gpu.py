@@ -492,6 +492,41 @@ def test_gemm_fused_resid_mod_backward(L, N, T, D, K, layout, with_up, with_dxo)
         L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
         torch.cuda.synchronize()
         assert torch.equal(dx, dx2) and torch.equal(dmod, dmod2)
+        # round 4: the downstream gradient as a 16-bit tensor (dxo_bf: what the 16-bit engines' fused backward runs on) gives the bits
+        # of the fp32 form on the same rounded values, and the bits of the UNFUSED pass (mapdit_resid_mod_bwd on the stored GEMM result)
+        if with_dxo:
+            dxo16 = dxod.to(MODE["dt"])
+            dxr = dxo16.float().contiguous()
+            res = []
+            for form in ("fp32 of the rounded values", "16-bit"):
+                dxf, dxbf_f, dmf, dyf = torch.zeros_like(dx), torch.zeros_like(dxbf), torch.zeros_like(dmod), torch.zeros_like(dy)
+                a.dxo, a.dxo_bf = (p(dxr), None) if form.startswith("fp32") else (None, p(dxo16))
+                a.dx, a.dx_bf = p(dxf), p(dxbf_f)
+                a.dshift, a.dscale = dmf.data_ptr() + 4 * 3 * D, dmf.data_ptr() + 4 * 4 * D
+                if with_up:
+                    a.dy_up = p(dyf)
+                L.lib().gemm_bf16(layout, M, D, K, p(ad), K, p(bd), D if layout == 1 else K, C.byref(e), st())
+                torch.cuda.synchronize()
+                res.append((dxf, dxbf_f, dmf[:, 3 * D:5 * D].clone(), dyf))
+            for u_, v_ in zip(*res):
+                assert torch.equal(u_, v_)
+            # the unfused pass on the bf16 GEMM result the fused epilogue sees
+            gm = torch.zeros(M, D, device=DEV, dtype=MODE["dt"])
+            run_gemm(L, layout, ad, bd, L.EPI_STORE_BF16, M, D, K, out=p(gm), ldo=D, alpha=1.0)
+            dxu, dmu, dyu = torch.zeros_like(dxbf), torch.zeros_like(dmod), torch.zeros_like(dy)
+            partu = torch.zeros(N * (D // 128) * 8, device=DEV)
+            a.dxm, a.dx, a.dx_bf, a.dgain_part = p(gm), None, p(dxu), p(partu)
+            a.dshift, a.dscale = dmu.data_ptr() + 4 * 3 * D, dmu.data_ptr() + 4 * 4 * D
+            if with_up:
+                a.dy_up = p(dyu)
+            L.lib().resid_mod_bwd(C.byref(a), st())
+            torch.cuda.synchronize()
+            assert torch.equal(dxu, res[1][1]) and torch.equal(dyu, res[1][3])                   # per-element work: the same bits
+            assert rel_err(dmu[:, 3 * D:5 * D].cpu().numpy(), res[1][2].cpu().numpy()) < 1e-6    # (column sums: another summation order)
+            a.dxm, a.dxo, a.dxo_bf, a.dx, a.dx_bf, a.dgain_part = None, p(dxod), None, p(dx), p(dxbf), p(part)
+            a.dshift, a.dscale = dmod.data_ptr() + 4 * 3 * D, dmod.data_ptr() + 4 * 4 * D
+            if with_up:
+                a.dy_up = p(dy)
     finally:
         L.lib().gemm_tuning(0, 2, 0)
     # shapes the 256x256 path does not take are refused, not mis-computed
