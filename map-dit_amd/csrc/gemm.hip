@@ -47,6 +47,7 @@ struct GemmP {
     int phases;     // 256^2 kernel: 4 = one output quadrant per phase (16 MFMAs), 2 = one half per phase (32 MFMAs)
     int n_off;      // 128^2 kernel: column offset handed to the epilogue (the launch covers columns [n_off, n_off + N) of a wider
                     // result whose first n_off columns another launch computes; B already points at that column block)
+    int stagger;    // 256^2 persistent kernels: every second workgroup of an XCD starts `stagger` x 8,128 cycles late (see stagger_start)
 };
 
 // Swizzle key of K-major row k.  One ds_read_b64_tr_b16 half-wave touches rows {8g+q, q = 0..3, g = 0..1} (then the
@@ -1404,6 +1405,16 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
     }   // !kReduce
 }
 
+// All workgroups of a persistent launch start together and every tile costs the same, so the chip alternates between "every CU in
+// its K loop" (HBM nearly idle) and "every CU in its epilogue" (HBM saturated, matrix pipes idle).  Half of the workgroups starting
+// late by about half a tile period interleaves the two populations.
+__device__ __forceinline__ void stagger_start(const GemmP& p) {
+    // stagger < 100: two populations; 100 + s: four populations, s units apart
+    const int pop = p.stagger >= 100 ? ((blockIdx.x >> 3) & 3) : ((blockIdx.x >> 3) & 1);
+    const int n = (p.stagger >= 100 ? p.stagger - 100 : p.stagger) * pop;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // Persistent form: the grid is at most one workgroup per CU; workgroup b takes the virtual workgroups b, b + grid, ... (b & 7 is its
 // XCD either way, so the band-major order keeps its meaning).  What it saves is the hand-over between two workgroups on a CU: the
 // dispatch of the next one waits for the previous one's stores to drain and its LDS to be released (3-7 k cycles per tile of
@@ -1419,6 +1430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
 #endif
     const int total = p.tiles * p.split_k;
+    stagger_start(p);
     for (int v = blockIdx.x; v < total; v += gridDim.x) {
         gemm256_tile<AK, BK, Epi, KTAIL, PH>(p, epi, smem, v, total);
         __syncthreads();                                   // the tile's last LDS reads are done before the next prologue lands
@@ -1575,6 +1587,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256w_kernel(GemmP p, Epi epi)
     const int total = p.tiles * p.split_k;
     int v = blockIdx.x;
     if (v >= total) return;
+    stagger_start(p);
     constexpr bool TR_ASM2 = AK == OP_KMAJ;                // transposing reads: asm for TN; NN keeps the builtin (see read_frag)
     TileCoord c = tile_coord(p, v, total);
     {
@@ -2090,11 +2103,13 @@ struct GemmEnv {
     int keep_mask = 1;
     int nsplit = 1;          // MAPDIT_GEMM_NSPLIT = 0: no column split of results whose width is an odd multiple of 128
     int w3 = 0;              // MAPDIT_GEMM_W3 = 1 (experiment builds only): the three-deep A ring variant of the round-4 kernel
+    int stagger = -1;        // MAPDIT_GEMM_STAGGER = late start of every second workgroup, units of 8,128 cycles (persistent launches); -1: by epilogue
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
         if (const char* e = getenv("MAPDIT_KEEP")) keep_mask = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_NSPLIT")) nsplit = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_W3")) w3 = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_STAGGER")) stagger = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
@@ -2201,7 +2216,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         return MAPDIT_ERR_ARG;
     }
     if (mfma && !force128 && mapdit_gemm_tile_size_k(M, N, K, split_k > 1) == 256) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2, 0};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN2), 0, split_k, 0, 2, 0, 0};
         p.tiles = cdiv(M, BM2) * p.tiles_n;
         p.phases = gemm_env().phases;
         // B sub-panel of one band = band * 256 columns * K * 2 bytes: keep it within ~2.5 MiB of the 4 MiB L2
@@ -2222,7 +2237,14 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         int grid = p.tiles * split_k;
         // one workgroup per CU looping over its tiles, from three rounds of the chip on (fewer: a static split of 1.5 rounds over
         // 256 workgroups only loses to the dispatcher: +0.05 ms on the step at 32 samples per GPU)
-        if (gemm_env().persist && grid >= 3 * gemm_env().persist) grid = gemm_env().persist;
+        if (gemm_env().persist && grid >= 3 * gemm_env().persist) {
+            grid = gemm_env().persist;
+            // RESID (10 B per result element of residual stream against 2 B for a plain store) is the launch whose epilogues are HBM
+            // bursts: isolated, same box, proj 153 -> 142 us and fc2 303 -> 298 us with two units (1, 3, 4, 6, 8 units and four
+            // populations: less or nothing); QKV heads, SiLU + derivative and the saved-factor product lose 1-5 % (VALU-bound
+            // epilogues: the late half just ends late).
+            p.stagger = gemm_env().stagger >= 0 ? gemm_env().stagger : (std::is_same<Epi, EpiResid>::value ? 2 : 0);
+        }
         auto go = [&](auto tail, auto ph) {
             constexpr bool TAIL = decltype(tail)::value;
             constexpr int PH = decltype(ph)::value;
@@ -2298,7 +2320,7 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             go(std::false_type(), T2());
         }
     } else if (mfma) {
-        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4, n_off};
+        GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4, n_off, 0};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;
         if constexpr (kHasTail<Epi>) {
