@@ -1249,6 +1249,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
         epi.coef(ck, ckb, ckd);
         float gain_acc = 0.f;
         float tot[2][2][3];                                    // [pass][half][dscale, dshift, dgate] of column n0 + tid (tid < 256)
+        typename Epi::Aux aux[4];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -1259,23 +1260,31 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                     const int col = wn * 64 + j * 16 + 4 * (lane >> 4);
                     *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
                 }
-            typename Epi::Acc r[2];
+            // One set of running sums at a time: block (pass, 0)'s leave for the 30 KiB of LDS behind the image as soon as the block is
+            // done (the image itself is still being read), block (pass, 1)'s for the image space after the barrier below.
+            typename Epi::Acc r;
+            float* const red0 = (float*)(smem + SMEM2_BYTES);      // [out][wave][256 columns] of half 0
+            float* const red = (float*)smem;                       // the same of half 1
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int mb = m0 + half * 128 + pass * 64;    // first row of this 64-row block
                 typename Epi::Tile tl;
-                typename Epi::Aux aux[4];
                 const bool blk_ok = col_ok && mb < p.M;
                 if (blk_ok) tl = epi.block_begin(mb, gn);
+                if (pass == 0 && half == 0) {                  // (every later block's operands are fetched under the block before it)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gm = mb + (tid >> 5) + 16 * q;
-                    if (blk_ok && gm < p.M) aux[q] = epi.load(gm, gn);
+                    for (int q = 0; q < 4; ++q) {
+                        const int gm = mb + (tid >> 5) + 16 * q;
+                        if (blk_ok && gm < p.M) aux[q] = epi.load(gm, gn);
+                    }
                 }
                 if (half == 0) __syncthreads();                // the image is complete
 #pragma unroll
-                for (int i = 0; i < 8; ++i) r[half].sc[i] = r[half].sh[i] = r[half].g[i] = 0.f;
-                r[half].gain = 0.f;
+                for (int i = 0; i < 8; ++i) r.sc[i] = r.sh[i] = r.g[i] = 0.f;
+                r.gain = 0.f;
+                // the block after this one in processing order: (pass, 1) after (pass, 0), (1, 0) after (0, 1)
+                const int mb_next = half == 0 ? mb + 128 : m0 + 64;
+                const bool next_ok = !(pass == 1 && half == 1) && col_ok && mb_next < p.M;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = half * 64 + (tid >> 5) + 16 * q;
@@ -1284,29 +1293,29 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                         float v[8];
                         *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + ecol);
                         *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
-                        epi.apply_r(gm, gn, v, aux[q], tl, r[half], ck, ckb, ckd);
+                        epi.apply_r(gm, gn, v, aux[q], tl, r, ck, ckb, ckd);
                     }
+                    // rolling prefetch: this slot's registers are free again - the same row of the next block goes there, so the
+                    // stream never drains between blocks and passes (round 4; one exposed memory latency per tile instead of four)
+                    const int gmn = mb_next + (tid >> 5) + 16 * q;
+                    if (next_ok && gmn < p.M) aux[q] = epi.load(gmn, gn);
                 }
-                gain_acc += r[half].gain;
+                gain_acc += r.gain;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {                  // the wave's two row groups
-                    r[half].sc[i] += __shfl_xor(r[half].sc[i], 32, 64);
-                    r[half].sh[i] += __shfl_xor(r[half].sh[i], 32, 64);
-                    r[half].g[i] += __shfl_xor(r[half].g[i], 32, 64);
+                    r.sc[i] += __shfl_xor(r.sc[i], 32, 64);
+                    r.sh[i] += __shfl_xor(r.sh[i], 32, 64);
+                    r.g[i] += __shfl_xor(r.g[i], 32, 64);
                 }
-            }
-            __syncthreads();                                   // every read of the image is done: its space holds the partials now
-            float* red = (float*)smem;                         // [half][out][wave][256 columns]
-            if (lane < 32) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float* base = red + ((half * 3) * 8 + wave) * 256 + ecol;
-                    *(float4*)(base) = make_float4(r[half].sc[0], r[half].sc[1], r[half].sc[2], r[half].sc[3]);
-                    *(float4*)(base + 4) = make_float4(r[half].sc[4], r[half].sc[5], r[half].sc[6], r[half].sc[7]);
-                    *(float4*)(base + 8 * 256) = make_float4(r[half].sh[0], r[half].sh[1], r[half].sh[2], r[half].sh[3]);
-                    *(float4*)(base + 8 * 256 + 4) = make_float4(r[half].sh[4], r[half].sh[5], r[half].sh[6], r[half].sh[7]);
-                    *(float4*)(base + 16 * 256) = make_float4(r[half].g[0], r[half].g[1], r[half].g[2], r[half].g[3]);
-                    *(float4*)(base + 16 * 256 + 4) = make_float4(r[half].g[4], r[half].g[5], r[half].g[6], r[half].g[7]);
+                if (half == 1) __syncthreads();                // every read of the image is done: its space holds half 1's partials
+                if (lane < 32) {
+                    float* base = (half == 0 ? red0 : red) + wave * 256 + ecol;
+                    *(float4*)(base) = make_float4(r.sc[0], r.sc[1], r.sc[2], r.sc[3]);
+                    *(float4*)(base + 4) = make_float4(r.sc[4], r.sc[5], r.sc[6], r.sc[7]);
+                    *(float4*)(base + 8 * 256) = make_float4(r.sh[0], r.sh[1], r.sh[2], r.sh[3]);
+                    *(float4*)(base + 8 * 256 + 4) = make_float4(r.sh[4], r.sh[5], r.sh[6], r.sh[7]);
+                    *(float4*)(base + 16 * 256) = make_float4(r.g[0], r.g[1], r.g[2], r.g[3]);
+                    *(float4*)(base + 16 * 256 + 4) = make_float4(r.g[4], r.g[5], r.g[6], r.g[7]);
                 }
             }
             __syncthreads();
@@ -1315,9 +1324,10 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                 for (int half = 0; half < 2; ++half)
 #pragma unroll
                     for (int o = 0; o < 3; ++o) {
+                        const float* src = half == 0 ? red0 : red;
                         float a = 0.f;
 #pragma unroll
-                        for (int w = 0; w < 8; ++w) a += red[((half * 3 + o) * 8 + w) * 256 + tid];
+                        for (int w = 0; w < 8; ++w) a += src[(o * 8 + w) * 256 + tid];
                         tot[pass][half][o] = a;
                     }
             }
@@ -1369,6 +1379,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
     const bool col_ok = gn < p.N;
     typename Epi::Tile tctx;
     if (col_ok) tctx = epi.tile_begin(m0, (m0 + BM2 <= p.M ? m0 + BM2 : p.M) - 1, gn);
+    typename Epi::Aux aux[8];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -1379,12 +1390,13 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                 const int col = wn * 64 + j * 16 + 4 * (lane >> 4);
                 *(f32x4_t*)(cs + row * CS2_LD + col) = acc[pass * 4 + i][j];
             }
-        typename Epi::Aux aux[8];                          // (after the accumulators of this pass are dead: register budget)
+        if (pass == 0) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {                   // the pass's stream operands: all in flight before the first use
-            const int row = (tid >> 5) + 16 * it;
-            const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
-            if (gm < p.M && col_ok) aux[it] = epi.load(gm, gn);
+            for (int it = 0; it < 8; ++it) {               // the pass's stream operands: all in flight before the first use
+                const int row = (tid >> 5) + 16 * it;      // (after the accumulators of this pass are dead: register budget)
+                const int gm = m0 + (row >> 6) * 128 + (row & 63);
+                if (gm < p.M && col_ok) aux[it] = epi.load(gm, gn);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -1397,6 +1409,9 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
                 *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
                 epi.apply(gm, gn, v, z, aux[it], tctx);
             }
+            // rolling prefetch (round 4): the slot is free again - pass 1's operands of the same row go there and land under the
+            // rest of pass 0 and the image writes of pass 1
+            if (pass == 0 && gm + 64 < p.M && col_ok) aux[it] = epi.load(gm + 64, gn);
         }
         __syncthreads();
         G256_TSTAMP(3 + pass);
@@ -1427,7 +1442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     constexpr int SM = PH != 2 ? SMEM_PH1 : SMEM2_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM + (PH != 2 ? 0 : (2 * STAMP_TILES * STAMP_POINTS + 8) * 8)];
 #else
-    __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : SMEM2_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[PH != 2 ? SMEM_PH1 : kReduce<Epi> ? SMEM2_BYTES + 3 * 8 * 256 * 4 : SMEM2_BYTES];
 #endif
     const int total = p.tiles * p.split_k;
     stagger_start(p);
@@ -2243,7 +2258,10 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             // bursts: isolated, same box, proj 153 -> 142 us and fc2 303 -> 298 us with two units (1, 3, 4, 6, 8 units and four
             // populations: less or nothing); QKV heads, SiLU + derivative and the saved-factor product lose 1-5 % (VALU-bound
             // epilogues: the late half just ends late).
-            p.stagger = gemm_env().stagger >= 0 ? gemm_env().stagger : (std::is_same<Epi, EpiResid>::value ? 2 : 0);
+            constexpr bool is_rmb = std::is_same<Epi, EpiRmbT<true>>::value || std::is_same<Epi, EpiRmbT<false>>::value;
+            const int sg = gemm_env().stagger;
+            p.stagger = sg >= 1000 ? (is_rmb ? sg - 1000 : std::is_same<Epi, EpiResid>::value ? 2 : 0)      // (A/B: 1000 + units for the RMB epilogue only)
+                        : sg >= 0 ? sg : (std::is_same<Epi, EpiResid>::value ? 2 : 0);
         }
         auto go = [&](auto tail, auto ph) {
             constexpr bool TAIL = decltype(tail)::value;
