@@ -45,6 +45,7 @@ def main():
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g).bfloat16()
     x, w_qkv, w_fc1, w_fc2 = rnd(M, D), rnd(3 * D, D) * 0.03, rnd(4 * D, D) * 0.03, rnd(D, 4 * D) * 0.03
     h, dy, dh = rnd(M, 4 * D), rnd(M, D), rnd(M, 4 * D)
+    dqkv = rnd(M, 3 * D)
     out_bf = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16)
     out_bf2 = torch.empty_like(out_bf)
     out_bf3 = torch.empty_like(out_bf)
@@ -66,6 +67,11 @@ def main():
         ("qkv  fwd NT heads", 0, M, 3 * D, D, x, D, w_qkv, D,
          ep(L.EPI_QKV_HEADS, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), out3=out_bf3.data_ptr(), out4=scales.data_ptr(),
             rows_per_sample=256, alpha=1.0)),
+        ("fc1  fwd NT store", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=4 * D, alpha=1.0)),
+        ("fc2  fwd NT store", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=D, alpha=1.0)),
+        ("proj fwd NT store", 0, M, D, D, x, D, w_qkv, D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=D, alpha=1.0)),
+        ("qkv  dX  NN store", 1, M, D, 3 * D, dqkv, 3 * D, w_qkv, D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=D, alpha=1.0)),
+        ("fc2  dX  NN store", 1, M, 4 * D, D, dy, D, w_fc2, 4 * D, ep(L.EPI_STORE_BF16, out=out_bf.data_ptr(), ldo=4 * D, alpha=1.0)),
         ("fc1  fwd NT silu2", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_SILU2, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), ldo=4 * D)),
         ("fc1  fwd NT silugrad", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_SILU2_GRAD, out=out_bf.data_ptr(), out2=out_bf2.data_ptr(), ldo=4 * D)),
         ("fc2  fwd NT resid", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D,
