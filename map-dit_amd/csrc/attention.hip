@@ -670,6 +670,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_bwd_fused_kernel(const bf16_
 // hoisted into registers that live across the whole kernel (hipcc hoisted ~30 such values here and spilled them to scratch - and
 // a scratch reload waits for vmcnt(0), i.e. for every prefetch in flight).
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }      // the same for a wave-uniform value
 #ifdef SB_STAMP        // A/B builds only (tools/build_probe.sh attention SB_STAMP 1): in-kernel time stamps of waves 0 and 4 of workgroup 0
 __device__ long long g_sb_stamps[2 * 8 * 8];
 #define SB_STAMP_AT(slot) do { if (blockIdx.x == 0 && (wave & 3) == 0 && t >= 16 && t < 24) { __builtin_amdgcn_sched_barrier(0); \
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
     // next head: K piece (4 of them, 64 rows each), the per-token scalars, this wave's V fragments
     u4v kp = {};
     float l1 = 0.f;
-    auto kpiece_issue = [&](int bh, int piece) { kp = gload<u4v>((const char*)kn + ((size_t)bh * T + 64 * piece) * 128, tid * 16); };
+    auto kpiece_issue = [&](int bh, int piece) { kp = gload<u4v>((const char*)kn + ((size_t)bh * T + 64 * piece) * 128, opaque(tid) * 16); };   // (opaque: see vf_issue)
     auto kpiece_commit = [&](int j, int piece) { *(u4v*)(ks_ + (j & 1) * KB + piece * 64 * 128 + o_kp) = kp; };
     // the per-token scalars in two steps of one register: lse (threads 0-255) and the q^ scales (256-511), then the k^ scales
     auto scal_issue = [&](int bh, int step) {
@@ -785,8 +786,11 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
     // V rows of this wave's keys as the B operand of dP = dO V^T, times the softmax scale (a power of two: exact), so that dS needs no
     // multiplication by it: dS = P (dP scale - delta scale)
     bf16x8_t vf[4];
-    const unsigned o_vf = (r * 64 + 8 * h2) * 2;
     auto vf_issue = [&](int bh) {                            // straight into the fragments: from the last dP product of a head on they are dead
+        // (the lane offset is formed here, from an opaque thread index: as a kernel-lifetime value hipcc added it to `v` once, kept the
+        // 64-bit lane pointer in scratch and reloaded it - with a wait for vmcnt(0) - in the middle of every head's last interval)
+        const int ln = opaque(tid) & 63;
+        const unsigned o_vf = ((ln & 31) * 64 + 8 * (ln >> 5)) * 2;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) vf[ks] = gload<bf16x8_t>((const char*)v + ((size_t)bh * T + k0) * 128 + 32 * ks, o_vf);
     };
@@ -926,8 +930,12 @@ __global__ __launch_bounds__(SB_NTH) void attn_bwd_stream_kernel(const bf16_t* _
         // reads is issued a step before the products that consume it.  The dQ products of tile t - 1 are independent of this tile's
         // chain S, dP -> P, dS -> dV, dK and fill its gaps; they run for t = 0 too (on whatever the images hold: never stored).
         const int tq = t - 1;                                // the tile whose dQ is formed
-        const unsigned qfr = OFF_Q + (t & 3) * TB + o_fr, dfr = OFF_DO + (t & 1) * TB + o_fr, kfr = (j & 1) * KB + k0 * 128 + o_fr;
-        const unsigned qtr = OFF_Q + (t & 3) * TB + o_tr, dtr = OFF_DO + (t & 1) * TB + o_tr;
+        // (in the LAST copy t & 3 and t & 1 are constants: hipcc then forms the twelve XOR variants of these addresses once, outside the
+        // head loop, and keeps them in scratch - a reload waits for vmcnt(0), i.e. for the tile prefetch; an opaque tile parity keeps
+        // them one add and one xor inside the interval)
+        const int t3 = LAST ? opaque_s(3) : (t & 3), t1 = LAST ? opaque_s(1) : (t & 1);
+        const unsigned qfr = OFF_Q + t3 * TB + o_fr, dfr = OFF_DO + t1 * TB + o_fr, kfr = (j & 1) * KB + k0 * 128 + o_fr;
+        const unsigned qtr = OFF_Q + t3 * TB + o_tr, dtr = OFF_DO + t1 * TB + o_tr;
         const char* dsa = dsb_ + (tq & 1) * DS_BYTES + o_dsa;
         const char* kqb = ks_ + ((tq >> 3) & 1) * KB + o_kqb;
         const char* kqb2 = ks_ + (((((tq >> 3) & 1) * KB + o_kqb) ^ 64) + 2048);
