@@ -202,6 +202,19 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float* v) {      // 
     v[6] = lo16(u.w); v[7] = hi16(u.w);
 }
 
+// Address of element (m, n) of a row-major stream.  U: m and n are wave-uniform (a tile row group, the tile's first column) and the
+// lane's own row / column offset arrives separately, in elements: scalar base + one 32-bit lane offset per access (the saddr form),
+// instead of a 64-bit lane pointer per row and stream - in the straight-line epilogues those filled the register file and spilled.
+template <bool U, class T> __device__ __forceinline__ T* rowptr(T* p, int m, int n, int ld, unsigned off) {
+    if constexpr (U) return (T*)((char*)(p + (size_t)m * ld + n) + (size_t)off * sizeof(T));
+    else return p + (size_t)m * ld + n;
+}
+// A wave-uniform value the optimiser cannot see through: what is computed from it stays where it is written.  (In the unrolled
+// straight-line epilogues hipcc otherwise forms the row bases of all 16 row groups and every stream at the top of the block - 100+
+// scalar registers, spilled through vector registers, spilled to scratch.)
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+template <class Epi> constexpr bool kUniformRows = false;   // the functor has load_u / apply_u (/ apply_r_u): see rowptr
+
 #define EPI_TRIVIAL_STEPS                                                                                      \
     typedef EpiNoAux Aux;                                                                                      \
     typedef EpiNoTile Tile;                                                                                    \
@@ -357,12 +370,34 @@ struct EpiResid {
         Aux a; a.x0 = xi[0]; a.x1 = xi[1];
         return a;
     }
+    // (host) every 256-row tile of an M % 256 == 0 result lies inside one sample; the store policies are the default ones
+    // and every optional output is there (the training forward of all blocks but the last): no test is left in the row body
+    bool fast_ok() const { return rows % 256 == 0 && xm_plain == 1 && y && xm && !rot; }
+    __device__ __forceinline__ int ld_rows() const { return ldo; }
+    __device__ __forceinline__ Aux load_u(int R, int n0u, unsigned off) const {        // rows R + lane row, columns n0u + lane column
+        const float4* xi = (const float4*)rowptr<true>(xin, R, n0u, ldo, off);
+        Aux a; a.x0 = xi[0]; a.x1 = xi[1];
+        return a;
+    }
+    template <bool ONE>
+    __device__ __forceinline__ void apply_u(int R, int n0u, unsigned off, const float* v, int, const Aux& a, const Tile& tc) const {
+        core<true, true>(R, n0u, off, v, a, tc);
+    }
     // One arithmetic path for both kernels (the 128^2 kernel calls operator(), the 256^2 kernel the three-step form), with the
     // roundings spelled out: a row's result must not depend on which kernel the batch size selects (-ffp-contract=fast would
     // otherwise be free to contract the two call sites differently).
-    __device__ __forceinline__ void apply(int m, int n, const float* v, int, const Aux& a, const Tile& tc) const {
+    __device__ __forceinline__ void apply(int m, int n, const float* v, int z, const Aux& a, const Tile& tc) const {
+        apply_t<false>(m, n, v, z, a, tc);
+    }
+    // ONE: the caller knows that the tile lies inside one sample (tc.smp >= 0): no per-row operand loads, no branch around them
+    template <bool ONE>
+    __device__ __forceinline__ void apply_t(int m, int n, const float* v, int, const Aux& a, const Tile& tc) const {
+        core<ONE, false>(m, n, 0u, v, a, tc);
+    }
+    template <bool ONE, bool U>
+    __device__ __forceinline__ void core(int m, int n, unsigned off, const float* v, const Aux& a, const Tile& tc) const {
         Tile t = tc;
-        if (tc.smp < 0) per_sample(m / rows, n, t);
+        if (!ONE && tc.smp < 0) per_sample(m / rows, n, t);
         const float g[8] = {t.g0.x, t.g0.y, t.g0.z, t.g0.w, t.g1.x, t.g1.y, t.g1.z, t.g1.w};
         const float x[8] = {a.x0.x, a.x0.y, a.x0.z, a.x0.w, a.x1.x, a.x1.y, a.x1.z, a.x1.w};
         float o[8];
@@ -370,27 +405,27 @@ struct EpiResid {
         for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(cb * g[i], v[i], ca * x[i]);
         // A/B (MAPDIT_KEEP bit 32, off): the residual checkpoint by non-temporal stores - fc1 3 us faster, the step 0.2 ms slower (the
         // next branch's residual read and the residual backward find less of it cached): not used
-        if (xm_plain & 2) {
-            __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, (f32x4_t*)(xout + (size_t)m * ldo + n));
-            __builtin_nontemporal_store(f32x4_t{o[4], o[5], o[6], o[7]}, (f32x4_t*)(xout + (size_t)m * ldo + n + 4));
+        if (!U && (xm_plain & 2)) {                          // (U: the default store policies as compile-time facts; fast_ok() checks)
+            __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, (f32x4_t*)rowptr<U>(xout, m, n, ldo, off));
+            __builtin_nontemporal_store(f32x4_t{o[4], o[5], o[6], o[7]}, (f32x4_t*)rowptr<U>(xout, m, n, ldo, off) + 1);
         } else {
-            float4* xo = (float4*)(xout + (size_t)m * ldo + n);
+            float4* xo = (float4*)rowptr<U>(xout, m, n, ldo, off);
             xo[0] = make_float4(o[0], o[1], o[2], o[3]);
             xo[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
-        if (y) store8_bf16(y + (size_t)m * ldo + n, v);
-        if (xm) {
+        if (U || y) store8_bf16(rowptr<U>(y, m, n, ldo, off), v);
+        if (U || xm) {
             const float c[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
             const float h[8] = {t.h0.x, t.h0.y, t.h0.z, t.h0.w, t.h1.x, t.h1.y, t.h1.z, t.h1.w};
             float w[8];
-            if (rot) {
+            if (!U && rot) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(o[i], c[i], o[i ^ 1] * h[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
             }
-            store8_bf16(xm + (size_t)m * ldo + n, w, (xm_plain & 1) != 0);
+            store8_bf16(rowptr<U>(xm, m, n, ldo, off), w, U || (xm_plain & 1) != 0);
         }
     }
     __device__ __forceinline__ void operator()(int m, int n, const float* v, int = 0) const {
@@ -436,13 +471,18 @@ struct EpiDSilu {
 // thread's four rows of a block, then over the 16 threads that share its columns (one xor-shuffle + eight LDS rows), then over
 // the blocks of the sample - all in a fixed order: no atomics, bit-reproducible.
 // DX16 (round 4): the downstream gradient arrives as a 16-bit tensor (dxo16; the block-to-block gradient stream of the 16-bit engines)
-template <bool DX16> struct EpiRmbT {
+// FAST (round 4): dxo16, dx_bf, y_up all present and dx absent - the block-to-block case of the 16-bit engines - as compile-time facts:
+// with the loads and stores behind (uniform) pointer tests hipcc's wait-count pass saw merging paths and put s_waitcnt vmcnt(0) in front
+// of every row chunk, i.e. a full memory round trip per chunk with nothing else in flight (16 of them per thread and tile).
+template <bool DX16, bool FAST = false> struct EpiRmbT {
     const bf16_t* dxo16;
     const float* dxo; const float* x; const float* shift; const float* scale; const float* gain;
     const bf16_t* y_up; const float* g_up;
     float* dx; bf16_t* dx_bf; bf16_t* dy_up; float* dshift; float* dscale; float* dg_up; float* dgain_part;
     int ldo, ldmod, ldg_up, ldd, ldd_up, T; float ca, cb, gscale;
-    struct Aux { float4 x0, x1, d0, d1; u32x4_t y, d16; };
+    struct AuxF { float4 x0, x1, d0, d1; u32x4_t y, d16; };
+    struct AuxH { float4 x0, x1; u32x4_t y, d16; };           // 16-bit downstream gradient: no fp32 fields to carry
+    typedef typename std::conditional<DX16, AuxH, AuxF>::type Aux;
     struct Tile { float4 sc0, sc1, sh0, sh1, gu0, gu1; };
     struct Acc { float sc[8], sh[8], g[8], gain; };    // running sums of the current 64-row block (gain: of the whole tile)
     __device__ __forceinline__ void coef(float& k, float& kb, float& kd) const {
@@ -456,7 +496,7 @@ template <bool DX16> struct EpiRmbT {
         const float4* sh = (const float4*)(shift + (size_t)smp * ldmod + n);
         t.sc0 = sc[0]; t.sc1 = sc[1]; t.sh0 = sh[0]; t.sh1 = sh[1];
         t.gu0 = t.gu1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y_up) {
+        if (FAST || y_up) {
             const float4* gu = (const float4*)(g_up + (size_t)smp * ldg_up + n);
             t.gu0 = gu[0]; t.gu1 = gu[1];
         }
@@ -466,13 +506,19 @@ template <bool DX16> struct EpiRmbT {
         Aux a;
         const float4* xi = (const float4*)(x + (size_t)m * ldo + n);
         a.x0 = xi[0]; a.x1 = xi[1];
-        a.d0 = a.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!DX16) a.d0 = a.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
         a.d16 = u32x4_t{0u, 0u, 0u, 0u};
-        if constexpr (DX16) {
+        if constexpr (FAST) {
+            a.d16 = *(const u32x4_t*)(dxo16 + (size_t)m * ldo + n);
+            a.y = __builtin_nontemporal_load((const u32x4_t*)(y_up + (size_t)m * ldo + n));
+            return a;
+        } else if constexpr (DX16) {
             if (dxo16) a.d16 = *(const u32x4_t*)(dxo16 + (size_t)m * ldo + n);
-        } else if (dxo) {
-            const float4* di = (const float4*)(dxo + (size_t)m * ldo + n);
-            a.d0 = di[0]; a.d1 = di[1];
+        } else {
+            if (dxo) {
+                const float4* di = (const float4*)(dxo + (size_t)m * ldo + n);
+                a.d0 = di[0]; a.d1 = di[1];
+            }
         }
         a.y = u32x4_t{0u, 0u, 0u, 0u};
         if (y_up) a.y = __builtin_nontemporal_load((const u32x4_t*)(y_up + (size_t)m * ldo + n));
@@ -480,9 +526,12 @@ template <bool DX16> struct EpiRmbT {
     }
     __device__ __forceinline__ void apply_r(int m, int n, const float* v, const Aux& a, const Tile& t, Acc& r, float k, float kb,
                                             float kd) const {
+
         const float xx[8] = {a.x0.x, a.x0.y, a.x0.z, a.x0.w, a.x1.x, a.x1.y, a.x1.z, a.x1.w};
-        float dd[8] = {a.d0.x, a.d0.y, a.d0.z, a.d0.w, a.d1.x, a.d1.y, a.d1.z, a.d1.w};
-        if constexpr (DX16) {
+        float dd[8];
+        if constexpr (!DX16) {
+            dd[0] = a.d0.x; dd[1] = a.d0.y; dd[2] = a.d0.z; dd[3] = a.d0.w; dd[4] = a.d1.x; dd[5] = a.d1.y; dd[6] = a.d1.z; dd[7] = a.d1.w;
+        } else {
             dd[0] = lo16(a.d16.x); dd[1] = hi16(a.d16.x); dd[2] = lo16(a.d16.y); dd[3] = hi16(a.d16.y);
             dd[4] = lo16(a.d16.z); dd[5] = hi16(a.d16.z); dd[6] = lo16(a.d16.w); dd[7] = hi16(a.d16.w);
         }
@@ -499,13 +548,13 @@ template <bool DX16> struct EpiRmbT {
             r.sh[i] += kb * vi;
             r.gain += vi * (sh[i] - xx[i] * sc[i]) * kd;
         }
-        if (dx) {
+        if (!FAST && dx) {
             float4* p = (float4*)(dx + (size_t)m * ldo + n);
             p[0] = make_float4(o[0], o[1], o[2], o[3]);
             p[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
-        if (dx_bf) store8_bf16(dx_bf + (size_t)m * ldo + n, o);
-        if (y_up) {
+        if (FAST || dx_bf) store8_bf16(dx_bf + (size_t)m * ldo + n, o);
+        if (FAST || y_up) {
             const float gu[8] = {t.gu0.x, t.gu0.y, t.gu0.z, t.gu0.w, t.gu1.x, t.gu1.y, t.gu1.z, t.gu1.w};
             const u32x4_t u = a.y;
             const float yy[8] = {lo16(u.x), hi16(u.x), lo16(u.y),
@@ -524,9 +573,29 @@ template <bool DX16> struct EpiRmbT {
     typedef EpiNoTile TileUnused;
     __device__ __forceinline__ void operator()(int, int, const float*, int = 0) const {}
 };
+template <> constexpr bool kUniformRows<EpiResid> = true;
+// (called from generic lambdas, where `if constexpr` on a property of Epi does not discard: these function templates do)
+template <bool ONE, class E> __device__ __forceinline__ void epi_apply_t(const E& e, int m, int n, const float* v, int z,
+                                                                         const typename E::Aux& a, const typename E::Tile& t);
+template <class E> __device__ __forceinline__ typename E::Aux epi_load_u(const E& e, int R, int n0u, unsigned off) {
+    if constexpr (kUniformRows<E>) return e.load_u(opaque_s(R), n0u, off); else return typename E::Aux();
+}
+template <class E> __device__ __forceinline__ void epi_apply_u(const E& e, int R, int n0u, unsigned off, const float* v, int z,
+                                                               const typename E::Aux& a, const typename E::Tile& t) {
+    if constexpr (kUniformRows<E>) e.template apply_u<true>(opaque_s(R), n0u, off, v, z, a, t);
+}
+template <class Epi> constexpr bool kFastEpi = false;       // has the straight-line (FE) instantiation of the 256^2 kernel and fast_ok()
+template <> constexpr bool kFastEpi<EpiResid> = true;
+template <class Epi> constexpr bool kOneSample = false;     // the functor has apply_t<ONE> and a Tile with smp (>= 0: tile inside one sample)
+template <> constexpr bool kOneSample<EpiResid> = true;
+template <bool ONE, class E> __device__ __forceinline__ void epi_apply_t(const E& e, int m, int n, const float* v, int z,
+                                                                         const typename E::Aux& a, const typename E::Tile& t) {
+    if constexpr (kOneSample<E>) e.template apply_t<ONE>(m, n, v, z, a, t); else e.apply(m, n, v, z, a, t);
+}
 template <class Epi> constexpr bool kReduce = false;
 template <> constexpr bool kReduce<EpiRmbT<false>> = true;
 template <> constexpr bool kReduce<EpiRmbT<true>> = true;
+template <> constexpr bool kReduce<EpiRmbT<true, true>> = true;
 
 // QKV projection with the head split and the cosine normalisation of q, k fused in.  Every kernel above hands the 8
 // chunks of one 64-column head segment of a row to 8 consecutive lanes, so the per-head sum of squares is three
@@ -824,7 +893,7 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ G, int ld,
 
 // One output tile (virtual workgroup `bid` of `nwg` in the band-major tile order).  The kernel below calls it once per tile of its
 // workgroup.
-template <int AK, int BK, class Epi, bool KTAIL, int PH>
+template <int AK, int BK, class Epi, bool KTAIL, int PH, bool FE = false>
 __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, char* smem, const int bid, const int nwg) {
 #ifdef MAPDIT_GEMM_STAMPS
     long long* stamp_lds = PH != 2 ? g_stamps : (long long*)(smem + SMEM2_BYTES);
@@ -1379,6 +1448,12 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
     const bool col_ok = gn < p.N;
     typename Epi::Tile tctx;
     if (col_ok) tctx = epi.tile_begin(m0, (m0 + BM2 <= p.M ? m0 + BM2 : p.M) - 1, gn);
+    // IN (= FE, chosen by the launcher: every tile lies inside the result and, RESID, inside one sample): no row / column test and no
+    // per-row operand load is left in the body, which is then one straight line with exact wait counts (loads behind tests made hipcc
+    // wait for vmcnt(0) in front of every row chunk: a full memory round trip each, the rolling prefetch drained as soon as issued)
+    unsigned uoff = 0;                                         // this lane's (row, column) offset inside a 16-row group, in elements
+    if constexpr (kUniformRows<Epi>) uoff = (unsigned)((tid >> 5) * epi.ld_rows() + ecol);
+    constexpr bool IN = FE;
     typename Epi::Aux aux[8];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -1395,7 +1470,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
             for (int it = 0; it < 8; ++it) {               // the pass's stream operands: all in flight before the first use
                 const int row = (tid >> 5) + 16 * it;      // (after the accumulators of this pass are dead: register budget)
                 const int gm = m0 + (row >> 6) * 128 + (row & 63);
-                if (gm < p.M && col_ok) aux[it] = epi.load(gm, gn);
+                if constexpr (IN && kUniformRows<Epi>) aux[it] = epi_load_u(epi, m0 + (it >> 2) * 128 + (it & 3) * 16, n0, uoff);
+                else if (IN || (gm < p.M && col_ok)) aux[it] = epi.load(gm, gn);
             }
         }
         __syncthreads();
@@ -1403,15 +1479,18 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
         for (int it = 0; it < 8; ++it) {
             const int row = (tid >> 5) + 16 * it;
             const int gm = m0 + (row >> 6) * 128 + pass * 64 + (row & 63);
-            if (gm < p.M && col_ok) {
+            if (IN || (gm < p.M && col_ok)) {
                 float v[8];
                 *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS2_LD + ecol);
                 *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS2_LD + ecol + 4);
-                epi.apply(gm, gn, v, z, aux[it], tctx);
+                if constexpr (IN && kUniformRows<Epi>) epi_apply_u(epi, m0 + (it >> 2) * 128 + pass * 64 + (it & 3) * 16, n0, uoff, v, z, aux[it], tctx);
+                else epi_apply_t<IN>(epi, gm, gn, v, z, aux[it], tctx);
             }
             // rolling prefetch (round 4): the slot is free again - pass 1's operands of the same row go there and land under the
             // rest of pass 0 and the image writes of pass 1
-            if (pass == 0 && gm + 64 < p.M && col_ok) aux[it] = epi.load(gm + 64, gn);
+            if constexpr (IN && kUniformRows<Epi>) { if (pass == 0) aux[it] = epi_load_u(epi, m0 + (it >> 2) * 128 + 64 + (it & 3) * 16, n0, uoff); }
+            else if (pass == 0 && (IN || (gm + 64 < p.M && col_ok))) aux[it] = epi.load(gm + 64, gn);
+            if (IN) __builtin_amdgcn_sched_barrier(0);             // (program order kept: one row chunk after the other)
         }
         __syncthreads();
         G256_TSTAMP(3 + pass);
@@ -1434,7 +1513,7 @@ __device__ __forceinline__ void stagger_start(const GemmP& p) {
 // XCD either way, so the band-major order keeps its meaning).  What it saves is the hand-over between two workgroups on a CU: the
 // dispatch of the next one waits for the previous one's stores to drain and its LDS to be released (3-7 k cycles per tile of
 // ~50 k); inside one workgroup the next tile's prologue starts behind the last store's issue.
-template <int AK, int BK, class Epi, bool KTAIL = false, int PH = 2>
+template <int AK, int BK, class Epi, bool KTAIL = false, int PH = 2, bool FE = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) {
 #ifdef MAPDIT_GEMM_STAMPS
     // (the one-phase loop uses all 160 KiB of LDS: its stamps go straight to the global buffer - the stamping waves then carry a
@@ -1447,7 +1526,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     const int total = p.tiles * p.split_k;
     stagger_start(p);
     for (int v = blockIdx.x; v < total; v += gridDim.x) {
-        gemm256_tile<AK, BK, Epi, KTAIL, PH>(p, epi, smem, v, total);
+        gemm256_tile<AK, BK, Epi, KTAIL, PH, FE>(p, epi, smem, v, total);
         __syncthreads();                                   // the tile's last LDS reads are done before the next prologue lands
     }
 }
@@ -2118,6 +2197,7 @@ struct GemmEnv {
     int keep_mask = 1;
     int nsplit = 1;          // MAPDIT_GEMM_NSPLIT = 0: no column split of results whose width is an odd multiple of 128
     int w3 = 0;              // MAPDIT_GEMM_W3 = 1 (experiment builds only): the three-deep A ring variant of the round-4 kernel
+    int fast_epi = 1;        // MAPDIT_GEMM_FE = 0: never the straight-line epilogue instantiation (RESID; A/B)
     int stagger = -1;        // MAPDIT_GEMM_STAGGER = late start of every second workgroup, units of 8,128 cycles (persistent launches); -1: by epilogue
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
@@ -2125,6 +2205,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_NSPLIT")) nsplit = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_W3")) w3 = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_STAGGER")) stagger = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_FE")) fast_epi = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
@@ -2335,7 +2416,20 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
 #ifdef MAPDIT_GEMM_EXPERIMENTS
             if (p.phases == 1) go(std::false_type(), T1()); else if (p.phases == 3) go(std::false_type(), T3()); else
 #endif
-            go(std::false_type(), T2());
+            {
+                // The straight-line epilogue (FE) where the launcher can promise what it assumes: every tile inside the result and, for
+                // RESID, inside one sample.  MAPDIT_GEMM_FE=0 keeps the guarded form (A/B).
+                bool fe = false;
+                if constexpr (kFastEpi<Epi>)
+                    fe = gemm_env().fast_epi && M % BM2 == 0 && N % BN2 == 0 && epi.fast_ok();
+                if (fe) {
+                    if constexpr (kFastEpi<Epi>) {
+                        if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_ROW, Epi, false, 2, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                        else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma256_kernel<OP_ROW, OP_KMAJ, Epi, false, 2, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                        else hipLaunchKernelGGL((gemm_mfma256_kernel<OP_KMAJ, OP_KMAJ, Epi, false, 2, true>), dim3(grid), dim3(512), 0, st, p, epi);
+                    }
+                } else go(std::false_type(), T2());
+            }
         }
     } else if (mfma) {
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4, n_off, 0};
@@ -2435,6 +2529,11 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
                      "gemm: RMB needs T in {64, 128, 256}, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
             MD_CHECK(a->ldmod % 4 == 0 && a->ldg_up % 4 == 0 && e->ldo % 8 == 0, "gemm: RMB row strides must be multiples of 4 / 8");
             MD_CHECK(!(a->dxo && a->dxo_bf), "gemm: RMB: dxo and dxo_bf are alternatives");
+            if (a->dxo_bf && a->dx_bf && a->y_up && !a->dx)         // the block-to-block case: every stream present, as compile-time facts
+                return launch(layout, M, N, K, A, lda, B, ldb,
+                              EpiRmbT<true, true>{(const bf16_t*)a->dxo_bf, nullptr, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, nullptr,
+                                                  (bf16_t*)a->dx_bf, (bf16_t*)a->dy_up, a->dshift, a->dscale, a->dg_up, a->dgain_part, e->ldo, a->ldmod,
+                                                  a->ldg_up, a->ldd, a->ldd_up, a->T, a->ca, a->cb, a->dgain_scale != 0.f ? a->dgain_scale : 1.f}, st);
             if (a->dxo_bf)
                 return launch(layout, M, N, K, A, lda, B, ldb,
                               EpiRmbT<true>{(const bf16_t*)a->dxo_bf, nullptr, a->x, a->shift, a->scale, a->gain, (const bf16_t*)a->y_up, a->g_up, a->dx,
