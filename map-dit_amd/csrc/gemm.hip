@@ -425,6 +425,11 @@ struct EpiResid {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w[i] = __builtin_fmaf(t.ka * o[i], c[i], t.kb * h[i]);
             }
+            // (fp16 build: left alone, hipcc folds the conversion below into the fma above - v_fma_mixlo_f16, ONE rounding - in some
+            // instantiations of this function and not in others; 63 of 10^6 values then differ by one fp16 ulp between kernels.
+            // The fp32 value is pinned here, so every kernel rounds twice, the same way.)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(w[i]));
             store8_bf16(rowptr<U>(xm, m, n, ldo, off), w, U || (xm_plain & 1) != 0);
         }
     }
@@ -548,6 +553,8 @@ template <bool DX16, bool FAST = false> struct EpiRmbT {
             r.sh[i] += kb * vi;
             r.gain += vi * (sh[i] - xx[i] * sc[i]) * kd;
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(o[i]));      // (pinned before the 16-bit conversion: see resid_mod_bwd_kernel)
         if (!FAST && dx) {
             float4* p = (float4*)(dx + (size_t)m * ldo + n);
             p[0] = make_float4(o[0], o[1], o[2], o[3]);

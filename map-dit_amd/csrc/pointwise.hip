@@ -113,6 +113,10 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
             }
         }
         if (p.dx) *(float4*)(p.dx + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+        // (the fp32 values are pinned before their 16-bit conversion: hipcc may otherwise fold the conversion into the fma above
+        // - one rounding instead of two - here and not in the GEMM epilogue that computes the same values, or the other way round)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(dx[i]));
         if (p.dx_bf) {
             uint2 u; u.x = pack16(dx[0], dx[1]); u.y = pack16(dx[2], dx[3]);
             *(uint2*)(p.dx_bf + off) = u;

@@ -210,6 +210,41 @@ def test_gemm_epilogues(L):
     assert rel_err(o3.float().cpu().numpy(), hh.grad.numpy()) < 3e-3
 
 
+@pytest.mark.parametrize("T", [256, 64])
+def test_resid_epilogue_same_bits_on_every_kernel(L, T):
+    """RESID with the fused next-branch modulate (dit_block.py:35-36 + utils.py:11-16) on [2048, 512] x K = 192: the 128^2 kernel, the
+    256^2 kernel's guarded epilogue (T = 64: four samples per tile) and its straight-line instantiation (T = 256: interior tiles, each
+    inside one sample, every optional output present) must agree bit for bit - a sample's activations do not depend on which kernel
+    its batch size selects."""
+    M, N, K = 2048, 512, 192
+    A, B = bf16_exact(M, K, seed=21), bf16_exact(N, K, seed=22, scale=0.2)
+    a, b = to_bf(A), to_bf(B)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(M, N, generator=g).to(DEV)
+    gate = torch.randn(M // T, 3 * N, generator=g).to(DEV)
+    mod = torch.randn(M // T, 2 * N, generator=g).to(DEV)
+    gain = torch.tensor([0.3], device=DEV)
+    res = []
+    for tile in (128, 256):
+        L.lib().gemm_tuning(tile, 2, 0)
+        xo = torch.zeros(M, N, device=DEV)
+        y = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
+        xm = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
+        run_gemm(L, 0, a, b, L.EPI_RESID, M, N, K, out=p(y), out2=p(xo), aux=p(x), gate=gate.data_ptr() + 4 * N, ldg=3 * N,
+                 rows_per_sample=T, ldo=N, alpha=0.7, beta=0.3, out3=p(xm), shift2=p(mod), scale2=mod.data_ptr() + 4 * N, gain2=p(gain),
+                 ld2=2 * N)
+        res.append((xo, y, xm))
+    L.lib().gemm_tuning(0, 2, 0)
+    for name, u, v in zip(("xout", "y", "xm"), res[0], res[1]):
+        assert torch.equal(u, v), (name, int((u != v).sum()), float((u.float() - v.float()).abs().max()))
+    acc = (A.double() @ B.double().t()).float()
+    ref = 0.7 * x.cpu() + 0.3 * gate.cpu()[:, N:2 * N].repeat_interleave(T, 0) * acc
+    assert rel_err(res[1][0].cpu().numpy(), ref.numpy()) < 2e-6
+    den = math.sqrt(0.7 ** 2 + 0.3 ** 2)
+    xm_ref = (0.7 * ref * mod.cpu()[:, N:].repeat_interleave(T, 0) + 0.3 * mod.cpu()[:, :N].repeat_interleave(T, 0)) / den
+    assert rel_err(res[1][2].float().cpu().numpy(), xm_ref.numpy()) < 3e-3
+
+
 def test_gemm_rejects_bad_args(L):
     a = torch.zeros(64, 64, device=DEV, dtype=MODE["dt"])
     ep = L.Epilogue()
