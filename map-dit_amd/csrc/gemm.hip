@@ -2346,10 +2346,9 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             // bursts: isolated, same box, proj 153 -> 142 us and fc2 303 -> 298 us with two units (1, 3, 4, 6, 8 units and four
             // populations: less or nothing); QKV heads, SiLU + derivative and the saved-factor product lose 1-5 % (VALU-bound
             // epilogues: the late half just ends late).
-            constexpr bool is_rmb = std::is_same<Epi, EpiRmbT<true>>::value || std::is_same<Epi, EpiRmbT<false>>::value;
+            // (the fused residual/modulate backward, the other stream-heavy epilogue: step +0.1 ... +0.3 ms with 1-4 units)
             const int sg = gemm_env().stagger;
-            p.stagger = sg >= 1000 ? (is_rmb ? sg - 1000 : std::is_same<Epi, EpiResid>::value ? 2 : 0)      // (A/B: 1000 + units for the RMB epilogue only)
-                        : sg >= 0 ? sg : (std::is_same<Epi, EpiResid>::value ? 2 : 0);
+            p.stagger = sg >= 0 ? sg : (std::is_same<Epi, EpiResid>::value ? 2 : 0);
         }
         auto go = [&](auto tail, auto ph) {
             constexpr bool TAIL = decltype(tail)::value;
