@@ -179,7 +179,9 @@ size_t carve(mapdit_engine* e, void* base) {
     for (int i = 0; i < nb; ++i) {
         BlockBufs& b = e->blk[i];
         b.xm = cv.take<bf16_t>(M * D);
-        b.qkv = e->generic_attn ? cv.take<bf16_t>(M * 3 * D) : nullptr;      // the fused QKV epilogue never writes qkv
+        // the fused QKV epilogue never writes qkv; nor does the head_dim-72 path without split / merge passes (raw72: q, k, v head-major
+        // straight from the GEMM) - DiT-XL/2: 113 MB x 28 blocks at 64 samples that were carved and never touched
+        b.qkv = (e->generic_attn && !e->raw72) ? cv.take<bf16_t>(M * 3 * D) : nullptr;
         b.qks = (e->generic_attn && !e->raw72) ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
         b.qn = cv.take<bf16_t>(M * D);
         b.kn = cv.take<bf16_t>(M * D);

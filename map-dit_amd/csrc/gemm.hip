@@ -2289,7 +2289,9 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         if (!force128 && n_off == 0 && split_k == 1 && gemm_env().nsplit && N % 256 == 128 && N >= 384 && K % BKT == 0 &&
             gemm_env().tile != 128 && M >= 512 && (long)cdiv(M, 256) * ((N - 128) / 256) >= 192 &&
             (long)cdiv(M, 256) * ((N - 128) / 256) <= 256 && !(((uintptr_t)A | (uintptr_t)B) & 15) &&
-            lda % 8 == 0 && ldb % 8 == 0) {
+            lda % 8 == 0 && ldb % 8 == 0 && !(a_kmaj && M % 8 != 0)) {
+            // (every condition of the MFMA path below holds for BOTH halves: the non-MFMA fallback knows no column offset, so a split
+            //  that fell through to it would write the second half over the first - TN with M % 8 != 0 was such a case)
             const int N1 = N - 128;
             const bf16_t* B2 = b_kmaj ? B + N1 : B + (size_t)N1 * ldb;
             if (!(((uintptr_t)B2) & 15)) {
@@ -2454,6 +2456,10 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_mfma_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
         else hipLaunchKernelGGL((gemm_mfma_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
     } else {
+        if (n_off != 0 || force128) {          // the scalar fallback indexes columns from 0: never the second half of a column split
+            mapdit_set_error("gemm: internal: column-offset launch reached the non-MFMA path (M=%d N=%d K=%d)", M, N, K);
+            return MAPDIT_ERR_ARG;
+        }
         const long sam = a_kmaj ? 1 : lda, sak = a_kmaj ? lda : 1;
         const long sbn = b_kmaj ? 1 : ldb, sbk = b_kmaj ? ldb : 1;
         const long total = (long)M * (N >> 3);

@@ -70,8 +70,20 @@ class FusedAdamEMA:
         # the loop; poll_overflow() (logging cadence) reports refused steps and halves the model's loss scale.
         # None = on while the model computes in "f16", off otherwise; True / False force it.
         self.nonfinite_guard = nonfinite_guard
-        self._status = torch.zeros(2, dtype=torch.int32, device=flat.device)     # {last bad step, number of bad steps}
+        self._status = torch.zeros(2, dtype=torch.int32, device=flat.device)     # {last bad launch, number of bad launches}
         self._overflows_seen = 0
+        # `step_count` counts APPLIED optimiser steps (bias corrections, LR schedule, EMA beta(t), the saved Adam "step": a refused step
+        # advances none of them, as with torch's GradScaler); `_launches` numbers the step() calls and is what the device-side guard
+        # compares (never rewinds, so a rolled-back run cannot meet a stale verdict).  A refusal becomes known to the host at the next
+        # poll: until then step_count runs ahead by the refused steps of that window and is rolled back there.
+        self._launches = 0
+        self._launches_polled = 0
+        self.growth_interval = 2000                  # applied steps without a refusal after which a halved loss scale doubles again
+        self.max_refused_at_unit_scale = 8           # consecutive refused steps with the loss scale at 1 (or no scale to lower): raise
+        self._scale_ceiling = None                   # the scale the run started from; growth never passes it
+        self._clean_since = 0                        # step_count at the last refusal / scale change
+        self._stuck = 0
+        self._poll_every_step = False                # set while refusals are occurring: poll after every step until one is applied
         self.status_sync = None                      # ZeRO-1: all-reduce(MAX) of the status words so that every rank refuses together
 
     def zero_grad(self, set_to_none: bool = True):
@@ -90,7 +102,9 @@ class FusedAdamEMA:
         assert m._pflat.numel() == self.exp_avg.numel(), "the model was re-flattened after the optimiser was built"
         lr = self.current_lr()                       # LambdaLR: lr for optimiser step k uses lambda(k), k from 0
         self.step_count += 1
+        self._launches += 1
         t = self.step_count
+        launch = self._launches
         b1, b2 = self.betas
         betas = [(1 - 1 / t) ** (g + 1) for g in self._gammas] if self.ema_stds else [0.0, 0.0]
         # the per-step values travel as kernel arguments: nothing is uploaded in the training loop
@@ -102,7 +116,7 @@ class FusedAdamEMA:
             with torch.cuda.device(m._pflat.device):
                 for lo, hi in self.shards:
                     if hi > lo:
-                        L.lib().grad_nonfinite_check(m._gflat.data_ptr() + lo * 4, hi - lo, self._status.data_ptr(), t, L.cur_stream())
+                        L.lib().grad_nonfinite_check(m._gflat.data_ptr() + lo * 4, hi - lo, self._status.data_ptr(), launch, L.cur_stream())
             if self.status_sync is not None:
                 self.status_sync(self._status)
         segs = []                                    # (lo, hi, with_ema)
@@ -128,12 +142,14 @@ class FusedAdamEMA:
                         self.exp_avg_sq.data_ptr() + off, ema[0].data_ptr() + off if ema else None,
                         ema[1].data_ptr() + off if ema else None, hi - lo, C.byref(hyper), b1, b2, self.eps)
                 if guard:
-                    L.lib().adam_ema_step_guarded(*args, self._status.data_ptr(), t, L.cur_stream())
+                    L.lib().adam_ema_step_guarded(*args, self._status.data_ptr(), launch, L.cur_stream())
                 else:
                     L.lib().adam_ema_step_scalars(*args, L.cur_stream())
         if self.after_step is not None:
             self.after_step()                        # ZeRO-1: all-gather of the updated parameter shards
         m.mark_weights_changed()
+        if guard and self._poll_every_step:
+            self.poll_overflow()
 
     # ---- non-finite gradient guard ------------------------------------------------------------------------------
     def overflow_steps(self) -> int:
@@ -141,15 +157,48 @@ class FusedAdamEMA:
         return int(self._status[1].item())
 
     def poll_overflow(self, halve_loss_scale: bool = True) -> int:
-        """Steps refused since the previous poll.  If there were any and `halve_loss_scale`, the model's fp16 loss scale is halved
-        (once per poll) so that the following backward passes stay in range.  Synchronises the stream."""
+        """Steps refused since the previous poll (synchronises the stream; train.py calls it at logging cadence).
+
+        * `step_count` is rolled back by that number: a refused step is not an optimiser step (bias corrections, LR schedule, EMA
+          beta(t) and the saved Adam "step" do not advance for updates that never happened).
+        * With `halve_loss_scale` the model's fp16 loss scale is halved ONCE PER REFUSED STEP (not once per poll), floor 1.
+        * While refusals are occurring the optimiser polls after every step by itself, so a scale 2^k too high costs k batches and
+          not k * log_every; it returns to the caller's cadence after the first applied step.
+        * Refusals that a lower scale cannot cure (scale already 1, or a NaN that comes from the data / a bf16 run with the guard
+          forced on) raise FloatingPointError after `max_refused_at_unit_scale` consecutive refused steps instead of refusing forever.
+        * After `growth_interval` applied steps without a refusal a halved scale doubles again, up to the scale the run started from.
+        """
         total = self.overflow_steps()
         new = total - self._overflows_seen
         self._overflows_seen = total
-        if new > 0 and halve_loss_scale and getattr(self.model, "gemm_precision", "") == "f16":
-            cur = self.model.effective_loss_scale()
-            if cur > 1.0:
-                self.model.loss_scale = cur / 2.0
+        launched = self._launches - self._launches_polled        # step() calls since the previous poll; `new` of them were refused
+        self._launches_polled = self._launches
+        f16 = getattr(self.model, "gemm_precision", "") == "f16"
+        if new > 0:
+            self.step_count = max(self.step_count - new, 0)
+            self._clean_since = self.step_count
+            self._poll_every_step = True
+            cur = self.model.effective_loss_scale() if f16 else 1.0
+            if self._scale_ceiling is None and f16:
+                self._scale_ceiling = cur
+            if halve_loss_scale and f16 and cur > 1.0:
+                self.model.loss_scale = max(cur / 2.0 ** new, 1.0)
+                self._stuck = 0
+            else:
+                self._stuck += new
+                if self._stuck >= self.max_refused_at_unit_scale:
+                    raise FloatingPointError(
+                        f"{self._stuck} consecutive optimiser steps refused for non-finite gradients with the loss scale at "
+                        f"{cur:g}: lowering the scale cannot cure this (NaN / inf in the data or in the weights?)")
+        elif launched > 0:                                       # every step of the window was applied
+            self._poll_every_step = False
+            self._stuck = 0
+            if (f16 and halve_loss_scale and self._scale_ceiling is not None
+                    and self.step_count - self._clean_since >= self.growth_interval):
+                cur = self.model.effective_loss_scale()
+                if cur < self._scale_ceiling:
+                    self.model.loss_scale = min(cur * 2.0, self._scale_ceiling)
+                self._clean_since = self.step_count
         return new
 
     # ---- checkpoint interchange with the reference (train.py:125-132 stores torch.optim.Adam.state_dict()) -------
@@ -180,6 +229,13 @@ class FusedAdamEMA:
         steps = {int(v["step"]) for v in sd["state"].values()}
         assert len(steps) <= 1, "per-parameter step counts differ"
         self.step_count = steps.pop() if steps else 0
+        # the guard's verdict words belong to the run that was loaded over: a refusal recorded for a step this optimiser is about to
+        # repeat must not be met again (launch numbers never rewind either: `_launches` is left alone)
+        self._status.zero_()
+        self._overflows_seen = 0
+        self._clean_since = self.step_count
+        self._stuck = 0
+        self._poll_every_step = False
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         for i, (o, n, shape) in enumerate(slots):

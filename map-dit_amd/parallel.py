@@ -297,6 +297,10 @@ class Zero1Reducer(_ReducerBase):
                 opt.status_sync = self._sync_status
 
     def _sync_status(self, status):
+        # RCCL: one 8-byte device-side all-reduce per step, nothing read back.  A host-staged group (gloo: the CPU rehearsal of the
+        # N > 1 path and the two-ranks-on-one-GPU tests, never a product configuration) cannot take device pointers: there - and only
+        # there - the verdict words pass through the host, which synchronises the stream once per optimiser step.  "Nothing is read
+        # back in the training loop" (mapdit.h, optim.py) is a statement about the RCCL path.
         if _host_staged(self.group, status):
             h = status.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)

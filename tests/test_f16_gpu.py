@@ -192,14 +192,45 @@ def test_f16_overflowing_step_is_refused_and_loss_scale_halved():
     assert torch.equal(m._pflat, w_before), "a refused step must not touch the weights"
     for a, b in zip(before, state()):
         assert torch.equal(a, b), "a refused step must not touch Adam moments or EMA copies"
+    assert opt.step_count == 2                        # not known to the host yet ...
     assert opt.poll_overflow() == 1
+    assert opt.step_count == 1, "a refused step is not an optimiser step (bias corrections, LR schedule, EMA beta, saved Adam step)"
     assert m.loss_scale == scale0 / 2 and opt.overflow_steps() == 1
     step(False)                                       # the next ordinary step is applied, on the halved scale
     assert m.effective_loss_scale() == scale0 / 2
     assert not torch.equal(m._pflat, w_before) and torch.isfinite(m._pflat).all()
-    assert opt.poll_overflow() == 0 and opt.overflow_steps() == 1
+    assert opt.overflow_steps() == 1 and opt.step_count == 2 and not opt._poll_every_step     # (step() polled by itself: applied)
+    assert opt.poll_overflow() == 0
+    assert float(opt.state_dict()["state"][0]["step"]) == 2.0
     for b in state():
         assert torch.isfinite(b).all()
+    # several refused steps inside one polling window: the scale is halved once per refused step, the counter rolled back by all of them
+    opt._poll_every_step = False
+    scale1 = m.effective_loss_scale()
+    step(True), step(True), step(True)
+    assert opt.step_count == 5 and opt.poll_overflow() == 3 and opt.step_count == 2
+    assert m.loss_scale == scale1 / 8
+    # while refusals occur the optimiser polls after every step by itself: k further bad steps cost k batches, not k * log_every
+    step(True)
+    assert opt.step_count == 2 and m.loss_scale == scale1 / 16
+    step(False)
+    assert opt.step_count == 3 and not opt._poll_every_step
+    # a checkpoint loaded over the optimiser forgets the verdict words (a refusal recorded for step t must not be met
+    # again when the run passes t a second time)
+    sd_opt = opt.state_dict()
+    opt.load_state_dict(sd_opt)
+    assert int(opt._status[0]) == 0 and int(opt._status[1]) == 0 and opt.step_count == 3 and opt.poll_overflow() == 0
+    # refusals a lower scale cannot cure end in an exception instead of a run that silently stops learning
+    m.loss_scale = 1.0
+    opt.max_refused_at_unit_scale = 3
+    with pytest.raises(FloatingPointError):
+        for _ in range(4):
+            out = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)["loss"].mean()
+            opt.zero_grad()
+            (out * float("inf")).backward()
+            opt.step()
+            opt.poll_overflow()
+    m.loss_scale = scale0 / 2
     # the guard off (what round 3 shipped): the same overflow poisons the state - shown once so that the test above means something
     opt2 = FusedAdamEMA(m, lr=1e-2, nonfinite_guard=False)
     out = diff.training_losses(m, x, t, dict(y=y_eff), noise=noise)["loss"].mean()

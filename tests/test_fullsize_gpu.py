@@ -265,7 +265,8 @@ def test_bf16_and_bf16x3_engines_agree_at_scale(b2):
     assert torch.isfinite(exact).all() and e < 3e-2
 
 
-def test_xl2_graphed_denoise_step_equals_eager_at_full_size():
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_xl2_graphed_denoise_step_equals_eager_at_full_size(precision):
     """BASELINE config 5 (DiT-XL/2, 250-step schedule, cfg 1.5, batch 2 x 128): one replay of the captured hipGraph at t = 0 (no noise
     added) must equal the eager p_sample step bit for bit, and the device-side step counter must move."""
     from mapdit_amd.diffusion import create_diffusion
@@ -273,6 +274,7 @@ def test_xl2_graphed_denoise_step_equals_eager_at_full_size():
     from mapdit_amd.src.models import DIT_MODELS
     torch.manual_seed(0)
     m = DIT_MODELS["DiT-XL/2"](in_channels=4, input_size=32, num_classes=1000).to(DEV).eval()
+    m.gemm_precision = precision
     d = create_diffusion("250")
     n = 128
     g = torch.Generator(device=DEV).manual_seed(2)

@@ -112,6 +112,28 @@ def test_gemm_layouts(L, layout, shape):
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3
 
 
+def test_gemm_column_split_shape_on_the_scalar_fallback(L):
+    """a result whose width is an odd multiple of 128 on ~one round of 256^2 tiles is run as two launches (256^2 kernel on
+    N - 128 columns + 128^2 kernel on the last 128).  A TN operand with M % 8 != 0 (padded leading dimension, so every alignment test
+    passes) is NOT MFMA-eligible: both halves would fall to the scalar kernel, which knows no column offset - the second half would
+    land on columns [0, 128).  The split must not be taken; the whole result comes from one scalar launch and is exact."""
+    M, N, K = 49156, 384, 64                       # 193 row tiles x 1 column tile of 256 (+128): inside the split's window; M % 8 == 4
+    lda = M + 4
+    A = bf16_exact(K, M, seed=31)
+    B = bf16_exact(K, N, seed=32)
+    a = torch.zeros(K, lda, dtype=MODE["dt"], device=DEV)
+    a[:, :M] = to_bf(A)
+    b = to_bf(B)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ep = L.Epilogue()
+    ep.kind, ep.out, ep.ldo, ep.alpha = L.EPI_STORE_F32, p(out), N, 1.0
+    L.lib().gemm_bf16(2, M, N, K, p(a), lda, p(b), N, C.byref(ep), st())
+    torch.cuda.synchronize()
+    ref = (A.double().t() @ B.double()).float()
+    assert torch.isfinite(out).all(), "columns left unwritten"
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6
+
+
 def test_gemm_split_k_slabs_feed_weightnorm_bwd(L):
     """dW = dy^T x with K cut into slabs; mapdit_weightnorm_bwd adds the slabs in order (deterministic split-K)."""
     from oracle.dit_oracle import normalize

@@ -314,13 +314,29 @@ def test_sampler_matches_reference(precision, tol):
 NAMED_GRAD_TOL = 4e-2     # sub-sampled tensors of >= 64 kept entries: measured <= 2.6e-2 (s2_n4; b2_n2 9.6e-3, xl2_n2 1.5e-2; pooled 3.8e-3)
 
 
+# Limits of the named (full-depth) models per engine precision.  bf16 is the dtype BENCH is quoted in, f16 the default engine: BOTH are
+# asserted here against the reference's own outputs (round 5: when the default flipped to f16 this test silently ran the f16 engine
+# against bf16's limits and left bf16 unasserted on every full-depth model).
+#   logits, loss, gradient norm per tensor, sub-sampled gradient tensor (>= 64 kept entries), scalar gains (of the largest gain gradient)
+NAMED_LIMITS = {
+    # measured bf16: logits s4_n8 6.0e-3, s2_n2 3.8e-3, s2_n4 8.1e-3, b2_n2 6.0e-3, xl2_n2 6.2e-3; loss <= 2.9e-3 (s2_n4); norms <= 1.09e-2
+    # (s4_n8); tensors <= 2.6e-2 (s2_n4; b2_n2 9.6e-3, xl2_n2 1.5e-2; pooled 3.8e-3)
+    "bf16": dict(logits=1.6e-2, loss=6e-3, gnorm=2.2e-2, gtensor=NAMED_GRAD_TOL, gsmall=0.12, gain=GAIN_TOL),
+    # f16: north_star's 1e-3 on the logits (measured worst s2_n4 9.3e-4), tests/test_f16_gpu.py's limits on the rest (worst tensor 1.6e-3)
+    "f16": dict(logits=1e-3, loss=5e-4, gnorm=3e-3, gtensor=3e-3, gsmall=1e-2, gain=5e-3),
+}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
 @pytest.mark.parametrize("name", ["s4_n8", "s2_n2", "s2_n4", "b2_n2", "xl2_n2"])
-def test_named_models_match_reference(name):
+def test_named_models_match_reference(name, precision):
     """DiT-S/4 (BASELINE configs[0]), DiT-S/2 (configs[1], full depth at n = 2 and n = 4), DiT-B/2 (the metric's model) and
-    DiT-XL/2 (configs[3] / [4]: patch 2, depth 28, head_dim 72, 256 tokens) against the reference's own outputs: eval logits,
-    training losses and every parameter gradient of one training step."""
+    DiT-XL/2 (configs[3] / [4]: patch 2, depth 28, head_dim 72, 256 tokens) built through DIT_MODELS[...] against the reference's own
+    outputs (src/dit.py:70-105, diffusion/gaussian_diffusion.py:715-787): eval logits, training losses and every parameter gradient of
+    one training step, in BOTH engine precisions with the precision set explicitly."""
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.models import DIT_MODELS
+    lim = NAMED_LIMITS[precision]
     g = load_golden(name)
     cfg = golden_cfg(g)
     sd = golden_state_dict(g, cfg)
@@ -328,19 +344,20 @@ def test_named_models_match_reference(name):
     m = DIT_MODELS[f"DiT-{fam}/{cfg.patch_size}"](in_channels=4, input_size=32, num_classes=1000)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
+    m.gemm_precision = precision
     x, t, y, y_eff, noise = dev(g, "x", "t", "y", "y_eff", "noise")
     with torch.no_grad():
         out = m(x, t, y)
     e = rel_err(out.cpu().numpy(), g["eval_out"])
-    print(f"{name}: eval logits rel err {e:.3e}")
-    assert e < 1.6e-2                 # measured: s4_n8 6.0e-3, s2_n2 3.8e-3, s2_n4 8.1e-3, b2_n2 6.0e-3, xl2_n2 6.2e-3
+    print(f"{name} [{precision}]: eval logits rel err {e:.3e}")
+    assert e < lim["logits"]
     m.train()
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     losses = create_diffusion("").training_losses(m, x, t, dict(y=y_eff), noise=noise)
     losses["loss"].mean().backward()
     e = rel_err(losses["loss"].detach().cpu().numpy(), g["train_loss"])
-    print(f"{name}: loss rel err {e:.3e}")
-    assert e < 6e-3                   # measured: <= 2.9e-3 (s2_n4)
+    print(f"{name} [{precision}]: loss rel err {e:.3e}")
+    assert e < lim["loss"]
     worst = worst_e = 0.0
     gain_scale = max(float(g["gradnorm/" + k]) for k, p in m.named_parameters() if p.dim() == 0)
     worst_gain = 0.0
@@ -349,19 +366,20 @@ def test_named_models_match_reference(name):
         if p.dim() == 0:     # cancellation-heavy scalar sums: see test_training_losses_and_gradients
             gain_dev = abs(float(p.grad) - float(g["grad/" + k])) / (gain_scale + 1e-30)
             worst_gain = max(worst_gain, gain_dev)
-            assert gain_dev < GAIN_TOL, (k, float(p.grad), float(g["grad/" + k]))
+            assert gain_dev < lim["gain"], (k, float(p.grad), float(g["grad/" + k]))
             continue
         if gn < 1e-7:
             continue
         got = float(p.grad.double().norm())
         worst = max(worst, abs(got / gn - 1))
-        assert abs(got / gn - 1) < 2.2e-2, (k, got, gn)          # measured: <= 1.09e-2 (s4_n8)
+        # (tensors of < 64 entries - the MPScale references, 8 sums with heavy cancellation - are held to the small-tensor limit)
+        assert abs(got / gn - 1) < (lim["gnorm"] if p.numel() >= 64 else lim["gsmall"]), (k, got, gn)
         gref = g["grad/" + k]
         e = rel_err(sub(p.grad, stride=4099), gref)
         if gref.size >= 64:
             worst_e = max(worst_e, e)
-        assert e < (NAMED_GRAD_TOL if gref.size >= 64 else 0.12) or p.numel() < 64, (k, e)
-    print(f"{name}: worst gradient-norm deviation {worst:.3e}, worst sub-sampled gradient tensor (>= 64 kept entries) {worst_e:.3e}, "
+        assert e < (lim["gtensor"] if gref.size >= 64 else lim["gsmall"]) or p.numel() < 64, (k, e)
+    print(f"{name} [{precision}]: worst gradient-norm deviation {worst:.3e}, worst sub-sampled gradient tensor (>= 64 kept entries) {worst_e:.3e}, "
           f"worst gain deviation {worst_gain:.3e}")
 
 

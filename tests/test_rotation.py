@@ -80,7 +80,9 @@ def test_oracle_network_at_zero_gain_equals_the_snapshot_network():
 
 
 @pytest.mark.gpu
-def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gain():
+@pytest.mark.parametrize("precision,ltol,losstol,gtol,gaintol", [("bf16", 7e-3, 2e-2, 1.4e-2, 1e-2),      # measured 3.3e-3 / - / 6.9e-3
+                                                                  ("f16", 1e-3, 2e-3, 3e-3, 5e-3)])
+def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gain(precision, ltol, losstol, gtol, gaintol):
     from mapdit_amd import _lib as L
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.dit import DiT
@@ -98,19 +100,21 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
     ma.load_state_dict(sd0)
     mr.load_state_dict(_rot_state_from(sd0, cfg))
     ma, mr = ma.to(dev).eval(), mr.to(dev).eval()
+    ma.gemm_precision = mr.gemm_precision = precision
     with torch.no_grad():
         assert torch.equal(ma(x.to(dev), t.to(dev), y.to(dev)), mr(x.to(dev), t.to(dev), y.to(dev)))
-    # (2) non-zero gains: eval logits, training loss and every gradient against the oracle's restatement (bf16 tolerances)
+    # (2) non-zero gains: eval logits, training loss and every gradient against the oracle's restatement (the precision's tolerances)
     rsd = O.init_state_dict(rcfg, seed=7, gains=0.4, perturb_reference=0.3)
     m = DiT(**rcfg.to_dict())
     m.load_state_dict(rsd)
     m = m.to(dev).eval()
+    m.gemm_precision = precision
     with torch.no_grad():
         out = m(x.to(dev), t.to(dev), y.to(dev)).cpu()
         want = O.dit_forward({k: v.clone() for k, v in rsd.items()}, rcfg, x, t, y, train=False)
     e = rel_err(out.numpy(), want.numpy())
-    print(f"rotation: eval logits vs oracle {e:.3e}")
-    assert e < 7e-3                                    # measured 3.3e-3
+    print(f"rotation [{precision}]: eval logits vs oracle {e:.3e}")
+    assert e < ltol
     m.train()
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     losses = create_diffusion("").training_losses(m, x.to(dev), t.to(dev), dict(y=y.to(dev)), noise=noise.to(dev))
@@ -121,19 +125,19 @@ def test_engine_rotation_matches_the_oracle_and_is_the_snapshot_path_at_zero_gai
     ref = DiffusionOracle("").training_losses(lambda xx, tt, **kw: O.dit_forward(osd, rcfg, xx, tt, kw["y"], train=True, drop=drop),
                                               x, t, dict(y=y), noise=noise)
     ref["loss"].mean().backward()
-    assert rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy()) < 2e-2
+    assert rel_err(losses["loss"].detach().cpu().numpy(), ref["loss"].detach().numpy()) < losstol
     gain_scale = max(float(osd[k].grad.abs().max()) for k in osd if "gain_" in k)
     worst = worst_gain = 0.0
     for k, p in m.named_parameters():
         gref = osd[k].grad
         if p.dim() == 0:
             worst_gain = max(worst_gain, abs(float(p.grad) - float(gref)) / (gain_scale + 1e-30))
-            assert abs(float(p.grad) - float(gref)) < 1e-2 * gain_scale + 1e-7, (k, float(p.grad), float(gref))
+            assert abs(float(p.grad) - float(gref)) < gaintol * gain_scale + 1e-7, (k, float(p.grad), float(gref))
             continue
         e = rel_err(sub(p.grad), sub(gref))
         worst = max(worst, e)
-        assert e < 1.4e-2 or float(gref.norm()) < 1e-7, (k, e)          # measured: worst tensor 6.9e-3
-    print(f"rotation: worst gradient rel err vs oracle {worst:.3e}, worst gain deviation {worst_gain:.3e}")
+        assert e < gtol or float(gref.norm()) < 1e-7, (k, e)
+    print(f"rotation [{precision}]: worst gradient rel err vs oracle {worst:.3e}, worst gain deviation {worst_gain:.3e}")
     # the modulation weight's angle rows do receive gradient
     mw = dict(m.named_parameters())["blocks.0.modulation.1.weight"].grad
     assert float(mw[:64].abs().sum()) > 0

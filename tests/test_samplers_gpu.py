@@ -25,6 +25,7 @@ def test_checkpoint_is_interchangeable_with_torch_adam(exp_dir):
     from mapdit_amd.src.models import DIT_MODELS
     ck = torch.load(os.path.join(exp_dir, "checkpoints", "0000008.pt"), weights_only=True)
     m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=10).to(DEV)
+    assert m.gemm_precision == "f16"          # the harness and the samplers above ran in the default precision; nothing here depends on it
     m.load_state_dict(ck["model"])
     # the reference resumes with torch.optim.Adam(...).load_state_dict(ck["opt"]) (train.py:57,125-132)
     adam = torch.optim.Adam(m.parameters(), lr=1e-2, betas=(0.9, 0.99))

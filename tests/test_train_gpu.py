@@ -54,7 +54,8 @@ def test_three_optimizer_steps_match_reference(precision, wtol, ltol):
         print(f"{precision} step {step}: worst weight rel err {worst:.2e}")
 
 
-def test_graphed_sampler_matches_eager_step():
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_graphed_sampler_matches_eager_step(precision):
     from oracle import dit_oracle as O
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.sampling import GraphedSampler
@@ -63,6 +64,7 @@ def test_graphed_sampler_matches_eager_step():
     m = DiT(**cfg.to_dict())
     m.load_state_dict(O.init_state_dict(cfg, seed=9, gains=0.3, perturb_reference=0.3))
     m = m.to(DEV).eval()
+    m.gemm_precision = precision
     d = create_diffusion("250")
     n = 4
     g = torch.Generator().manual_seed(3)
@@ -329,6 +331,7 @@ def test_ema_class_matches_fused_optimizer(tmp_path):
         m = DiT(**cfg.to_dict())
         m.load_state_dict(sd)
         m = m.to(DEV).train()
+        m.gemm_precision = "f16"        # explicit: the default engine (both loops run the same engine; only the optimiser differs)
         m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
         if fused:
             opt = FusedAdamEMA(m, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1))
@@ -386,6 +389,7 @@ def test_overlapped_reducer_through_rccl_single_rank():
             m = DiT(**cfg.to_dict())
             m.load_state_dict(sd)
             m = m.to(DEV).train()
+            m.gemm_precision = "f16"    # explicit: the default engine incl. its non-finite guard on the reduced gradients
             m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
             r = OverlappedGradReducer(m, force_collective=through_rccl)
             opt = FusedAdamEMA(m, lr=1e-2, grad_scale=r.grad_scale)
