@@ -32,7 +32,7 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
+int mapdit_abi_version(void);   /* 5: mapdit_weightnorm_bwd_slim (the Jacobian beside a GEMM on another stream).  4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
                                  * mapdit_engine_loss_scale, loss_scale must be a power of two.  3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
                                  * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
@@ -141,6 +141,11 @@ int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int 
  * G is scratch: with nslabs > 1 its slab 0 is overwritten with the sum. */
 int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
                           int cols, float out_scale, int accumulate, void* stream);
+/* The same pass, same bits, in 48 registers per lane and no LDS: the form to launch on a second stream while a weight-gradient GEMM
+ * (two 228-register waves per SIMD) occupies the CUs - the engine runs the Jacobian of weight i beside the GEMM of weight i + 1
+ * (autograd of src/basic/mp_linear.py:38-46 needs the whole row of G: it cannot be the GEMM's epilogue). */
+int mapdit_weightnorm_bwd_slim(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
+                               int cols, float out_scale, int accumulate, void* stream);
 
 /* torch.optim.Adam (train.py:57) fused with the two power-function EMA copies (src/ema.py:135-140) over flat
  * fp32 buffers.  hyper (device, 5 floats): lr/(1-b1^t), 1/sqrt(1-b2^t), ema beta a, ema beta b, grad scale. */

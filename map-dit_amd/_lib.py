@@ -71,6 +71,7 @@ _SIGS = {
     "mapdit_gemm_bf16": [ci, ci, ci, ci, vp, ci, vp, ci, C.POINTER(Epilogue), vp],
     "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
+    "mapdit_weightnorm_bwd_slim": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],

@@ -113,6 +113,25 @@ struct mapdit_engine {
         bf16_t *AsT, *BsT;
     } pg;
     long G_cap = 0;                       // floats available in G (split-K slabs)
+    // Round 5: the weight-norm Jacobian of weight i runs on a SIDE STREAM beside the weight-gradient GEMM of weight i + 1 (the Jacobian
+    // is an HBM-bound pass with idle matrix pipes, the GEMM an MFMA-bound one with idle HBM; the 48-register form of the pass fits
+    // beside the GEMM's waves on the same CUs).  Two slab buffers alternate: GEMM k writes Gbuf[k & 1] on the caller's stream, the
+    // Jacobian reads it on `side` behind ev_gemm, the GEMM after next waits for ev_jac before it overwrites that buffer, and the
+    // caller's stream joins the side stream before a backward call returns (the stage's gradients are then final in stream order: the
+    // data-parallel reducer and the optimiser see exactly what they saw before).
+    // MEASURED, NOT THE DEFAULT (MAPDIT_SIDE_JAC=1 switches it on; profiles/r05_side_stream_jacobian.txt, same box, interleaved):
+    // 43.16 -> 43.43 ms per 256-sample step.  The kernel trace says why: the Jacobian does run beside the next kernel (12.2 ms of a step
+    // with two kernels in flight), but a streaming pass that shares CUs with a GEMM costs the GEMM about what the pass takes alone
+    // (weight-gradient GEMM 247 -> 256 us, fused backward 327 -> 335, saved-factor GEMM 335 -> 348, next weight-gradient GEMM 186 ->
+    // 207), the 48-register form is latency-bound at one wave per SIMD (48 us beside a GEMM against 15 us alone), only the weight-gradient
+    // GEMMs leave it room at all (the fused-backward and attention kernels hold 482+ of a SIMD's 512 registers: the pass waits for
+    // their workgroups to drain), and every cross-stream event costs the caller's queue a 6 us bubble (idle time 0.15 -> 0.85 ms).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_jac[2] = {nullptr, nullptr};
+    float* Gbuf[2] = {nullptr, nullptr};
+    bool jac_pending[2] = {false, false};
+    int gcur = 0;
+    bool side_jac = false;
     // bf16 engines: the conditioning path (timestep MLP, every modulation linear, the MPScale linears: [samples, D] rows, a
     // negligible share of the FLOPs) runs its forward products fp32-accurately on split operands like the bf16x3 engine.  With
     // bf16 operands it is the largest single source of the logits' distance to the reference (tools/precision_rank.py, DiT-B/2:
@@ -131,6 +150,13 @@ struct mapdit_engine {
 namespace {
 
 int pidx_block(int i, int which) { return MAPDIT_NUM_GLOBAL + i * MAPDIT_NUM_BLOCK + which; }
+
+// MAPDIT_SIDE_JAC=1 moves the weight-norm Jacobians to a side stream (round 5, measured and NOT the default: see the comment at
+// mapdit_engine::side); read once.
+bool side_jac_wanted() {
+    static const bool on = [] { const char* v = getenv("MAPDIT_SIDE_JAC"); return v && v[0] == '1'; }();
+    return on;
+}
 
 // Lay out every buffer; with base == nullptr this only measures.
 size_t carve(mapdit_engine* e, void* base) {
@@ -279,6 +305,8 @@ size_t carve(mapdit_engine* e, void* base) {
         if (gmax < (size_t)1152 * 128 * 128) gmax = (size_t)1152 * 128 * 128;   // room for ~1024 split-K tile slabs
         e->G = cv.take<float>(gmax);
         e->G_cap = (long)gmax;
+        e->Gbuf[0] = e->G;
+        e->Gbuf[1] = (!precise && side_jac_wanted()) ? cv.take<float>(gmax) : nullptr;    // (bf16x3 keeps one stream: not a fast path)
         e->DXa = cv.take<float>(M * D);
         e->DXb = cv.take<float>(M * D);
         e->DXa16 = (bf16_t*)e->DXa;                       // (the 16-bit stream of the fp16 engine lives in the same buffers)
@@ -512,6 +540,29 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
 }
 
 // dW for one linear: G = dy^T x (TN GEMM into scratch), then the weight-norm Jacobian into the bound grad.
+#define HIP_TRY(call, what)                                                                          \
+    do {                                                                                             \
+        const hipError_t he_ = (call);                                                               \
+        if (he_ != hipSuccess) {                                                                     \
+            mapdit_set_error("%s: %s", what, hipGetErrorString(he_));                                \
+            return MAPDIT_ERR_HIP;                                                                   \
+        }                                                                                            \
+    } while (0)
+
+// Slab buffer `b` is about to be written on stream `st`: a Jacobian still reading it on the side stream goes first.
+int g_claim(mapdit_engine* e, int b, void* st) {
+    if (e->jac_pending[b]) {
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)st, e->ev_jac[b], 0), "engine: wait for the side stream");
+        e->jac_pending[b] = false;
+    }
+    return MAPDIT_OK;
+}
+// Everything the side stream was given is ordered before what follows on `st` (end of a backward call: the gradients are final).
+int side_join(mapdit_engine* e, void* st) {
+    TRY(g_claim(e, 0, st));
+    return g_claim(e, 1, st);
+}
+
 int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf16_t* x, int ld_x, int K, float alpha, void* st) {
     const WeightImg& w = e->wimg[pidx];
     // Few output tiles, very long K (= tokens): cut K into slabs so the launch fills the chip; the slabs are summed,
@@ -521,9 +572,24 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
     mapdit_epilogue_t ep = epi_f32(e->G, w.cols, alpha * e->ginv);      // (fp16: dy carries the loss scale, the weight gradient does not)
     ep.split_k = split;
     ep.slab_stride = slab;
+    if (!e->side_jac || !e->grads[pidx]) {
+        TRY(g_claim(e, 0, st));
+        TRY(gemm16(e, MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
+        if (e->grads[pidx])
+            TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
+        return MAPDIT_OK;
+    }
+    // the GEMM on the caller's stream into the buffer whose previous Jacobian has finished, the Jacobian behind it on the side stream
+    const int b = e->gcur;
+    e->gcur ^= 1;
+    TRY(g_claim(e, b, st));
+    ep.out = e->Gbuf[b];
     TRY(gemm16(e, MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
-    if (e->grads[pidx])
-        TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
+    HIP_TRY(hipEventRecord(e->ev_gemm[b], (hipStream_t)st), "linear_dw: event record");
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_gemm[b], 0), "linear_dw: side stream wait");
+    TRY(mapdit_weightnorm_bwd_slim(e->params[pidx], e->Gbuf[b], w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, e->side));
+    HIP_TRY(hipEventRecord(e->ev_jac[b], e->side), "linear_dw: event record (side)");
+    e->jac_pending[b] = true;
     return MAPDIT_OK;
 }
 
@@ -560,6 +626,18 @@ extern "C" size_t mapdit_engine_workspace_bytes(const mapdit_config_t* cfg, int 
     return carve(&tmp, nullptr);
 }
 
+static void side_release(mapdit_engine* e) {
+    if (e->side) (void)hipStreamSynchronize(e->side);
+    for (int b = 0; b < 2; ++b) {
+        if (e->ev_gemm[b]) (void)hipEventDestroy(e->ev_gemm[b]);
+        if (e->ev_jac[b]) (void)hipEventDestroy(e->ev_jac[b]);
+        e->ev_gemm[b] = e->ev_jac[b] = nullptr;
+    }
+    if (e->side) (void)hipStreamDestroy(e->side);
+    e->side = nullptr;
+    e->side_jac = false;
+}
+
 extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void* workspace, size_t workspace_bytes, void* stream,
                                     mapdit_engine_t** out) {
     TRY(check_cfg(cfg));
@@ -589,6 +667,20 @@ extern "C" int mapdit_engine_create(const mapdit_config_t* cfg, int train, void*
         mapdit_set_error("engine_create: memset failed: %s", hipGetErrorString(he));
         return MAPDIT_ERR_HIP;
     }
+    if (train && e->Gbuf[1]) {
+        // side stream + hand-over events of the weight-norm Jacobians (non-blocking: no implicit ordering with the null stream)
+        bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < 2 && ok; ++b)
+            ok = hipEventCreateWithFlags(&e->ev_gemm[b], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_jac[b], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            side_release(e);
+            delete e;
+            mapdit_set_error("engine_create: side stream / events: %s", hipGetErrorString(hipGetLastError()));
+            return MAPDIT_ERR_HIP;
+        }
+        e->side_jac = true;
+    }
     *out = e;
     return MAPDIT_OK;
 }
@@ -605,6 +697,7 @@ static void prof_release(mapdit_engine* e) {
 extern "C" void mapdit_engine_destroy(mapdit_engine_t* e) {
     if (!e) return;
     prof_release(e);
+    side_release(e);
     delete e;
 }
 
@@ -1216,6 +1309,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * e->MW, ldm, e->c_silu, D, N, 1.f, st));
         if (i == 0) {
             // d c_silu += dmod_all W_mod_all: ONE split-K GEMM over K = L*6D, slabs summed into dcs
+            TRY(g_claim(e, 0, st));                            // e->G = slab buffer 0: a Jacobian of the side stream may still read it
             mapdit_epilogue_t ep = epi_f32(e->G, D, 1.f);
             const long slab = (long)N * D;
             ep.split_k = pick_split_k(N, D, ldm, e->G_cap / slab);
@@ -1226,11 +1320,12 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     }
 
     e->next_stage = stage_to + 1;
-    if (stage_to < L + 1) return MAPDIT_OK;
+    if (stage_to < L + 1) return side_join(e, st);         // the stages' gradients are final in the caller's stream order
     // ---- patch embedding: x0 = (x_embedder(patches) + pos) * C5 -----------------------------------------------------
     {
         const float c5 = 0.70710678118654752f;
         const long slab = (long)D * e->ldp;
+        TRY(g_claim(e, 0, st));
         mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5 * e->ginv);
         ep.split_k = pick_split_k(D, e->ldp, M, e->G_cap / slab);
         ep.slab_stride = slab;
@@ -1246,5 +1341,5 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));
     e->have_saved = false;
     e->next_stage = 0;
-    return MAPDIT_OK;
+    return side_join(e, st);
 }

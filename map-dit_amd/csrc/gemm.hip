@@ -2481,7 +2481,7 @@ void mapdit_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mapdit_last_error(void) { return g_err; }
-extern "C" int mapdit_abi_version(void) { return 4; }
+extern "C" int mapdit_abi_version(void) { return 5; }
 #endif
 
 extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,

@@ -193,6 +193,65 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     }
 }
 
+// The same pass for a SIDE STREAM (round 5): the engine runs the Jacobian of weight i beside the weight-gradient GEMM of weight i + 1.
+// A GEMM workgroup holds two 228-register waves per SIMD (464 of the 512 registers per lane after the allocation granule), so a
+// co-resident wave may own 48 registers and no LDS (tools/overlap_probe.py: a streaming kernel that fits beside the persistent GEMM hides
+// about half of its time).  One column chunk at a time, up to four slab loads in flight (the form above unrolls three chunks of six: 76
+// registers).  Same additions in the same order as weightnorm_bwd_kernel<true>: the results are the same bits.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48)))
+void weightnorm_bwd_slim_kernel(const float* __restrict__ W, float* __restrict__ G, int ldg, int nslabs, long slab_stride,
+                                float* __restrict__ dW, int rows, int cols, float out_scale, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* w = W + (size_t)row * cols;
+    float* g = G + (size_t)row * ldg;
+    float* d = dW + (size_t)row * cols;
+    float ss = 0.f, gw = 0.f;
+#pragma unroll 1
+    for (int c = lane * 4; c < cols; c += 256) {
+        float4 b = *(const float4*)(g + c);
+        const float4 a = *(const float4*)(w + c);
+        int s = 1;
+        for (; s + 3 < nslabs; s += 4) {
+            const float* gs = g + (size_t)s * slab_stride + c;
+            float4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = *(const float4*)(gs + (size_t)k * slab_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { b.x += t[k].x; b.y += t[k].y; b.z += t[k].z; b.w += t[k].w; }
+        }
+        for (; s + 1 < nslabs; s += 2) {
+            const float* gs = g + (size_t)s * slab_stride + c;
+            const float4 t0 = *(const float4*)(gs), t1 = *(const float4*)(gs + slab_stride);
+            b.x += t0.x; b.y += t0.y; b.z += t0.z; b.w += t0.w;
+            b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+        }
+        for (; s < nslabs; ++s) {
+            const float4 t = *(const float4*)(g + (size_t)s * slab_stride + c);
+            b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
+        }
+        if (nslabs > 1) *(float4*)(g + c) = b;
+        ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        gw += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    ss = wave_sum(ss);
+    gw = wave_sum(gw);
+    const float n = sqrtf(ss);
+    const float a1 = out_scale / (n + NORM_EPS);
+    const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
+#pragma unroll 1
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 b = *(const float4*)(g + c), a = *(const float4*)(w + c);
+        float4 r = make_float4(a1 * b.x - a2 * a.x, a1 * b.y - a2 * a.y, a1 * b.z - a2 * a.z, a1 * b.w - a2 * a.w);
+        if (accumulate) {
+            const float4 o = *(const float4*)(d + c);
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        *(float4*)(d + c) = r;
+    }
+}
+
 // torch.optim.Adam (train.py:57: lr, betas (0.9, 0.99), eps 1e-8, no weight decay) fused with the two
 // power-function EMA copies (src/ema.py:135-140: ema.lerp_(param, beta)).  Step-dependent scalars are read
 // from a small device array so the launch is graph-replayable:
@@ -286,6 +345,22 @@ extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nsla
     else
         hipLaunchKernelGGL(weightnorm_bwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg,
                            nslabs, slab_stride, dW, rows, cols, out_scale, accumulate);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+#endif
+
+#if MAPDIT_DT == 0
+// The 48-register form of mapdit_weightnorm_bwd (same bits) for a launch that is to run beside a GEMM on another stream.  Vector path
+// only: cols, ldg, slab_stride multiples of 4 and 16-byte aligned buffers (every weight of the engine).
+extern "C" int mapdit_weightnorm_bwd_slim(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW,
+                                          int rows, int cols, float out_scale, int accumulate, void* stream) {
+    MD_CHECK(W && G && dW && rows > 0 && cols > 0 && ldg >= cols && nslabs >= 1, "weightnorm_bwd_slim: null/empty argument");
+    const bool vec = (cols % 4 == 0) && (ldg % 4 == 0) && (slab_stride % 4 == 0) &&
+                     ((((uintptr_t)W | (uintptr_t)G | (uintptr_t)dW) & 15) == 0);
+    if (!vec) return mapdit_weightnorm_bwd(W, G, ldg, nslabs, slab_stride, dW, rows, cols, out_scale, accumulate, stream);
+    hipLaunchKernelGGL(weightnorm_bwd_slim_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg, nslabs,
+                       slab_stride, dW, rows, cols, out_scale, accumulate);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

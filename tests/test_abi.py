@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(cdll, s), f"{s} declared in mapdit.h but not exported by libmapdit_hip.so"
     assert sorted(L.EXPORTS) == syms, set(L.EXPORTS) ^ set(syms)
-    assert cdll.mapdit_abi_version() == 4
+    assert cdll.mapdit_abi_version() == 5
 
 
 def test_no_compiler_generated_packed_fp32_code():

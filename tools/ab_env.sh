@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of one environment switch on the default bench step:  tools/ab_env.sh VAR A_VALUE B_VALUE [rounds] [extra bench args]
+# Interleaved runs (A B A B ...), median ms per step of each; output under gpurun_out/ab_<VAR>.log
+var=$1; a=$2; b=$3; rounds=${4:-3}; shift 4
+out=gpurun_out/ab_${var}.log
+mkdir -p gpurun_out; : > $out
+for r in $(seq $rounds); do
+  for v in $a $b; do
+    line=$(env $var=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-f16-leg "$@" 2>/dev/null | tail -1)
+    echo "$var=$v $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ms_per_step", round(d["ms_per_step"],3), "median", round(d["ms_per_step_median"],3), "fc1_ms", round(d["roofline"]["avg_launch_ms"],4))')" | tee -a $out
+  done
+done
