@@ -251,6 +251,8 @@ def main():
                     help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce)")
     ap.add_argument("--rotation-modulation", action="store_true",
                     help="BASELINE config 3's block conditioning (README.md:1-3; not in the reference snapshot: parity unpinned)")
+    ap.add_argument("--mp-off", default="", help="comma-separated off forms of the README's --use-* flags: mp_silu, mp_residual, mp_pos_enc, "
+                                                 "mp_embedding (README.md:57-66; not in the reference snapshot: parity unpinned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -283,13 +285,18 @@ def main():
         B = args.global_batch
     global_batch = B * world
 
+    mp_off = [f.strip() for f in args.mp_off.split(",") if f.strip()]
+    assert all(f in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding") for f in mp_off), f"--mp-off: unknown flag in {mp_off}"
+    unpinned = bool(args.rotation_modulation or mp_off)      # configurations with no reference code behind them
+
     def timed_run(precision, steps, warmup):
         """Builds the model in `precision`, runs `warmup` untimed + `steps` timed training steps; returns the measurements."""
         parity = None
-        if rank == 0 and not args.no_parity and not args.rotation_modulation:
+        if rank == 0 and not args.no_parity and not unpinned:
             parity = parity_leg(args.model, precision, dev)
         torch.manual_seed(0)                               # model seed 0 on every rank: identical replicas, no broadcast needed
         mkw = dict(rotation_modulation=True) if args.rotation_modulation else {}
+        mkw.update({f: False for f in mp_off})
         model = DIT_MODELS[args.model](in_channels=4, input_size=32, num_classes=1000, **mkw).to(dev).train()
         model.gemm_precision = precision
         torch.manual_seed(1000 + rank)                     # from here on every rank draws its OWN timesteps, noise and label drops
@@ -359,7 +366,8 @@ def main():
     achieved = fc1_flops / (fc1_ms * 1e-3) / 1e12 if r["fc1_count"] else None
     at = f"@{global_batch}" if args.scaling == "strong" else f"@{B}/GPU"
     out = {
-        "metric": f"latent-images/sec training step, {args.model} {args.precision}{' rotation-modulation' if args.rotation_modulation else ''} {at}",
+        "metric": f"latent-images/sec training step, {args.model} {args.precision}{' rotation-modulation' if args.rotation_modulation else ''}"
+                  f"{' off:' + '+'.join(mp_off) if mp_off else ''} {at}",
         "value": value, "unit": "latent-img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": statistics.median(per_step),
         "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
@@ -373,7 +381,11 @@ def main():
                    "grad_comm": r["grad_comm"],
                    "seeds": {"model": 0, "data": "1+rank", "t/noise/drop": "1000+rank"}, "final_loss": final_loss},
         "step_mfma_frac": value * 3 * f_fwd / (world * PEAK_BF16_DENSE_TFLOPS * 1e12),
-        "parity": parity if not args.rotation_modulation else {
+        "parity": parity if not unpinned else {
+            "pinned": False,
+            "note": "off forms of the README's --use-* flags (README.md:57-66) are not in the reference snapshot, which hard-wires every flag "
+                    "on (SURVEY F5): there is no reference output to compare with.  The engine is held to this repo's own restatement "
+                    "(oracle.dit_oracle.DiTConfig.mp_*; tests/test_mp_flags_gpu.py): parity unpinned"} if mp_off else {
             "pinned": False,
             "note": "rotation modulation is described in the reference's README but absent from its code snapshot (SURVEY F6): there "
                     "is no reference output to compare with.  The engine is held to this repo's own restatement of the README "
@@ -386,7 +398,7 @@ def main():
     }
     # The same step with IEEE fp16 operands (gemm_precision = "f16": same kernels, same MFMA rate, 10 mantissa bits): the path
     # whose forward logits are inside north_star's 1e-3 of the reference.  The headline above stays BASELINE.json's bf16.
-    if args.precision == "bf16" and world == 1 and not args.no_f16_leg and not args.rotation_modulation:
+    if args.precision == "bf16" and world == 1 and not args.no_f16_leg and not unpinned:
         h = timed_run("f16", args.steps, max(3, args.warmup // 2))
         h_ms = h["fc1_ms"] / max(h["fc1_count"], 1)
         out["f16"] = {"value": world * B * args.steps / h["elapsed"], "unit": "latent-img/s", "ms_per_step": 1e3 * h["elapsed"] / args.steps,
@@ -395,7 +407,7 @@ def main():
                       "fc1_tflops": fc1_flops / (h_ms * 1e-3) / 1e12 if h["fc1_count"] else None,
                       "note": "same engine, IEEE fp16 GEMM / attention operands, static power-of-two loss scale"}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not args.rotation_modulation:
+        if world == 1 and not args.no_cpu_baseline and not unpinned:
             out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps, args.cpu_c1_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

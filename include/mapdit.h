@@ -32,7 +32,8 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 5: mapdit_weightnorm_bwd_slim (the Jacobian beside a GEMM on another stream).  4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
+int mapdit_abi_version(void);   /* 5: mapdit_weightnorm_bwd_slim (the Jacobian beside a GEMM on another stream); mapdit_config_t.mp_off (off forms of four
+                                 * --use-* flags), mapdit_patch_embed_fwd(out_scale), mapdit_scale_copy.  4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
                                  * mapdit_engine_loss_scale, loss_scale must be a power of two.  3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
                                  * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
@@ -253,6 +254,9 @@ int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void*
 int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream);
 /* acc[i] += sum over nslabs of slabs[s*slab_stride + i], in slab order (deterministic split-K reduction). */
 int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
+/* out[i] = alpha * x[i] (abi 5): the label table's gradient when the table is a plain nn.Embedding (MAPDIT_OFF_MP_EMBEDDING) - the
+ * scattered rows, divided by the fp16 loss scale. */
+int mapdit_scale_copy(float* out, const float* x, long n, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Cosine attention (src/layers/attention.py:37-51).  Head-major operands are [B*H][T][head_dim] bf16, row-major.
@@ -305,8 +309,10 @@ int mapdit_attn_generic_bwd(const uint16_t* qn, const uint16_t* kn, const uint16
 /* ------------------------------------------------------------------------------------------------------------
  * Embedding / conditioning / output side (src/dit.py:81-101, timestep_embedder.py, label_embedder.py, final_layer.py).
  * ------------------------------------------------------------------------------------------------------------ */
+/* out_scale (abi 5): 0 = the snapshot's mp_sum(x_embedder(x), pos_embed, 0.5) = (a + b) / sqrt(2) (dit.py:84); 1 = the plain sum
+ * a + b (the off form of README.md:65 --use-mp-pos-enc; unpinned). */
 int mapdit_patch_embed_fwd(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
-                           int ldp, int N, int C, int S, int p, int D, void* stream);
+                           int ldp, int N, int C, int S, int p, int D, float out_scale, void* stream);
 int mapdit_fourier_fwd(const int64_t* t, const float* scale, const float* shift, uint16_t* out, int n, int F,
                        void* stream);
 /* Labels outside [0, table_rows) and timesteps outside [0, nsteps) never index memory: the kernels clamp them and record a
@@ -356,6 +362,7 @@ int mapdit_ddim_step(const float* model_out, const float* x, const float* noise,
 /* ------------------------------------------------------------------------------------------------------------
  * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).
  * ------------------------------------------------------------------------------------------------------------ */
+enum { MAPDIT_OFF_MP_SILU = 1, MAPDIT_OFF_MP_RESIDUAL = 2, MAPDIT_OFF_MP_POS_ENC = 4, MAPDIT_OFF_MP_EMBEDDING = 8 };
 typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
@@ -367,6 +374,15 @@ typedef struct {
     int rotation;   /* != 0: rotation modulation (README.md:1-3; parity unpinned): a block's modulation linear has 5*hidden rows
                      * (theta_a [D/2], scale_a, gate_a, theta_m [D/2], scale_m, gate_m); the rotation is fused into the residual GEMM epilogues and
                      * the residual / modulate backward (mapdit_rot_coef_fwd above).  Not with MAPDIT_PREC_BF16X3. */
+    /* Off forms of four of the reference README's --use-* flags (README.md:57-66; the snapshot hard-wires every one on and holds no
+     * code for the off forms: PARITY UNPINNED, each is this build's restatement of one README line + upstream DiT's form of the same
+     * operation, pinned only to oracle/dit_oracle.py).  0 = the snapshot's arithmetic.  Not with MAPDIT_PREC_BF16X3.
+     *   MAPDIT_OFF_MP_SILU      plain SiLU wherever the snapshot has MPSiLU (mp_silu.py:7: no division by 0.596)
+     *   MAPDIT_OFF_MP_RESIDUAL  x + gate * branch instead of mp_sum(x, gate * branch, 0.3) (dit_block.py:35-36)
+     *   MAPDIT_OFF_MP_POS_ENC   x_embedder(x) + pos_embed instead of mp_sum(., ., 0.5) (dit.py:84)
+     *   MAPDIT_OFF_MP_EMBEDDING nn.Embedding for the labels: plain row gather, no row normalisation, no in-place rewrite
+     *                           (mp_embedding.py:15-24) */
+    int mp_off;
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
                        * divided by it again before it is written.  A finite power of two (anything else is refused: the division
@@ -495,7 +511,7 @@ int mapdit_attn_generic_bwd_f16(const uint16_t* qn, const uint16_t* kn, const ui
                                 const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                                 int head_dim, void* stream);
 int mapdit_patch_embed_fwd_f16(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
-                               int ldp, int N, int C, int S, int p, int D, void* stream);
+                               int ldp, int N, int C, int S, int p, int D, float out_scale, void* stream);
 int mapdit_cond_combine_fwd_f16(const float* temb, const float* table, const int64_t* y, float* c, uint16_t* c_silu,
                                 uint16_t* c_f16, int n, int D, int table_rows, void* stream);
 int mapdit_cond_combine_bwd_f16(const float* c, const float* dcs, const float* dcd, const int64_t* y, uint16_t* dtemb,

@@ -47,7 +47,11 @@ class AdamScalars(C.Structure):    # mapdit_adam_scalars_t
 class Config(C.Structure):
     _fields_ = [("depth", ci), ("hidden", ci), ("patch", ci), ("input_size", ci), ("in_channels", ci),
                 ("num_heads", ci), ("mlp_hidden", ci), ("table_rows", ci), ("max_batch", ci), ("precision", ci), ("rotation", ci),
-                ("loss_scale", cf)]
+                ("mp_off", ci), ("loss_scale", cf)]
+
+
+# mapdit_config_t.mp_off bits (mapdit.h MAPDIT_OFF_*): off forms of four README --use-* flags (parity unpinned)
+MP_OFF = {"mp_silu": 1, "mp_residual": 2, "mp_pos_enc": 4, "mp_embedding": 8}
 
 
 # engine precisions (mapdit.h MAPDIT_PREC_*).  "f16": the bf16 engine with IEEE fp16 operands - same speed, 10 mantissa bits
@@ -88,6 +92,7 @@ _SIGS = {
     "mapdit_f32_to_bf16": [vp, vp, cl, cf, vp],
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
     "mapdit_sum_slabs": [vp, vp, ci, cl, cl, vp],
+    "mapdit_scale_copy": [vp, vp, cl, cf, vp],
     "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
@@ -99,7 +104,7 @@ _SIGS = {
     "mapdit_qkv_merge_bwd_generic": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_generic_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_generic_bwd": [vp] * 10 + [ci, ci, ci, ci, vp],
-    "mapdit_patch_embed_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "mapdit_patch_embed_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
     "mapdit_fourier_fwd": [vp, vp, vp, vp, ci, ci, vp],
     "mapdit_cond_combine_fwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
     "mapdit_cond_combine_bwd": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],

@@ -20,7 +20,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ pos, float* __restrict__ out,
                                                             bf16_t* __restrict__ patches, int ldp, int C, int S, int p,
-                                                            int D, long M) {
+                                                            int D, long M, float c5) {
     extern __shared__ float sm[];
     const int P = p * p * C, P1 = P + 1, grid = S / p, T = grid * grid;
     float* ws = sm;                    // [P1][DT]
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
         if (m >= M) break;
         float a = 0.f;
         for (int j = 0; j < P1; ++j) a += ps[tok * P1 + j] * ws[j * DT + d];
-        out[m * D + d0 + d] = (a + pos[(size_t)(m % T) * D + d0 + d]) * C5;
+        out[m * D + d0 + d] = (a + pos[(size_t)(m % T) * D + d0 + d]) * c5;
     }
 }
 
@@ -203,7 +203,8 @@ __global__ void cfg_combine_kernel(const float* __restrict__ in, float* __restri
 MD_NS_CLOSE
 
 extern "C" int MD_SYM(patch_embed_fwd)(const float* x, const float* w_eff, const float* pos, float* out, uint16_t* patches,
-                                      int ldp, int N, int C, int S, int p, int D, void* stream) {
+                                      int ldp, int N, int C, int S, int p, int D, float out_scale, void* stream) {
+    const float c5 = out_scale > 0.f ? out_scale : C5;       // 0: mp_sum(., ., 0.5) of the snapshot (dit.py:84); 1: the plain sum
     MD_CHECK(x && w_eff && pos && out, "patch_embed_fwd: null argument");
     MD_CHECK(S % p == 0 && D % 128 == 0, "patch_embed_fwd: S=%d p=%d D=%d unsupported", S, p, D);
     const int P1 = p * p * C + 1, T = (S / p) * (S / p);
@@ -212,13 +213,13 @@ extern "C" int MD_SYM(patch_embed_fwd)(const float* x, const float* w_eff, const
     const size_t shm = (size_t)(P1 * 128 + 64 * P1) * 4;
     if (shm <= 64 * 1024) {
         hipLaunchKernelGGL(patch_embed_fwd_kernel<128>, dim3(cdiv(M, 64), D / 128), dim3(256), shm, (hipStream_t)stream, x, w_eff,
-                           pos, out, patches, ldp, C, S, p, D, M);
+                           pos, out, patches, ldp, C, S, p, D, M, c5);
     } else {                                   // patch-8 models: 257-wide rows, 64-feature tiles, > 64 KiB of LDS
         const size_t shm64 = (size_t)(P1 * 64 + 64 * P1) * 4;
         MD_CHECK(shm64 <= 150 * 1024, "patch_embed_fwd: patch dim %d too large", P1 - 1);
         (void)hipFuncSetAttribute((const void*)patch_embed_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64);
         hipLaunchKernelGGL(patch_embed_fwd_kernel<64>, dim3(cdiv(M, 64), D / 64), dim3(256), shm64, (hipStream_t)stream, x, w_eff,
-                           pos, out, patches, ldp, C, S, p, D, M);
+                           pos, out, patches, ldp, C, S, p, D, M, c5);
     }
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;

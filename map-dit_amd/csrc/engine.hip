@@ -62,6 +62,16 @@ struct mapdit_engine {
     // rows and their scales, and mapdit_attn_cos_bwd_fused applies the Jacobian and writes dqkv).  MAPDIT_ATTN72=0 / MAPDIT_ATTN72_RAW=0
     // fall back to the split / merge kernels around the attention (A/B runs).
     bool raw72 = false;
+    // Off forms of the README's --use-* flags (mapdit_config_t.mp_off; parity unpinned).  Each is a handful of scalars, no kernel:
+    //  * plain SiLU = 0.596 x MPSiLU, and every MPSiLU of the network feeds a LINEAR layer (MLP fc2, the modulation linears, the
+    //    timestep MLP's second linear): the kernels keep computing MPSiLU and its derivative factor, and the consuming product is
+    //    scaled by s_act = 0.596 - the MLP branch through its residual coefficient cb_mlp (forward epilogue and backward alike), the
+    //    conditioning linears through the GEMM's alpha (forward, dX and dW);
+    //  * plain residual: ca = cb = 1 instead of 0.7 / sqrt(0.58), 0.3 / sqrt(0.58);
+    //  * plain positional sum: c5 = 1 instead of 1 / sqrt(2) in the patch embedding and its weight gradient;
+    //  * nn.Embedding: the label table is used as stored (no normalised copy, no rewrite) and its gradient is the scattered rows.
+    float ca = 0.f, cb_attn = 0.f, cb_mlp = 0.f, s_act = 1.f, c5 = 0.70710678118654752f;
+    bool plain_embedding = false;
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
     float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
     int last_N = 0;
@@ -150,6 +160,8 @@ struct mapdit_engine {
 namespace {
 
 int pidx_block(int i, int which) { return MAPDIT_NUM_GLOBAL + i * MAPDIT_NUM_BLOCK + which; }
+
+const float CA = 0.7f / sqrtf(0.58f), CB = 0.3f / sqrtf(0.58f);   // mp_sum(x, y, 0.3): src/utils.py:15-16
 
 // MAPDIT_SIDE_JAC=1 moves the weight-norm Jacobians to a side stream (round 5, measured and NOT the default: see the comment at
 // mapdit_engine::side); read once.
@@ -360,6 +372,9 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(loss_scale_ok(c->loss_scale), "engine: loss_scale=%g must be 0 (automatic) or a finite power of two", (double)c->loss_scale);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
+    MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING)) == 0,
+             "engine: unknown bits in mp_off=%d", c->mp_off);
+    MD_CHECK(!c->mp_off || c->precision != MAPDIT_PREC_BF16X3, "engine: the --use-* off forms are not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
              "engine: head_dim=%d unsupported (<= 96)", c->hidden / (c->num_heads ? c->num_heads : 1));
     MD_CHECK(c->input_size % c->patch == 0, "engine: input_size %% patch != 0");
@@ -400,6 +415,12 @@ void init_dims(mapdit_engine* e) {
     const int D = c.hidden;
     e->rot = c.rotation != 0;
     e->f16 = c.precision == MAPDIT_PREC_F16;
+    e->s_act = (c.mp_off & MAPDIT_OFF_MP_SILU) ? MP_SILU_DIV : 1.f;          // silu(h) = 0.596 * mp_silu(h)
+    e->ca = (c.mp_off & MAPDIT_OFF_MP_RESIDUAL) ? 1.f : CA;
+    e->cb_attn = (c.mp_off & MAPDIT_OFF_MP_RESIDUAL) ? 1.f : CB;
+    e->cb_mlp = e->cb_attn * e->s_act;                                        // the MLP branch enters only as cb * gate * fc2(act)
+    e->c5 = (c.mp_off & MAPDIT_OFF_MP_POS_ENC) ? 1.f : 0.70710678118654752f;
+    e->plain_embedding = (c.mp_off & MAPDIT_OFF_MP_EMBEDDING) != 0;
     {   // 16-bit engines: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream, for A/B runs; =f: fp16 engine only)
         const char* v = getenv("MAPDIT_DX16");
         e->dx16 = c.precision != MAPDIT_PREC_BF16X3 && !(v && v[0] == '0') && (e->f16 || !(v && v[0] == 'f'));
@@ -458,13 +479,12 @@ mapdit_epilogue_t epi_dsilu(bf16_t* out, const bf16_t* pre, int ldo) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
     e.kind = MAPDIT_EPI_DSILU; e.out = out; e.aux = pre; e.ldo = ldo; return e;
 }
-const float CA = 0.7f / sqrtf(0.58f), CB = 0.3f / sqrtf(0.58f);   // mp_sum(x, y, 0.3): src/utils.py:15-16
-mapdit_epilogue_t epi_resid(bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo,
+mapdit_epilogue_t epi_resid(float ca, float cb, bf16_t* y, const float* xin, float* xout, const float* gate, int ldg, int rows, int ldo,
                             bf16_t* xm_next, const float* nshift, const float* nscale, int ldn, const float* ngain, int rot = 0) {
     mapdit_epilogue_t e; memset(&e, 0, sizeof(e));
     e.rot2 = rot;                                      // rotation form: nscale / nshift are the A / B rows (mapdit_rot_coef_fwd)
     e.kind = MAPDIT_EPI_RESID; e.out = y; e.out2 = xout; e.aux = xin; e.gate = gate; e.ldg = ldg; e.rows_per_sample = rows;
-    e.ldo = ldo; e.alpha = CA; e.beta = CB;
+    e.ldo = ldo; e.alpha = ca; e.beta = cb;
     e.out3 = xm_next; e.shift2 = nshift; e.scale2 = nscale; e.ld2 = ldn; e.gain2 = ngain;   // modulate() of the next branch
     return e;
 }
@@ -757,7 +777,8 @@ extern "C" int mapdit_engine_bind(mapdit_engine_t* e, float* const* params_host,
                 job(e->params[i], e->wimg[i].rows, e->wimg[i].cols, 1.f, e->wimg[i].img, nullptr,
                     i < e->cp.img3.size() ? e->cp.img3[i] : nullptr);
         job(e->params[MAPDIT_P_X_EMB], e->D, e->P1, 1.f, nullptr, e->wx_eff);
-        job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff);
+        if (!e->plain_embedding)            // (nn.Embedding: the stored table is what the forward gathers from)
+            job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff);
     }
     return MAPDIT_OK;
 }
@@ -819,7 +840,7 @@ static int forward_precise(mapdit_engine* e, const float* x, const int64_t* t, c
         TRY(mapdit_patchify32(x, e->pg.patches, e->ldp, N, c.in_channels, c.input_size, c.patch, st));
     }
     TRY(mapdit_patch_embed_fwd(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], nullptr, e->ldp, N, c.in_channels, c.input_size,
-                               c.patch, D, st));
+                               c.patch, D, 0.f, st));
     TRY(mapdit_split3(e->c, D, px.As, N, D, MAPDIT_SPLIT_A, SILU, st));
     TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, px.As, 3 * D, e->wimg[pidx_block(0, MAPDIT_B_MOD)].img, 3 * D, epi_f32(e->mod_all, ldm), st));
     TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, px.As, 3 * D, e->wimg[MAPDIT_P_F_MOD].img, 3 * D, epi_f32(e->fmod, 2 * D), st));
@@ -1002,33 +1023,35 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // conditioning: c = mp_sum(t_embedder(t), y_embedder(y), 0.5)        (dit.py:86-88), fp32-accurate: every product of this
     // [samples, D] path runs on two-term split operands (see mapdit_engine::cp).  The backward keeps its bf16 operands: the
     // Fourier features, the timestep MLP's pre-activation and activation are also written as bf16 for it.
-    auto cond_linear = [&](const float* src, int K, int op, int widx, int nout, float* dst, int ldo) -> int {
+    auto cond_linear = [&](const float* src, int K, int op, int widx, int nout, float* dst, int ldo, float alpha) -> int {
         TRY(mapdit_split3(src, K, e->cp.As, N, K, MAPDIT_SPLIT_A, op, st));
-        return gemm(MAPDIT_NT, N, nout, 3 * K, e->cp.As, 3 * K, e->cp.img3[widx], 3 * K, epi_f32(dst, ldo), st);
+        return gemm(MAPDIT_NT, N, nout, 3 * K, e->cp.As, 3 * K, e->cp.img3[widx], 3 * K, epi_f32(dst, ldo, alpha), st);
     };
+    const float sa = e->s_act;        // 1, or 0.596 for plain SiLU: the scale of every linear that consumes an MPSiLU (mapdit_engine::s_act)
     TRY(mapdit_fourier32(t, e->params[MAPDIT_P_FOURIER_SCALE], e->params[MAPDIT_P_FOURIER_SHIFT], e->cp.four32, N, FOURIER, st));
-    TRY(cond_linear(e->cp.four32, FOURIER, MAPDIT_SPLIT_OP_NONE, MAPDIT_P_T0, D, e->cp.h1, D));
-    TRY(cond_linear(e->cp.h1, D, MAPDIT_SPLIT_OP_MPSILU, MAPDIT_P_T2, D, e->temb, D));
+    TRY(cond_linear(e->cp.four32, FOURIER, MAPDIT_SPLIT_OP_NONE, MAPDIT_P_T0, D, e->cp.h1, D, 1.f));
+    TRY(cond_linear(e->cp.h1, D, MAPDIT_SPLIT_OP_MPSILU, MAPDIT_P_T2, D, e->temb, D, sa));
     if (save) {
         TRY(to16(e, e->cp.four32, e->four, (long)N * FOURIER, 1.f, st));
         TRY(to16(e, e->cp.h1, e->h1_pre, (long)N * D, 1.f, st));
         TRY(mpsilu16(e, e->cp.h1, e->h1_act, (long)N * D, st));
     }
-    TRY(DT_FN(e, mapdit_cond_combine_fwd)(e->temb, e->table_eff, y_eff, e->c, e->c_silu, e->c_bf, N, D, c.table_rows, st));
+    TRY(DT_FN(e, mapdit_cond_combine_fwd)(e->temb, e->plain_embedding ? e->params[MAPDIT_P_Y_EMB] : e->table_eff, y_eff, e->c, e->c_silu, e->c_bf,
+                                          N, D, c.table_rows, st));
     if (save) {
         hipError_t he = hipMemcpyAsync(e->y_copy, y_eff, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)st);
         MD_CHECK(he == hipSuccess, "engine_forward: label copy failed: %s", hipGetErrorString(he));
     }
     // patch embedding                                                  (dit.py:81-84)
     TRY(DT_FN(e, mapdit_patch_embed_fwd)(x, e->wx_eff, e->params[MAPDIT_P_POS_EMBED], e->X[0], save ? e->patches : nullptr, e->ldp, N,
-                               c.in_channels, c.input_size, c.patch, D, st));
+                               c.in_channels, c.input_size, c.patch, D, e->c5, st));
     // (shift, scale, gate) x 2 of EVERY block = MPLinearChunk(MPSiLU(c)) (dit_block.py:33) as ONE GEMM against the
     // contiguous [L*6D, D] weight image, plus the final layer's (shift, scale); all later modulate()s are fused into
     // the residual GEMM epilogues that produce their inputs.
     const int ldm = e->ldm;
     TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_MPSILU, st));
-    TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm), st));
-    TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D), st));
+    TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm, sa), st));
+    TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D, sa), st));
     // The (scale, shift) rows of a branch's modulate and the gain it blends them with.  Rotation modulation: the A / B coefficient
     // rows of y[j] = A x[j] + B x[j ^ 1] (mapdit_rot_coef_fwd: one pass over [samples, L * 2 * D], one sincos per pair), read by the
     // same fused epilogues in their rot form - slot (block, branch) at column (2 * block + branch) * D.
@@ -1098,16 +1121,16 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         else if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         else TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
-                 epi_resid(save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
+                 epi_resid(e->ca, e->cb_attn, save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size();
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm16(e, MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm16(e, MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
-                 i + 1 < L ? epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
+                 i + 1 < L ? epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
                                        sh_of(i + 1, 0), sc_of(i + 1, 0), ldn, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)), rot)
-                           : epi_resid(save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
+                           : epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
                                        e->params[MAPDIT_P_F_GAIN]), st));
     }
     float* xL = e->X[save ? 2 * L : (2 * L) % 3];
@@ -1226,6 +1249,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         TRY(gemm16(e, MAPDIT_NN, N, D, NSCALE, da, NSCALE, W(pi), D, epi_f32(e->dcd, D, 1.f, 1), st));
         TRY(linear_dw(e, pi, da, NSCALE, e->c_bf, D, N, 1.f, st));
     }
+    const float sa = e->s_act;        // scale of every product that consumes an MPSiLU (plain SiLU = 0.596 x MPSiLU: mapdit_engine::s_act)
     TRY(linear_dw(e, MAPDIT_P_F_LIN, e->dlin, e->ldl, e->xmodf, D, M, 1.f, st));
     {
         const BlockBufs& bl = e->blk[L - 1];
@@ -1235,13 +1259,14 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         a.y_up = bl.y2; a.g_up = e->mod_all + (size_t)(L - 1) * e->MW + e->o_gm; a.ldg_up = e->ldm; a.dy_up = e->dy;
         a.dg_up = e->dmod + (size_t)(L - 1) * e->MW + e->o_gm; a.ldd_up = e->ldm;
         if (e->dx16) a.dx_bf = e->DXa16; else a.dx = e->DXa;
-        a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+        a.n_samples = N; a.T = T; a.D = D; a.ca = e->ca; a.cb = e->cb_mlp;      // (the residual above the final layer: block L-1's MLP branch)
         TRY(dx_resid_mod_bwd(e, M, e->ldl, e->dlin, e->ldl, W(MAPDIT_P_F_LIN), a, G(MAPDIT_P_F_GAIN), st));
     }
     TRY(to16(e, e->dfmod, e->dmod_bf, (long)N * 2 * D, 1.f, st));
-    TRY(gemm16(e, MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, 1.f, 1), st));
-    TRY(linear_dw(e, MAPDIT_P_F_MOD, e->dmod_bf, 2 * D, e->c_silu, D, N, 1.f, st));
+    TRY(gemm16(e, MAPDIT_NN, N, D, 2 * D, e->dmod_bf, 2 * D, W(MAPDIT_P_F_MOD), D, epi_f32(e->dcs, D, sa, 1), st));
+    TRY(linear_dw(e, MAPDIT_P_F_MOD, e->dmod_bf, 2 * D, e->c_silu, D, N, sa, st));
     }   // stage 0
+    const float sa = e->s_act;
 
     // ---- blocks, last to first.  Invariant: DXa = d/d X[2i+2]; dy = grad of the MLP branch output y2_i. -----------
     for (int i = L - 1; i >= 0; --i) {
@@ -1269,7 +1294,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
             a.dshift = dmod + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
             a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
             if (e->dx16) a.dx_bf = e->DXb16; else a.dx = e->DXb;
-            a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+            a.n_samples = N; a.T = T; a.D = D; a.ca = e->ca; a.cb = e->cb_attn;       // (the residual above: this block's attention branch)
             const RotBwd rb{mod + e->o_shm, mod + e->o_scm, dmod + e->o_shm, dmod + e->o_scm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
             TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st,
                                  e->rot ? &rb : nullptr));
@@ -1298,7 +1323,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
             } else {
                 a.dx_bf = e->dx0_bf;    // grad wrt the patch embedding output, operand of the x_embedder dW GEMM
             }
-            a.n_samples = N; a.T = T; a.D = D; a.ca = CA; a.cb = CB;
+            a.n_samples = N; a.T = T; a.D = D; a.ca = e->ca; a.cb = e->cb_mlp;        // (the residual above: block i-1's MLP branch)
             const RotBwd rb{mod + e->o_sha, mod + e->o_sca, dmod + e->o_sha, dmod + e->o_sca, e->params[pidx_block(i, MAPDIT_B_GAIN_MSA)]};
             TRY(dx_resid_mod_bwd(e, M, 3 * D, e->dqkv, 3 * D, W(pidx_block(i, MAPDIT_B_QKV)), a, G(pidx_block(i, MAPDIT_B_GAIN_MSA)), st,
                                  e->rot ? &rb : nullptr));
@@ -1306,11 +1331,11 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // modulation linear of this block (its six gradient chunks are complete now): dW here, so the block's gradient
         // slice is final when its stage ends (the DP reducer relies on that); d c_silu for all blocks in one GEMM below
         TRY(to16_2d(e, dmod, ldm, e->dmod_bf + (size_t)i * e->MW, ldm, N, e->MW, 1.f, st));
-        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * e->MW, ldm, e->c_silu, D, N, 1.f, st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_MOD), e->dmod_bf + (size_t)i * e->MW, ldm, e->c_silu, D, N, sa, st));
         if (i == 0) {
             // d c_silu += dmod_all W_mod_all: ONE split-K GEMM over K = L*6D, slabs summed into dcs
             TRY(g_claim(e, 0, st));                            // e->G = slab buffer 0: a Jacobian of the side stream may still read it
-            mapdit_epilogue_t ep = epi_f32(e->G, D, 1.f);
+            mapdit_epilogue_t ep = epi_f32(e->G, D, sa);
             const long slab = (long)N * D;
             ep.split_k = pick_split_k(N, D, ldm, e->G_cap / slab);
             ep.slab_stride = slab;
@@ -1323,7 +1348,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     if (stage_to < L + 1) return side_join(e, st);         // the stages' gradients are final in the caller's stream order
     // ---- patch embedding: x0 = (x_embedder(patches) + pos) * C5 -----------------------------------------------------
     {
-        const float c5 = 0.70710678118654752f;
+        const float c5 = e->c5;
         const long slab = (long)D * e->ldp;
         TRY(g_claim(e, 0, st));
         mapdit_epilogue_t ep = epi_f32(e->G, e->ldp, c5 * e->ginv);
@@ -1334,11 +1359,15 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     }
     // ---- conditioning path ------------------------------------------------------------------------------------------
     TRY(DT_FN(e, mapdit_cond_combine_bwd)(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, c.table_rows, st));
-    TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D) * e->ginv, 0,
-                              st));
+    if (e->plain_embedding)           // nn.Embedding: the gradient is the scattered rows (no normalisation Jacobian)
+        TRY(mapdit_scale_copy(G(MAPDIT_P_Y_EMB), e->dtable, (long)c.table_rows * D, e->ginv, st));
+    else
+        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_Y_EMB], e->dtable, D, 1, 0, G(MAPDIT_P_Y_EMB), c.table_rows, D, sqrtf((float)D) * e->ginv, 0,
+                                  st));
     TRY(gemm16(e, MAPDIT_NN, N, D, D, e->dtemb_bf, D, W(MAPDIT_P_T2), D, epi_dsilu(e->dh1_bf, e->h1_pre, D), st));
-    TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, 1.f, st));
-    TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, 1.f, st));
+    // (plain SiLU: temb = 0.596 W2 mp_silu(h1) - the factor reaches both weight gradients of the timestep MLP; dh1 itself has no other use)
+    TRY(linear_dw(e, MAPDIT_P_T2, e->dtemb_bf, D, e->h1_act, D, N, sa, st));
+    TRY(linear_dw(e, MAPDIT_P_T0, e->dh1_bf, D, e->four, FOURIER, N, sa, st));
     e->have_saved = false;
     e->next_stage = 0;
     return side_join(e, st);

@@ -374,6 +374,11 @@ __global__ void f32_to_bf16_2d_kernel(const float* __restrict__ x, int ldx, bf16
     const int r = (int)(i / cols), c = (int)(i % cols);
     out[(size_t)r * ldo + c] = cvt16(alpha * x[(size_t)r * ldx + c]);
 }
+// out[i] = alpha * x[i]
+__global__ void scale_copy_kernel(float* __restrict__ out, const float* __restrict__ x, long n, float alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha * x[i];
+}
 // acc[i] += sum_s slabs[s*stride + i]   (fixed order: deterministic split-K reduction)
 __global__ void sum_slabs_kernel(float* __restrict__ acc, const float* __restrict__ slabs, int nslabs, long stride, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,6 +399,12 @@ extern "C" int MD_SYM_F32_TO_16_2D(const float* x, int ldx, uint16_t* out, int l
 }
 
 #if MAPDIT_DT == 0          // no 16-bit operand: one copy in the library
+extern "C" int mapdit_scale_copy(float* out, const float* x, long n, float alpha, void* stream) {
+    MD_CHECK(out && x && n > 0, "scale_copy: bad argument");
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, x, n, alpha);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
 extern "C" int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream) {
     MD_CHECK(acc && slabs && nslabs >= 1 && n > 0, "sum_slabs: bad argument");
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, acc, slabs, nslabs, slab_stride, n);

@@ -192,6 +192,7 @@ class _Runtime:
                             input_size=model.input_size, in_channels=model.in_channels, num_heads=model.num_heads,
                             mlp_hidden=model.blocks[0].mlp.hidden_dim, table_rows=rows, max_batch=max_batch,
                             precision=L.PRECISIONS[precision], rotation=int(getattr(model, "rotation_modulation", False)),
+                            mp_off=sum(bit for name, bit in L.MP_OFF.items() if not getattr(model, name, True)),
                             loss_scale=float(getattr(model, "loss_scale", 0.0)) if precision == "f16" else 0.0)
         need = lib.engine_workspace_bytes(C.byref(self.cfg), int(train))
         if need == 0:
@@ -277,7 +278,8 @@ class DiT(nn.Module):
 
     def __init__(self, depth: int, hidden_size: int, patch_size: int, input_size: int = 32, in_channels: int = 3,
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
-                 learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True):
+                 learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True,
+                 mp_silu: bool = True, mp_residual: bool = True, mp_pos_enc: bool = True, mp_embedding: bool = True):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -297,12 +299,20 @@ class DiT(nn.Module):
         # (mp_linear.py:38-40, 68-70, mp_embedding.py:17-19) and keeps everything else: the one flag whose off-path can be read
         # off the snapshot's code; the other seven name layers the snapshot does not contain.
         self.forced_weight_normalization = bool(forced_weight_normalization)
+        # Off forms of four more README flags (README.md:62-66: --use-mp-residual, --use-mp-silu, --use-mp-pos-enc, --use-mp-embedding).
+        # The snapshot hard-wires them on and holds no code for the off forms: PARITY UNPINNED - each is this build's
+        # restatement of one README line with upstream DiT's form of the operation (oracle.dit_oracle.DiTConfig), held to that
+        # restatement by tests/test_mp_flags_gpu.py.  True = the snapshot's arithmetic.  The remaining three off forms (LayerNorm, biased
+        # nn.Linear, plain SDPA) name layers with parameters / kernels the snapshot does not have and stay refused (train.py).
+        self.mp_silu, self.mp_residual = bool(mp_silu), bool(mp_residual)
+        self.mp_pos_enc, self.mp_embedding = bool(mp_pos_enc), bool(mp_embedding)
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
         self.y_embedder = LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
         pe = torch.from_numpy(get_2d_sincos_pos_embed(hidden_size, input_size // patch_size)).float().unsqueeze(0)
-        pe = pe * math.sqrt(pe.shape[-1]) / (torch.linalg.vector_norm(pe, dim=-1, keepdim=True) + 1e-4)   # dit.py:46-48
+        if self.mp_pos_enc:           # (off form: the raw table, added plainly, as upstream DiT does)
+            pe = pe * math.sqrt(pe.shape[-1]) / (torch.linalg.vector_norm(pe, dim=-1, keepdim=True) + 1e-4)   # dit.py:46-48
         self.register_buffer("pos_embed", pe)
         self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, rotation_modulation=self.rotation_modulation)
                                      for _ in range(depth)])
@@ -536,7 +546,8 @@ class DiT(nn.Module):
         new = DiT(depth=self.depth, hidden_size=self.hidden_size, patch_size=self.patch_size, input_size=self.input_size,
                   in_channels=self.in_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
                   class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
-                  rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization)
+                  rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization,
+                  mp_silu=self.mp_silu, mp_residual=self.mp_residual, mp_pos_enc=self.mp_pos_enc, mp_embedding=self.mp_embedding)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

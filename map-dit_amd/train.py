@@ -29,12 +29,21 @@ MP_FLAGS = ["cosine-attention", "weight-normalization", "forced-weight-normaliza
             "no-layernorm", "mp-pos-enc", "mp-embedding"]          # reference README.md:59-66
 
 
+# Off forms this engine builds besides --no-use-forced-weight-normalization (DiT(..., mp_silu=False) etc.; src/dit.py).  The other
+# three (--no-use-cosine-attention, --no-use-weight-normalization, --no-use-no-layernorm) name layers the snapshot does not contain
+# (plain SDPA with learnt scale, biased nn.Linear, LayerNorm) and are refused.
+BUILT_OFF_FORMS = ["mp-residual", "mp-silu", "mp-pos-enc", "mp-embedding"]
+
+
 def get_model(args):
     """reference utils.py:9-17."""
     a = vars(args) if isinstance(args, argparse.Namespace) else args
     kw = dict(rotation_modulation=True) if a.get("use_rotation_modulation") else {}
     if not a.get("use_forced_weight_normalization", True):
         kw["forced_weight_normalization"] = False
+    for flag in BUILT_OFF_FORMS:                    # off forms that are built (parity unpinned: README lines, no reference code)
+        if not a.get("use_" + flag.replace("-", "_"), True):
+            kw[flag.replace("-", "_")] = False
     return DIT_MODELS[a["model"]](in_channels=a["in_channels"], input_size=a["input_size"], num_classes=a["num_classes"], **kw)
 
 
@@ -105,11 +114,16 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    # --no-use-forced-weight-normalization is the one off-path the snapshot's code defines (skip the in-place rewrite)
-    off = [f for f in MP_FLAGS if not getattr(args, "use_" + f.replace("-", "_")) and f != "forced-weight-normalization"]
+    # --no-use-forced-weight-normalization is the one off-path the snapshot's code defines (skip the in-place rewrite); four more are
+    # built as restatements of their README lines (BUILT_OFF_FORMS, parity unpinned); the rest is refused
+    off = [f for f in MP_FLAGS if not getattr(args, "use_" + f.replace("-", "_"))
+           and f != "forced-weight-normalization" and f not in BUILT_OFF_FORMS]
     if off:
-        raise NotImplementedError(f"--no-use-{off[0]}: the reference snapshot hard-wires every magnitude-preserving "
-                                  "feature on (SURVEY F5) and so does this engine")
+        raise NotImplementedError(f"--no-use-{off[0]}: the reference snapshot hard-wires every magnitude-preserving feature on (SURVEY F5) "
+                                  "and holds no code for this layer's off form; built off forms: --no-use-forced-weight-normalization, "
+                                  + ", ".join("--no-use-" + f for f in BUILT_OFF_FORMS))
+    if args.precision == "bf16x3" and any(not getattr(args, "use_" + f.replace("-", "_")) for f in BUILT_OFF_FORMS):
+        raise NotImplementedError("the --no-use-mp-* off forms are built for the f16 / bf16 engines, not for --precision bf16x3")
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -44,6 +44,14 @@ class DiTConfig:
     # NOT in the reference snapshot (its README.md:1-3 describes it): the block conditioning by rotation modulation.
     # PARITY UNPINNED - see modulate_rot.
     rotation_modulation: bool = False
+    # Off forms of four of the README's --use-* flags (reference README.md:57-66).  NOT in the reference snapshot, which hard-wires every
+    # magnitude-preserving feature on and contains none of the layers the off forms name: PARITY UNPINNED - each off form
+    # below is this build's restatement of one README line together with upstream DiT's form of the same operation, and changes exactly
+    # the named operation.  True (the default) is the snapshot's arithmetic.
+    mp_silu: bool = True          # False: plain SiLU (no division by 0.596) wherever the snapshot has MPSiLU
+    mp_residual: bool = True      # False: x + gate * branch  instead of  mp_sum(x, gate * branch, 0.3)
+    mp_pos_enc: bool = True       # False: x_embedder(x) + pos_embed with the raw sin-cos table instead of mp_sum(.., normalize(table), 0.5)
+    mp_embedding: bool = True     # False: nn.Embedding (plain row gather, no row normalisation) for the class labels
 
     @property
     def grid(self) -> int:
@@ -70,6 +78,9 @@ class DiTConfig:
         d = asdict(self)
         if not d["rotation_modulation"]:
             del d["rotation_modulation"]
+        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding"):      # (likewise: only when switched off)
+            if d[k]:
+                del d[k]
         return d
 
 
@@ -129,6 +140,16 @@ def modulate_rot(x: Tensor, theta: Tensor, scale: Tensor, gain) -> Tensor:
 def mp_silu(x: Tensor) -> Tensor:
     """src/basic/mp_silu.py:5-7."""
     return torch.nn.functional.silu(x) / MP_SILU_DIV
+
+
+def act_fn(cfg):
+    """The block / conditioning nonlinearity: MPSiLU (snapshot) or, with ``mp_silu=False`` (README.md:63; unpinned), plain SiLU."""
+    return mp_silu if getattr(cfg, "mp_silu", True) else torch.nn.functional.silu
+
+
+def residual_sum(cfg, x: Tensor, branch: Tensor) -> Tensor:
+    """dit_block.py:35-36: mp_sum(x, gate * branch, 0.3); with ``mp_residual=False`` (README.md:62; unpinned) the plain residual."""
+    return mp_sum(x, branch, RESIDUAL_T) if getattr(cfg, "mp_residual", True) else x + branch
 
 
 def patchify(x: Tensor, p: int) -> Tensor:
@@ -233,9 +254,11 @@ def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_iden
     return torch.nn.functional.linear(_at(rnd, "x:" + layer)(x), _at(rnd, "w:" + layer)(w_eff))
 
 
-def mp_embedding(idx: Tensor, sd: Dict[str, Tensor], key: str, train: bool) -> Tensor:
-    """src/basic/mp_embedding.py:15-24."""
+def mp_embedding(idx: Tensor, sd: Dict[str, Tensor], key: str, train: bool, mp: bool = True) -> Tensor:
+    """src/basic/mp_embedding.py:15-24.  ``mp=False`` (README.md:66 off form; unpinned): nn.Embedding's plain gather."""
     w = sd[key]
+    if not mp:
+        return w[idx]
     if train:
         with torch.no_grad():
             w.copy_(normalize(w))
@@ -310,7 +333,7 @@ def init_state_dict(cfg: DiTConfig, seed: int = 0, gains: Optional[float] = None
     for k, shp in param_shapes(cfg).items():
         if k == "pos_embed":
             pe = torch.from_numpy(sincos_pos_embed(cfg.hidden_size, cfg.grid)).float().unsqueeze(0)
-            sd[k] = normalize(pe)
+            sd[k] = normalize(pe) if cfg.mp_pos_enc else pe          # (off form: the raw table, as upstream DiT adds it)
         elif k.endswith("embedding.scale"):
             sd[k] = (2 * math.pi * torch.randn(shp, generator=g)).float()
         elif k.endswith("embedding.shift"):
@@ -366,9 +389,9 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
     return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd)
 
 
-def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None) -> Tensor:
+def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None, act=mp_silu) -> Tensor:
     """src/layers/mlp.py:16-25."""
-    h = mp_silu(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
+    h = act(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
     _rec(trace, prefix + "hact", _at(rnd, "x:fc2")(h))
     return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
 
@@ -383,7 +406,7 @@ class _WithFull:
 def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
-    mod = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd)
+    mod = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd)
     _rec(trace, p + "mod", mod)
     if cfg.rotation_modulation:             # (theta, scale, gate) x 2 with D/2-wide angle chunks; see modulate_rot
         D = x.shape[-1]
@@ -400,12 +423,12 @@ def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd
     x = x.stored if isinstance(x, _WithFull) else x
     xm = mod_a(x_full)
     _rec(trace, p + "xm", _at(rnd, "x:qkv")(xm))
-    x_full = mp_sum(x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace), RESIDUAL_T)
+    x_full = residual_sum(cfg, x, g_a.unsqueeze(1) * attention(xm, sd, p + "attn.", cfg, train, rnd, trace))
     x = _at(rnd, "res")(x_full)
     _rec(trace, p + "xmid", x)
     xm2 = mod_m(x_full)
     _rec(trace, p + "xm2", _at(rnd, "x:fc1")(xm2))
-    x_full = mp_sum(x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace), RESIDUAL_T)
+    x_full = residual_sum(cfg, x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace, act=act_fn(cfg)))
     x = _at(rnd, "res")(x_full)
     _rec(trace, p + "xout", x)
     return _WithFull(x, x_full) if x is not x_full else x
@@ -422,7 +445,7 @@ def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_iden
     (modulation, linear, mean_scale, sigma_scale) — it matters only for forced-WN side effects,
     which are per-weight and order independent."""
     p = "final_layer."
-    shift, scale = mp_linear(mp_silu(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
+    shift, scale = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
     x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
     _rec(trace, p + "xmod", _at(rnd, "x:flin")(x_mod))
     out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd)
@@ -451,14 +474,17 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: 
     dt = sd["x_embedder.weight"].dtype
     h = patchify(x.to(dt), cfg.patch_size)
     h = torch.cat([h, torch.ones_like(h[:, :, :1])], dim=-1)
-    h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)          # fp32 kernel in the engine
+    if cfg.mp_pos_enc:
+        h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)      # fp32 kernel in the engine
+    else:                                                        # README.md:65 off form (unpinned): upstream DiT's plain addition
+        h = mp_linear(h, sd, "x_embedder.weight", train) + sd["pos_embed"]
 
     four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
     four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
     _rec(trace, "x0", h); _rec(trace, "four", _at(rnd, "x:t0")(four))
     temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd)
-    temb = mp_linear(mp_silu(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
-    yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train)
+    temb = mp_linear(act_fn(cfg)(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
+    yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train, mp=cfg.mp_embedding)
     c = mp_sum(temb, yemb, EMBED_T)
     _rec(trace, "temb", temb); _rec(trace, "c", c)
 

@@ -966,9 +966,13 @@ def test_patch_embed(L, p_, S):
     out = torch.zeros(N * T, D, device=DEV)
     patches = torch.full((N * T, ldp), 7.0, device=DEV, dtype=MODE["dt"])
     xd, wd, pd = x.to(DEV), w.to(DEV), pos.to(DEV)
-    L.lib().patch_embed_fwd(p(xd), p(wd), p(pd), p(out), p(patches), ldp, N, C_, S, p_, D, st())
+    L.lib().patch_embed_fwd(p(xd), p(wd), p(pd), p(out), p(patches), ldp, N, C_, S, p_, D, 0.0, st())
     torch.cuda.synchronize()
     assert rel_err(out.cpu().numpy().reshape(N, T, D), ref.numpy()) < 1e-6
+    out1 = torch.zeros_like(out)                   # out_scale 1: the plain sum (off form of --use-mp-pos-enc)
+    L.lib().patch_embed_fwd(p(xd), p(wd), p(pd), p(out1), None, ldp, N, C_, S, p_, D, 1.0, st())
+    torch.cuda.synchronize()
+    assert rel_err(out1.cpu().numpy().reshape(N, T, D), (h @ w.t() + pos.unsqueeze(0)).numpy()) < 1e-6
     assert rel_err(patches[:, :P + 1].float().cpu().numpy().reshape(N, T, P + 1), h.numpy()) < 3e-3
     assert float(patches[:, P + 1:].float().abs().max()) == 0.0
 

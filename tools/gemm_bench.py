@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="", help="comma-separated substrings: only the cases whose name contains one of them")
+    ap.add_argument("--four-phase", action="store_true", help="also the four-phase K loop (one output quadrant per phase)")
     args = ap.parse_args()
     D, M = args.hidden, args.tokens
     dev = "cuda"
@@ -86,6 +87,8 @@ def main():
         ("proj dW  TN split", 2, D, D, M, dy, D, x, D, None),
     ]
     variants = [("128", 128, 4), ("256/r3", 256, 7), ("256/w", 256, 2)]
+    if args.four_phase:
+        variants.append(("256/4ph", 256, 4))
     if args.cases:
         cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     print(f"{'case':20s} {'kernel':>8s} {'ms':>8s} {'TFLOP/s':>9s}")

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=65536)
     ap.add_argument("--cold", action="store_true", help="write 1 GiB elsewhere before every launch: the cache state a launch meets inside the "
                                                         "training step (its operands were produced long ago, L2 / Infinity Cache hold other data)")
+    ap.add_argument("--force-w", action="store_true", help="phases = 6: the stamped (wave-private epilogue) kernel for EVERY epilogue - RESID and the "
+                                                          "fp32 split-K store (weight gradients, TN) included: their K loops are the shipped kernels' K loop")
     args = ap.parse_args()
     lib = C.CDLL(os.path.join(HERE, "_stamps", "libgemm_stamps.so"))
     lib.mapdit_gemm_bf16.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(L.Epilogue), C.c_void_p]
@@ -60,11 +62,22 @@ def main():
         ("fc1 dX NN store", 1, M, D, 4 * D, dh, 4 * D, w_fc1, D, ep(L.EPI_STORE_BF16, out=o0.data_ptr(), ldo=D, alpha=1.0)),
         ("fc1 dW TN split16", 2, 4 * D, D, M, dh, 4 * D, x, D,
          ep(L.EPI_STORE_F32, out=out_f32.data_ptr(), ldo=D, alpha=1.0, split_k=16, slab_stride=4 * D * D)),
+        # the engine's own launches of the weight gradients (pick_split_k: one round of the chip) and plain long-K launches of the other
+        # two layouts beside them (round 5)
+        ("fc1 dW TN split7", 2, 4 * D, D, M, dh, 4 * D, x, D,
+         ep(L.EPI_STORE_F32, out=out_f32.data_ptr(), ldo=D, alpha=1.0, split_k=7, slab_stride=4 * D * D)),
+        ("fc2 dW TN split7", 2, D, 4 * D, M, dy, D, h, 4 * D,
+         ep(L.EPI_STORE_F32, out=out_f32.data_ptr(), ldo=4 * D, alpha=1.0, split_k=7, slab_stride=4 * D * D)),
+        ("qkv dW TN split9", 2, 3 * D, D, M, h, 4 * D, x, D,
+         ep(L.EPI_STORE_F32, out=out_f32.data_ptr(), ldo=D, alpha=1.0, split_k=9, slab_stride=3 * D * D)),
+        ("fc2 NT store K3072", 0, M, D, 4 * D, h, 4 * D, w_fc2, 4 * D, ep(L.EPI_STORE_BF16, out=o0.data_ptr(), ldo=D, alpha=1.0)),
+        ("fc1 dX NN store K3072", 1, M, D, 4 * D, dh, 4 * D, w_fc1, D, ep(L.EPI_STORE_BF16, out=o0.data_ptr(), ldo=D, alpha=1.0)),
+        ("fc1 NT store K768", 0, M, 4 * D, D, x, D, w_fc1, D, ep(L.EPI_STORE_BF16, out=o0.data_ptr(), ldo=4 * D, alpha=1.0)),
     ]
     if args.cases:
         cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     st = torch.cuda.current_stream().cuda_stream
-    lib.mapdit_gemm_tuning(256, 2, 0)
+    lib.mapdit_gemm_tuning(256, 6 if args.force_w else 2, 0)
     print(f"{'case':20s} {'us':>7s} {'TF/s':>6s} | per tile, wave 0: {'wait':>6s} {'kloop':>6s} {'issue':>6s} {'epi':>6s} {'total':>6s} | wave 4: "
           f"{'wait':>6s} {'kloop':>6s} {'issue':>6s} {'epi':>6s}   tiles/wg")
     for name, layout, m, n, k, a, lda, b, ldb, e in cases:
@@ -99,7 +112,8 @@ def main():
         w0 = (r[:, 0:4].sum(0) / r[:, 4].sum()).tolist()
         w4 = (r[:, 8:12].sum(0) / r[:, 12].sum()).tolist()
         print(f"{name:20s} {ms * 1e3:7.1f} {2.0 * m * n * k / ms / 1e9:6.0f} |                   {w0[0]:6.0f} {w0[1]:6.0f} {w0[2]:6.0f} {w0[3]:6.0f} {sum(w0):6.0f} |         "
-              f"{w4[0]:6.0f} {w4[1]:6.0f} {w4[2]:6.0f} {w4[3]:6.0f}   {tiles:.1f}")
+              f"{w4[0]:6.0f} {w4[1]:6.0f} {w4[2]:6.0f} {w4[3]:6.0f}   {tiles:.1f}"
+              f"   K-tiles/tile {k / 64 / max(e.split_k, 1):.1f}: {w0[1] / (k / 64 / max(e.split_k, 1)):.0f} cycles per K-tile (2,048 of MFMA issue)")
 
 
 if __name__ == "__main__":

@@ -52,10 +52,14 @@ def main():
     slabs = torch.empty(8, 4 * D * D, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     names = ["A:issue", "A:dma-wait", "A:barrier", "A:mfma", "A:barrier2", "B:issue", "B:dma-wait", "B:barrier", "B:mfma", "B:barrier2"]
-    for label in ("NN fc1 dX (K=3072)", "TN fc1 dW (K=65536, split 7)"):
+    h2, w2 = rnd(M, 4 * D), rnd(D, 4 * D)
+    for label in ("NT fc2 fwd (K=3072)", "NN fc1 dX (K=3072)", "TN fc1 dW (K=65536, split 7)"):
         e = L.Epilogue()
         for _ in range(3):
-            if label.startswith("NN"):
+            if label.startswith("NT"):
+                e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, out.data_ptr(), D, 1.0
+                rc = lib.mapdit_gemm_bf16(0, M, D, 4 * D, h2.data_ptr(), 4 * D, w2.data_ptr(), 4 * D, C.byref(e), st)
+            elif label.startswith("NN"):
                 e.kind, e.out, e.ldo, e.alpha = L.EPI_STORE_BF16, out.data_ptr(), D, 1.0
                 rc = lib.mapdit_gemm_bf16(1, M, D, 4 * D, dh.data_ptr(), 4 * D, w4.data_ptr(), D, C.byref(e), st)
             else:
@@ -70,6 +74,8 @@ def main():
             print(f"   {nm:12s} {d[0].median().item():7.0f} | {d[1].median().item():7.0f}")
         per = (s[:, 3:, 0] - s[:, 2:-1, 0]).float()
         print(f"   K-tile total {per[0].median().item():7.0f} | {per[1].median().item():7.0f}   (MFMA issue alone: 2 x 512)")
+    if "--kloop-only" in sys.argv:
+        return
     # whole-tile timeline of the forward shape (NT [65536,768] x [3072,768]^T, 12 K-tiles per output tile, 12 rounds of tiles):
     # where the time of one tile goes outside the K loop, for a first-round workgroup and for later ones
     setb = lib.mapdit_debug_set_stamps_block
