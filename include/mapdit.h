@@ -222,6 +222,10 @@ typedef struct {
      * the bf16 and fp16 engines run it that way (fp16: the gradients carry the loss scale) - every activation gradient is rounded to the
      * operand format as a GEMM operand anyway; measured gradient error against the reference +1 %. */
     const uint16_t* dxo_bf;
+    /* optional (abi 5; 0 = D): row stride of the [tokens, D] tensors (dxo / dxo_bf, dxm, x, y_up, dx, dx_bf, dy_up).  With every
+     * column-indexed pointer advanced by c0 this runs the pass on columns [c0, c0 + D) of wider tensors: DiT-XL (1152 = 4 x 256 + 128)
+     * takes the fused GEMM epilogue on its first 1024 columns and this pass on the last 128. */
+    int ldx;
 } mapdit_resid_mod_bwd_t;
 int mapdit_resid_mod_bwd(const mapdit_resid_mod_bwd_t* args, void* stream);
 

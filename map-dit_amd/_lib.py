@@ -32,7 +32,7 @@ class ResidModBwd(C.Structure):
                 ("g_up", vp), ("dx", vp), ("dx_bf", vp), ("dshift", vp), ("dscale", vp), ("dgain_part", vp),
                 ("dy_up", vp), ("dg_up", vp), ("ldmod", ci), ("ldg_up", ci), ("ldd", ci), ("ldd_up", ci),
                 ("n_samples", ci), ("T", ci), ("D", ci), ("ca", cf), ("cb", cf), ("part_scratch", vp), ("part_scratch_bytes", C.c_size_t),
-                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("rot", ci), ("dgain_scale", cf), ("dxo_bf", vp)]
+                ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("rot", ci), ("dgain_scale", cf), ("dxo_bf", vp), ("ldx", ci)]
 
 
 class WnJob(C.Structure):          # mapdit_wn_job_t

@@ -543,6 +543,39 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
                                 e->gain_part, e->ginv, a.n_samples, D, st));
         return mapdit_reduce_partials(e->gain_part, a.n_samples * cdiv(D / 2, 256), dgain, 0, st);
     }
+    // Round 5: a width that is an odd multiple of 128 on few enough rows that the 256^2 tiles of its first D - 128 columns fill the
+    // chip about once (DiT-XL/2 at 64 samples: 1152 = 4 x 256 + 128, 64 x 4 = 256 tiles) was refused by the rule above (320 tiles with
+    // the half-empty fifth column -> the 128^2 kernel, which has no reduce epilogue): plain stores + the separate pass over all 1152
+    // columns.  Now the fused epilogue takes the first D - 128 columns and the last 128 go through the 128^2 kernel's plain store and
+    // the pass restricted to that column range (mapdit_resid_mod_bwd_t.ldx); the scalar-gain partials of both parts are summed in
+    // order.  MAPDIT_RMB_NSPLIT=0 switches it off (A/B).
+    static const bool nsplit_env = [] { const char* v = getenv("MAPDIT_RMB_NSPLIT"); return !(v && v[0] == '0'); }();
+    if (nsplit_env && !no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && (M <= 32768 || any_m) && D % 256 == 128 && D >= 384 &&
+        mapdit_gemm_tile_size_k(M, D, K, 0) != 256 && mapdit_gemm_tile_size_k(M, D - 128, K, 0) == 256) {
+        const int D1 = D - 128;
+        mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
+        ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;
+        a.dxm = nullptr;
+        TRY(gemm16(e, MAPDIT_NN, M, D1, K, dy, ld_dy, wimg, D, ep, st));
+        const int npart1 = cdiv(M, 256) * (D1 / 256);
+        TRY(gemm16(e, MAPDIT_NN, M, 128, K, dy, ld_dy, wimg + D1, D, epi_bf16(e->dxm + D1, D), st));
+        mapdit_resid_mod_bwd_t b = a;                    // the same pass on columns [D1, D)
+        b.ldx = D; b.D = 128;
+        b.dxm = e->dxm + D1;
+        if (b.dxo) b.dxo += D1;
+        if (b.dxo_bf) b.dxo_bf += D1;
+        b.x += D1; b.shift += D1; b.scale += D1;
+        if (b.y_up) { b.y_up += D1; b.g_up += D1; b.dy_up += D1; b.dg_up += D1; }
+        if (b.dx) b.dx += D1;
+        if (b.dx_bf) b.dx_bf += D1;
+        b.dshift += D1; b.dscale += D1;
+        b.dgain_part = a.dgain_part + npart1;
+        b.part_scratch_bytes = (size_t)8 * e->cfg.max_batch * 3 * 128 * sizeof(float);
+        int npart2 = 0;
+        b.gain_partials_out = &npart2;
+        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&b, st));
+        return mapdit_reduce_partials(e->gain_part, npart1 + npart2, dgain, 0, st);
+    }
     if (!no_fuse && e->T % 64 == 0 && 256 % e->T == 0 && K % 64 == 0 && (M <= 32768 || any_m) && mapdit_gemm_tile_size_k(M, D, K, 0) == 256) {
         mapdit_epilogue_t ep; memset(&ep, 0, sizeof(ep));
         ep.kind = MAPDIT_EPI_RMB; ep.ldo = D; ep.rmb = &a;

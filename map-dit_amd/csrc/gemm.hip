@@ -2537,8 +2537,9 @@ extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, i
             MD_CHECK(!a->rot, "gemm: the RMB epilogue computes the AdaLN form only (rot != 0: use mapdit_resid_mod_bwd after a plain dX GEMM)");
             // a sample's rows must lie inside ONE 256-row tile: the per-sample column sums are stored once per tile (T = 192, 512, ...
             // would have two tiles overwrite each other's partial sums)
-            MD_CHECK(a->T > 0 && a->T % 64 == 0 && 256 % a->T == 0 && M % a->T == 0 && N == a->D,
-                     "gemm: RMB needs T in {64, 128, 256}, M = samples * T, N = D (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
+            // (N < D, a multiple of 256: the first N columns of a D-wide problem - the tensors' row stride is ldo; round 5, DiT-XL)
+            MD_CHECK(a->T > 0 && a->T % 64 == 0 && 256 % a->T == 0 && M % a->T == 0 && (N == a->D || (N < a->D && N % 256 == 0 && e->ldo >= a->D)),
+                     "gemm: RMB needs T in {64, 128, 256}, M = samples * T, N = D or a multiple of 256 below it (T=%d M=%d N=%d D=%d)", a->T, M, N, a->D);
             MD_CHECK(a->ldmod % 4 == 0 && a->ldg_up % 4 == 0 && e->ldo % 8 == 0, "gemm: RMB row strides must be multiples of 4 / 8");
             MD_CHECK(!(a->dxo && a->dxo_bf), "gemm: RMB: dxo and dxo_bf are alternatives");
             if (a->dxo_bf && a->dx_bf && a->y_up && !a->dx)         // the block-to-block case: every stream present, as compile-time facts

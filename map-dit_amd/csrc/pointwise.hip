@@ -56,6 +56,7 @@ struct RmbP {
     // partial in dgain_part[(z * samples + n) * D/128 + column block]; rmb_finish_kernel adds the z slices in order
     float* part;
     const bf16_t* dxo16;              // the downstream gradient as a 16-bit tensor (instead of dxo)
+    int ldx;                          // row stride of the [tokens, D] tensors (>= D: a column range of wider tensors)
 };
 
 // ROT: the rotation form (compile-time: the AdaLN form's loop carries no trace of it).  CL: column lanes of 4 columns each; a
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void resid_mod_bwd_kernel(RmbP p) {
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, guv[4] = {gu.x, gu.y, gu.z, gu.w};
     const int rows_z = p.T / gridDim.z, t_beg = blockIdx.z * rows_z;
     for (int t = t_beg + rg; t < t_beg + rows_z; t += RG) {
-        const size_t off = ((size_t)n * p.T + t) * p.D + d;
+        const size_t off = ((size_t)n * p.T + t) * p.ldx + d;
         float dx[4] = {0, 0, 0, 0};
         if (p.dxo) {
             float4 v = *(const float4*)(p.dxo + off);
@@ -441,6 +442,8 @@ extern "C" int MD_SYM(resid_mod_bwd)(const mapdit_resid_mod_bwd_t* a, void* stre
     p.gscale = a->dgain_scale != 0.f ? a->dgain_scale : 1.f;
     p.rot = a->rot;
     p.dxo16 = (const bf16_t*)a->dxo_bf;
+    p.ldx = a->ldx > 0 ? a->ldx : a->D;
+    MD_CHECK(p.ldx >= a->D && p.ldx % 4 == 0, "resid_mod_bwd: ldx=%d must be >= D=%d and a multiple of 4", p.ldx, a->D);
     // Small batches: one block per (sample, 128 columns) is too few blocks to stream at the HBM rate (32 samples x 6 = 192 blocks:
     // 60 us for 25 us of traffic).  With scratch given, the rows of a sample are cut into Z pieces (grid z), the column sums
     // parked per piece and added in order by a second small kernel; the gain partials simply become Z times as many.

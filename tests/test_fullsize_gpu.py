@@ -209,6 +209,52 @@ def test_full_size_step_is_reproducible_and_gradients_add_over_batch_halves(b2):
     print(f"gradient additivity over batch halves: worst relative difference {worst:.2e}")
 
 
+def test_xl_width_column_split_backward_adds_over_batch_halves():
+    """DiT-XL's width (1152 = 4 x 256 + 128) at 64 samples takes the round-5 column split of the fused dX + residual / modulate backward
+    (fused epilogue on the first 1024 columns, plain store + restricted pass on the last 128); its halves of 32 samples take the
+    whole-width fused epilogue with a ragged fifth column tile.  Per-sample losses are the same bits either way, and the 64-sample
+    gradient is the sum of the two halves' gradients up to fp32 summation order - i.e. the split changes no per-element value."""
+    from mapdit_amd.diffusion import create_diffusion
+    from mapdit_amd.src.dit import DiT
+    torch.manual_seed(0)
+    m = DiT(depth=2, hidden_size=1152, patch_size=2, input_size=32, in_channels=4, num_heads=16, num_classes=10).to(DEV).eval()
+    m.gemm_precision = "bf16"
+    with torch.no_grad():
+        for k, p_ in m.named_parameters():
+            if "gain_" in k:
+                p_.fill_(0.2)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x, noise = torch.randn(64, 4, 32, 32, device=DEV, generator=g), torch.randn(64, 4, 32, 32, device=DEV, generator=g)
+    y, t = torch.randint(0, 10, (64,), device=DEV, generator=g), torch.randint(0, 1000, (64,), device=DEV, generator=g)
+    diff = create_diffusion("")
+
+    def grads(sl):
+        for p_ in m.parameters():
+            p_.grad = None
+        loss = diff.training_losses(m, x[sl].contiguous(), t[sl].contiguous(), dict(y=y[sl].contiguous()), noise=noise[sl].contiguous())["loss"]
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), m._gflat.clone()
+
+    l1, g1 = grads(slice(0, 64))
+    l2, g2 = grads(slice(0, 64))
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    la, ga = grads(slice(0, 32))
+    lb, gb = grads(slice(32, 64))
+    assert torch.equal(torch.cat([la, lb]), l1)
+    worst = 0.0
+    for (k, p_), o in zip(m.named_parameters(), m._poffs):
+        n = p_.numel()
+        whole, parts = g1[o:o + n].double(), (ga[o:o + n].double() + gb[o:o + n].double())
+        if float(whole.norm()) < 1e-9 or n == 1:
+            continue
+        e = float((whole - parts).norm() / whole.norm())
+        worst = max(worst, e)
+        cond_path = k.startswith(("t_embedder.", "y_embedder.")) or ".modulation." in k       # (see the DiT-B/2 test above)
+        assert e < (1e-3 if cond_path else 2e-4), (k, e)
+    print(f"XL width, 64 = 32 + 32 samples: worst relative difference {worst:.2e}")
+
+
 def test_fused_adam_ema_over_all_parameters(b2):
     """Two fused optimiser steps over the flat 130 M-parameter buffer against the same arithmetic in torch (Adam with bias
     correction, lr 1e-2, betas (0.9, 0.99), eps 1e-8; power-function EMA ema.lerp_(w, (1 - 1/t)^(gamma+1)) for sigma_rel 0.05

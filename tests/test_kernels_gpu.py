@@ -112,6 +112,81 @@ def test_gemm_layouts(L, layout, shape):
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3
 
 
+def test_rmb_column_split_equals_the_whole_width_pass(L):
+    """Round 5 (DiT-XL: hidden 1152 = 4 x 256 + 128): the dX GEMM + residual / modulate backward of a width that is an odd multiple
+    of 128 runs as THREE launches - the fused EPI_RMB epilogue on the first D - 128 columns (N < D with the tensors' row stride in ldo),
+    a plain 16-bit store of the last 128 columns, and mapdit_resid_mod_bwd restricted to that column range (ldx = D, every column-indexed
+    pointer advanced) - and must give what the whole-width unfused pass gives: per-element outputs bit for bit, column sums to
+    summation order, the scalar gain gradient from both parts' partials."""
+    N, T, D, K = 4, 256, 384, 128
+    D1 = D - 128
+    M = N * T
+    g = torch.Generator().manual_seed(91)
+    xp = torch.randn(M, D, generator=g).to(DEV)
+    y_up = to_bf(bf16_exact(M, D, seed=12))
+    mod, mod_up = torch.randn(N, 6 * D, generator=g).to(DEV), torch.randn(N, 6 * D, generator=g).to(DEV)
+    gain = torch.tensor(0.37, device=DEV)
+    dxo16 = torch.randn(M, D, generator=g).to(DEV).to(MODE["dt"])
+    ad, bd = to_bf(bf16_exact(M, K, seed=13)), to_bf(bf16_exact(K, D, seed=14) * 0.25)          # NN: dX = dy W
+    ca, cb = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58)
+
+    def args(dxm, dx_bf, dy, dmod, dmod_up, part, c0=0, width=D, ldx=0):
+        a = L.ResidModBwd()
+        el = lambda t, n: t.data_ptr() + n * t.element_size()
+        a.dxo_bf, a.dxm, a.x = el(dxo16, c0), (el(dxm, c0) if dxm is not None else None), el(xp, c0)
+        a.shift, a.scale, a.gain, a.ldmod = el(mod, 3 * D + c0), el(mod, 4 * D + c0), p(gain), 6 * D
+        a.y_up, a.g_up, a.ldg_up = el(y_up, c0), el(mod_up, 5 * D + c0), 6 * D
+        a.dy_up, a.dg_up, a.ldd_up = el(dy, c0), el(dmod_up, 5 * D + c0), 6 * D
+        a.dx_bf = el(dx_bf, c0)
+        a.dshift, a.dscale, a.ldd = el(dmod, 3 * D + c0), el(dmod, 4 * D + c0), 6 * D
+        a.dgain_part = p(part)
+        a.n_samples, a.T, a.D, a.ca, a.cb, a.ldx = N, T, width, ca, cb, ldx
+        return a
+
+    mk = lambda: (torch.zeros(M, D, device=DEV, dtype=MODE["dt"]), torch.zeros(M, D, device=DEV, dtype=MODE["dt"]),
+                  torch.zeros(N, 6 * D, device=DEV), torch.zeros(N, 6 * D, device=DEV), torch.zeros(4096, device=DEV))
+    # whole width: plain GEMM store + the pass
+    gm = torch.zeros(M, D, device=DEV, dtype=MODE["dt"])
+    run_gemm(L, 1, ad, bd, L.EPI_STORE_BF16, M, D, K, out=p(gm), ldo=D, alpha=1.0)
+    dx_w, dy_w, dmod_w, dmu_w, part_w = mk()
+    a = args(gm, dx_w, dy_w, dmod_w, dmu_w, part_w)
+    npart = C.c_int(0)
+    a.gain_partials_out = C.pointer(npart)
+    L.lib().resid_mod_bwd(C.byref(a), st())
+    dgain_w = torch.zeros((), device=DEV)
+    L.lib().reduce_partials(p(part_w), npart.value, p(dgain_w), 0, st())
+    # split: fused epilogue on [0, D1), plain store + restricted pass on [D1, D)
+    dx_s, dy_s, dmod_s, dmu_s, part_s = mk()
+    a1 = args(None, dx_s, dy_s, dmod_s, dmu_s, part_s)
+    e = L.Epilogue()
+    e.kind, e.ldo, e.rmb = L.EPI_RMB, D, C.addressof(a1)
+    L.lib().gemm_tuning(256, 2, 0)
+    try:
+        L.lib().gemm_bf16(1, M, D1, K, p(ad), K, p(bd), D, C.byref(e), st())
+    finally:
+        L.lib().gemm_tuning(0, 2, 0)
+    n1 = (M // 256) * (D1 // 256)
+    gm2 = torch.zeros(M, D, device=DEV, dtype=MODE["dt"])
+    ep = L.Epilogue()
+    ep.kind, ep.out, ep.ldo, ep.alpha = L.EPI_STORE_BF16, gm2.data_ptr() + D1 * 2, D, 1.0
+    L.lib().gemm_bf16(1, M, 128, K, p(ad), K, bd.data_ptr() + D1 * 2, D, C.byref(ep), st())
+    part2 = torch.zeros(4096, device=DEV)
+    a2 = args(gm2, dx_s, dy_s, dmod_s, dmu_s, part2, c0=D1, width=128, ldx=D)
+    npart2 = C.c_int(0)
+    a2.gain_partials_out = C.pointer(npart2)
+    L.lib().resid_mod_bwd(C.byref(a2), st())
+    torch.cuda.synchronize()
+    part_s[n1:n1 + npart2.value] = part2[:npart2.value]
+    dgain_s = torch.zeros((), device=DEV)
+    L.lib().reduce_partials(p(part_s), n1 + npart2.value, p(dgain_s), 0, st())
+    torch.cuda.synchronize()
+    assert torch.equal(gm2[:, D1:], gm[:, D1:])
+    assert torch.equal(dx_s, dx_w) and torch.equal(dy_s, dy_w), "per-element outputs must not depend on the split"
+    assert float(dx_w.float().abs().sum()) > 0 and float(dy_w[:, D1:].float().abs().sum()) > 0
+    assert rel_err(dmod_s.cpu().numpy(), dmod_w.cpu().numpy()) < 1e-6 and rel_err(dmu_s.cpu().numpy(), dmu_w.cpu().numpy()) < 1e-6
+    assert abs(dgain_s.item() - dgain_w.item()) < 1e-5 * abs(dgain_w.item()) + 1e-4
+
+
 def test_gemm_column_split_shape_on_the_scalar_fallback(L):
     """a result whose width is an odd multiple of 128 on ~one round of 256^2 tiles is run as two launches (256^2 kernel on
     N - 128 columns + 128^2 kernel on the last 128).  A TN operand with M % 8 != 0 (padded leading dimension, so every alignment test
