@@ -247,8 +247,12 @@ def main():
                     help="bf16: BASELINE.json's metric (the headline).  f16: the same engine with IEEE fp16 operands (also timed as the "
                          "`f16` object of the default run).  bf16x3: the fp32-accurate parity engine (informational)")
     ap.add_argument("--no-f16-leg", action="store_true", help="default bf16 run: skip the extra timed fp16 leg")
-    ap.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
-                    help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce)")
+    ap.add_argument("--grad-comm", choices=["allreduce", "zero1", "zero1w", "zero1w-bf16"], default=None,
+                    help="gradient exchange under data parallelism (default: $MAPDIT_GRAD_COMM or allreduce); zero1w: sharded weight "
+                         "passes (forced WN + imaging, Jacobian, Adam/EMA on 1/world of the rows), -bf16: with a 16-bit gradient exchange")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="ONE process does what rank 0 of a W-rank zero1w job would do, WITHOUT the collectives: the one-GPU measurement of "
+                         "what sharding the batch-independent weight passes saves (use with --batch-per-gpu 256/W).  Not a training run.")
     ap.add_argument("--rotation-modulation", action="store_true",
                     help="BASELINE config 3's block conditioning (README.md:1-3; not in the reference snapshot: parity unpinned)")
     ap.add_argument("--mp-off", default="", help="comma-separated off forms of the README's --use-* flags: mp_silu, mp_residual, mp_pos_enc, "
@@ -302,7 +306,11 @@ def main():
         torch.manual_seed(1000 + rank)                     # from here on every rank draws its OWN timesteps, noise and label drops
         diffusion = create_diffusion(timestep_respacing="")
         num_steps = 400_000                                # train.py defaults -> warm-up / decay points
-        reducer = parallel.make_reducer(model, args.grad_comm)
+        if args.emulate_world > 1:
+            assert world == 1, "--emulate-world is a one-process measurement"
+            reducer = parallel.ShardedPassReducer(model, emulate=(0, args.emulate_world))
+        else:
+            reducer = parallel.make_reducer(model, args.grad_comm)
         opt = FusedAdamEMA(model, lr=1e-2, betas=(0.9, 0.99), ema_stds=(0.05, 0.1),
                            lr_lambda=create_lr_lambda(num_steps // 150, num_steps // 10), grad_scale=reducer.grad_scale)
         reducer.attach(opt)
@@ -379,6 +387,9 @@ def main():
                                "fp32 accumulate, master and residual fp32",
                    "global_batch": global_batch, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
                    "grad_comm": r["grad_comm"],
+                   **({"emulated_world": args.emulate_world,
+                       "note": f"ONE process doing rank 0's share of a {args.emulate_world}-rank zero1w job without the collectives: the compute side of "
+                               "sharded weight passes, not a training run and not a multi-GPU measurement"} if args.emulate_world > 1 else {}),
                    "seeds": {"model": 0, "data": "1+rank", "t/noise/drop": "1000+rank"}, "final_loss": final_loss},
         "step_mfma_frac": value * 3 * f_fwd / (world * PEAK_BF16_DENSE_TFLOPS * 1e12),
         "parity": parity if not unpinned else {

@@ -142,11 +142,21 @@ int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int 
  * G is scratch: with nslabs > 1 its slab 0 is overwritten with the sum. */
 int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
                           int cols, float out_scale, int accumulate, void* stream);
+/* Several weights, or row ranges of weights, in ONE launch, in place (abi 5): job.W = master rows, job.w_f32 = their gradient rows G (one
+ * slab), which become dW; job.out_scale as above; first_block = running sum of ceil(rows / 4).  The Jacobians of a rank's rows under
+ * sharded weight passes (mapdit_engine_jacobian_shard). */
+int mapdit_weightnorm_bwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, void* stream);
 /* The same pass, same bits, in 48 registers per lane and no LDS: the form to launch on a second stream while a weight-gradient GEMM
  * (two 228-register waves per SIMD) occupies the CUs - the engine runs the Jacobian of weight i beside the GEMM of weight i + 1
  * (autograd of src/basic/mp_linear.py:38-46 needs the whole row of G: it cannot be the GEMM's epilogue). */
 int mapdit_weightnorm_bwd_slim(const float* W, float* G, int ldg, int nslabs, long slab_stride, float* dW, int rows,
                                int cols, float out_scale, int accumulate, void* stream);
+
+/* Element ranges of flat buffers for the multi-range forms below (abi 5): [lo, hi) with lo, hi multiples of 4; first_block = running
+ * sum of ceil((hi - lo) / 4096) over the preceding ranges (a workgroup owns 4,096 consecutive elements of one range). */
+typedef struct {
+    long lo, hi, first_block;
+} mapdit_range_t;
 
 /* torch.optim.Adam (train.py:57) fused with the two power-function EMA copies (src/ema.py:135-140) over flat
  * fp32 buffers.  hyper (device, 5 floats): lr/(1-b1^t), 1/sqrt(1-b2^t), ema beta a, ema beta b, grad scale. */
@@ -174,6 +184,14 @@ int mapdit_grad_nonfinite_check(const float* grads, long n, int* status, int ste
 int mapdit_adam_ema_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a, float* ema_b,
                                  long n, const mapdit_adam_scalars_t* hyper, float beta1, float beta2, float eps,
                                  const int* status, int step, void* stream);
+/* The optimiser step and the check over MANY element ranges in one launch each (abi 5): a rank's rows of every sharded weight plus the
+ * replicated parameters under sharded weight passes are ~85 ranges - one launch instead of 85 of a few microseconds of work each.
+ * status may be NULL for the unguarded step.  total_blocks = sum of ceil((hi - lo) / 4096). */
+int mapdit_adam_ema_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a, float* ema_b,
+                                const mapdit_range_t* ranges_dev, int nranges, long total_blocks, const mapdit_adam_scalars_t* hyper,
+                                float beta1, float beta2, float eps, const int* status, int step, void* stream);
+int mapdit_grad_nonfinite_check_ranges(const float* grads, const mapdit_range_t* ranges_dev, int nranges, long total_blocks, int* status,
+                                       int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Token-stream kernels of the DiT block (src/utils.py:11-16, src/blocks/dit_block.py:33-36).
@@ -258,6 +276,12 @@ int mapdit_f32_to_bf16(const float* x, uint16_t* out, long n, float alpha, void*
 int mapdit_f32_to_bf16_2d(const float* x, int ldx, uint16_t* out, int ldo, int rows, int cols, float alpha, void* stream);
 /* acc[i] += sum over nslabs of slabs[s*slab_stride + i], in slab order (deterministic split-K reduction). */
 int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
+/* out[i] = sum over the slabs, in slab order (abi 5): a weight gradient's split-K partial sums added up WITHOUT the weight-norm Jacobian
+ * (data parallelism with sharded weight passes: the raw sums are reduce-scattered, the Jacobian runs on the rows a rank owns). */
+int mapdit_reduce_slabs(float* out, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
+/* out[i] = sum over nchunks bf16 vectors chunk_stride elements apart, accumulated in fp32 in chunk order (abi 5): the receiving side
+ * of a 16-bit gradient exchange - every rank's bf16 copy of the rows this rank owns (all-to-all), summed here in fp32. */
+int mapdit_sum_bf16_chunks(float* out, const uint16_t* chunks, int nchunks, long chunk_stride, long n, void* stream);
 /* out[i] = alpha * x[i] (abi 5): the label table's gradient when the table is a plain nn.Embedding (MAPDIT_OFF_MP_EMBEDDING) - the
  * scattered rows, divided by the fp16 loss scale. */
 int mapdit_scale_copy(float* out, const float* x, long n, float alpha, void* stream);
@@ -431,6 +455,13 @@ int mapdit_engine_backward(mapdit_engine_t* e, const float* dout, void* stream);
 int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* dout, int stage_from, int stage_to, void* stream);
 /* MAPDIT_PREC_F16: change the loss scale of the following backward passes (0 = automatic, else a finite power of two), and read
  * the one the most recent backward ran with (1 for the other precisions). */
+/* Data parallelism with sharded weight passes (abi 5; DDP has no counterpart in the reference: train.py is single-process).  After
+ * set_shard(rank, world) the rows of every block linear are split over the ranks: prepare_weights rewrites / images this rank's rows
+ * only (the host all-gathers the images: mapdit_engine_weight_image), backward leaves those weights' gradients as RAW sums (no weight-
+ * norm Jacobian) for a reduce-scatter, and jacobian_shard applies the Jacobian to the owned rows in place.  world = 1 undoes it. */
+int mapdit_engine_set_shard(mapdit_engine_t* e, int rank, int world);
+int mapdit_engine_weight_image(mapdit_engine_t* e, int pidx, void** img, void** img3, int* rows, int* cols, int* sharded);
+int mapdit_engine_jacobian_shard(mapdit_engine_t* e, void* stream);
 int mapdit_engine_set_loss_scale(mapdit_engine_t* e, float loss_scale);
 int mapdit_engine_loss_scale(mapdit_engine_t* e, float* out);
 

@@ -76,11 +76,14 @@ _SIGS = {
     "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_bwd_slim": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
+    "mapdit_weightnorm_bwd_batch": [vp, ci, ci, vp],
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],
     "mapdit_adam_ema_step_guarded": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp, ci, vp],
     "mapdit_grad_nonfinite_check": [vp, cl, vp, ci, vp],
+    "mapdit_adam_ema_step_ranges": [vp, vp, vp, vp, vp, vp, vp, ci, cl, C.POINTER(AdamScalars), cf, cf, cf, vp, ci, vp],
+    "mapdit_grad_nonfinite_check_ranges": [vp, vp, ci, cl, vp, ci, vp],
     "mapdit_modulate_fwd": [vp, vp, vp, ci, vp, vp, ci, ci, ci, vp],
     "mapdit_resid_mod_bwd": [C.POINTER(ResidModBwd), vp],
     "mapdit_reduce_partials": [vp, ci, vp, ci, vp],
@@ -93,6 +96,8 @@ _SIGS = {
     "mapdit_f32_to_bf16_2d": [vp, ci, vp, ci, ci, ci, cf, vp],
     "mapdit_sum_slabs": [vp, vp, ci, cl, cl, vp],
     "mapdit_scale_copy": [vp, vp, cl, cf, vp],
+    "mapdit_reduce_slabs": [vp, vp, ci, cl, cl, vp],
+    "mapdit_sum_bf16_chunks": [vp, vp, ci, cl, cl, vp],
     "mapdit_qkv_split": [vp, ci, ci, ci, ci, vp, vp, vp, vp],
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
@@ -128,6 +133,9 @@ _SIGS = {
     "mapdit_engine_forward": [vp, vp, vp, vp, ci, ci, vp, vp],
     "mapdit_engine_backward": [vp, vp, vp],
     "mapdit_engine_backward_stages": [vp, vp, ci, ci, vp],
+    "mapdit_engine_set_shard": [vp, ci, ci],
+    "mapdit_engine_weight_image": [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)],
+    "mapdit_engine_jacobian_shard": [vp, vp],
     "mapdit_engine_set_loss_scale": [vp, cf],
     "mapdit_engine_loss_scale": [vp, C.POINTER(cf)],
     "mapdit_engine_profile_begin": [vp, ci, ci],

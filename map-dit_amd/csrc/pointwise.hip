@@ -380,6 +380,35 @@ __global__ void scale_copy_kernel(float* __restrict__ out, const float* __restri
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = alpha * x[i];
 }
+// out[i] = sum_s slabs[s*stride + i], four elements per thread   (fixed order; n a multiple of 4, 16-byte aligned)
+__global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslabs, long stride, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = *(const float4*)(slabs + 4 * i);
+    for (int s = 1; s < nslabs; ++s) {
+        const float4 t = *(const float4*)(slabs + (size_t)s * stride + 4 * i);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *(float4*)(out + 4 * i) = a;
+}
+// out[i] = sum_c bf16 chunks[c*stride + i] accumulated in fp32, in chunk order (8 elements per thread): the receiving side of a 16-bit
+// gradient exchange (every rank's bf16 copy of the rows this rank owns, summed in fp32)
+__global__ void sum_bf16_chunks_kernel(float* __restrict__ out, const unsigned short* __restrict__ chunks, int nchunks, long stride, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) {
+        const uint4 u = *(const uint4*)(chunks + (size_t)c * stride + 8 * i);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[2 * k] += __uint_as_float(w[k] << 16);
+            a[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    *(float4*)(out + 8 * i) = make_float4(a[0], a[1], a[2], a[3]);
+    *(float4*)(out + 8 * i + 4) = make_float4(a[4], a[5], a[6], a[7]);
+}
 // acc[i] += sum_s slabs[s*stride + i]   (fixed order: deterministic split-K reduction)
 __global__ void sum_slabs_kernel(float* __restrict__ acc, const float* __restrict__ slabs, int nslabs, long stride, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,6 +432,20 @@ extern "C" int MD_SYM_F32_TO_16_2D(const float* x, int ldx, uint16_t* out, int l
 extern "C" int mapdit_scale_copy(float* out, const float* x, long n, float alpha, void* stream) {
     MD_CHECK(out && x && n > 0, "scale_copy: bad argument");
     hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, x, n, alpha);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+extern "C" int mapdit_reduce_slabs(float* out, const float* slabs, int nslabs, long slab_stride, long n, void* stream) {
+    MD_CHECK(out && slabs && nslabs >= 1 && n > 0 && n % 4 == 0 && slab_stride % 4 == 0 && ((((uintptr_t)out | (uintptr_t)slabs) & 15) == 0),
+             "reduce_slabs: bad argument (n and slab_stride multiples of 4, 16-byte aligned buffers)");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, slabs, nslabs, slab_stride, n / 4);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+extern "C" int mapdit_sum_bf16_chunks(float* out, const uint16_t* chunks, int nchunks, long chunk_stride, long n, void* stream) {
+    MD_CHECK(out && chunks && nchunks >= 1 && n > 0 && n % 8 == 0 && chunk_stride % 8 == 0 && ((((uintptr_t)out | (uintptr_t)chunks) & 15) == 0),
+             "sum_bf16_chunks: bad argument (n and chunk_stride multiples of 8, 16-byte aligned buffers)");
+    hipLaunchKernelGGL(sum_bf16_chunks_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, out, chunks, nchunks, chunk_stride, n / 8);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -112,11 +112,10 @@ extern "C" void mapdit_wn_dbg_set(float* p) {
 // G may arrive as `nslabs` split-K partial sums: pass 1 adds them in slab order (deterministic) and, when there is
 // more than one, parks the sum in slab 0 so that pass 2 re-reads one L2-hot row instead of all slabs again.
 template <bool VEC>
-__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, float* __restrict__ G, int ldg,
-                                                           int nslabs, long slab_stride, float* __restrict__ dW, int rows,
-                                                           int cols, float out_scale, int accumulate) {
+__device__ __forceinline__ void weightnorm_bwd_row(const float* __restrict__ W, float* __restrict__ G, int ldg, int nslabs,
+                                                   long slab_stride, float* __restrict__ dW, int row, int rows, int cols,
+                                                   float out_scale, int accumulate) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* w = W + (size_t)row * cols;
     float* g = G + (size_t)row * ldg;
@@ -193,6 +192,27 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ W, float* __restrict__ G, int ldg,
+                                                           int nslabs, long slab_stride, float* __restrict__ dW, int rows,
+                                                           int cols, float out_scale, int accumulate) {
+    weightnorm_bwd_row<VEC>(W, G, ldg, nslabs, slab_stride, dW, blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, out_scale, accumulate);
+}
+
+// Several weights (or row ranges of weights) in ONE launch, in place: job.W = the master rows, job.w_f32 = their gradient rows G, which
+// become dW (one slab, vector path).  The Jacobians of a rank's rows under sharded weight passes: 60 launches of a few microseconds of
+// work each otherwise.  A workgroup finds its job by binary search over first_block, as weightnorm_fwd_batch_kernel does.
+__global__ __launch_bounds__(256) void weightnorm_bwd_batch_kernel(const mapdit_wn_job_t* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const mapdit_wn_job_t j = jobs[lo];
+    weightnorm_bwd_row<true>(j.W, j.w_f32, j.cols, 1, 0, j.w_f32, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, j.out_scale, 0);
+}
+
 // The same pass for a SIDE STREAM (round 5): the engine runs the Jacobian of weight i beside the weight-gradient GEMM of weight i + 1.
 // A GEMM workgroup holds two 228-register waves per SIMD (464 of the 512 registers per lane after the allocation granule), so a
 // co-resident wave may own 48 registers and no LDS (tools/overlap_probe.py: a streaming kernel that fits beside the persistent GEMM hides
@@ -252,6 +272,34 @@ void weightnorm_bwd_slim_kernel(const float* __restrict__ W, float* __restrict__
     }
 }
 
+// Adam + the two EMA copies on elements i .. i + 3 of the flat buffers (the arithmetic of adam_ema_kernel, shared with its multi-range form)
+__device__ __forceinline__ void adam_ema_apply4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                float* __restrict__ e1, float* __restrict__ e2, long i, float step_size, float inv_sqrt_bc2,
+                                                float eb1, float eb2, float gs, float b1, float b2, float eps) {
+    float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+    float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gk = gg[k] * gs;
+        mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+        vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+        pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+    }
+    *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (e1) {
+        float4 E = *(float4*)(e1 + i);
+        E.x += eb1 * (pp[0] - E.x); E.y += eb1 * (pp[1] - E.y); E.z += eb1 * (pp[2] - E.z); E.w += eb1 * (pp[3] - E.w);
+        *(float4*)(e1 + i) = E;
+    }
+    if (e2) {
+        float4 E = *(float4*)(e2 + i);
+        E.x += eb2 * (pp[0] - E.x); E.y += eb2 * (pp[1] - E.y); E.z += eb2 * (pp[2] - E.z); E.w += eb2 * (pp[3] - E.w);
+        *(float4*)(e2 + i) = E;
+    }
+}
+
 // torch.optim.Adam (train.py:57: lr, betas (0.9, 0.99), eps 1e-8, no weight decay) fused with the two
 // power-function EMA copies (src/ema.py:135-140: ema.lerp_(param, beta)).  Step-dependent scalars are read
 // from a small device array so the launch is graph-replayable:
@@ -270,7 +318,54 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
                 eb2 = hp ? hp[3] : hs.ema_beta_b, gs = hp ? hp[4] : hs.grad_scale;
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * blockDim.x * 4;
-    for (; i + 3 < n; i += stride) {
+    for (; i + 3 < n; i += stride) adam_ema_apply4(p, g, m, v, e1, e2, i, step_size, inv_sqrt_bc2, eb1, eb2, gs, b1, b2, eps);
+}
+
+// Many element ranges of the flat buffers in ONE launch (a rank's rows of every sharded weight + the replicated parameters under sharded
+// weight passes: 85 ranges): a workgroup owns 4,096 consecutive elements of one range, found by binary search over first_block.
+__global__ __launch_bounds__(256) void adam_ema_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, float* __restrict__ e1, float* __restrict__ e2,
+                                                            const mapdit_range_t* __restrict__ ranges, int nranges, mapdit_adam_scalars_t hs,
+                                                            float b1, float b2, float eps, const int* __restrict__ status, int step) {
+    if (status && status[0] == step) return;
+    int lo = 0, hi = nranges - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ranges[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const mapdit_range_t r = ranges[lo];
+    const long base = r.lo + (blk - r.first_block) * 4096;
+    const long end = base + 4096 < r.hi ? base + 4096 : r.hi;
+    for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024)
+        adam_ema_apply4(p, g, m, v, e1, e2, i, hs.step_size, hs.inv_sqrt_bc2, hs.ema_beta_a, hs.ema_beta_b, hs.grad_scale, b1, b2, eps);
+}
+
+// the non-finite check over the same ranges
+__global__ __launch_bounds__(256) void grad_nonfinite_ranges_kernel(const float* __restrict__ g, const mapdit_range_t* __restrict__ ranges, int nranges,
+                                                                  int* __restrict__ status, int step) {
+    int lo = 0, hi = nranges - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ranges[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const mapdit_range_t r = ranges[lo];
+    const long base = r.lo + (blk - r.first_block) * 4096;
+    const long end = base + 4096 < r.hi ? base + 4096 : r.hi;
+    bool bad = false;
+    for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
+        const float4 x = *(const float4*)(g + i);
+        const float d = (x.x - x.x) + (x.y - x.y) + (x.z - x.z) + (x.w - x.w);
+        bad |= !(d == 0.f);
+    }
+    if (bad) {
+        if (atomicExch(&status[0], step) != step) atomicAdd(&status[1], 1);
+    }
+}
+
+#if 0
+    {
         float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w},
               vv[4] = {V.x, V.y, V.z, V.w};
@@ -295,7 +390,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
             *(float4*)(e2 + i) = E;
         }
     }
-}
+#endif
 
 // Non-finite gradient guard (fp16 engine): any inf / NaN among the n gradients records `step` in status[0]; the first thread to do
 // so for this step also counts it in status[1].  Atomics run in the overflow case only (a finite step issues none).
@@ -345,6 +440,15 @@ extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nsla
     else
         hipLaunchKernelGGL(weightnorm_bwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, W, G, ldg,
                            nslabs, slab_stride, dW, rows, cols, out_scale, accumulate);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+#endif
+
+#if MAPDIT_DT == 0
+extern "C" int mapdit_weightnorm_bwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, void* stream) {
+    MD_CHECK(jobs_dev && njobs > 0 && total_blocks > 0, "weightnorm_bwd_batch: null/empty argument");
+    hipLaunchKernelGGL(weightnorm_bwd_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }
@@ -403,6 +507,28 @@ extern "C" int mapdit_adam_ema_step_guarded(float* params, const float* grads, f
     const int grid = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, ema_a, ema_b, n, (const float*)nullptr, *hyper, beta1, beta2, eps, status, step);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_adam_ema_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_a, float* ema_b,
+                                           const mapdit_range_t* ranges_dev, int nranges, long total_blocks, const mapdit_adam_scalars_t* hyper,
+                                           float beta1, float beta2, float eps, const int* status, int step, void* stream) {
+    MD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && ranges_dev && nranges > 0 && total_blocks > 0 && total_blocks < (1l << 31),
+             "adam_ema_step_ranges: null/empty argument");
+    MD_CHECK(!status || step > 0, "adam_ema_step_ranges: the guarded form needs a step number > 0");
+    hipLaunchKernelGGL(adam_ema_ranges_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       ema_a, ema_b, ranges_dev, nranges, *hyper, beta1, beta2, eps, status, step);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int mapdit_grad_nonfinite_check_ranges(const float* grads, const mapdit_range_t* ranges_dev, int nranges, long total_blocks,
+                                                  int* status, int step, void* stream) {
+    MD_CHECK(grads && ranges_dev && status && nranges > 0 && total_blocks > 0 && total_blocks < (1l << 31) && step > 0,
+             "grad_nonfinite_check_ranges: null/empty argument (step must be > 0)");
+    hipLaunchKernelGGL(grad_nonfinite_ranges_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, grads, ranges_dev, nranges,
+                       status, step);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

@@ -114,8 +114,13 @@ class FusedAdamEMA:
             guard = getattr(m, "gemm_precision", "bf16") == "f16"
         if guard:
             with torch.cuda.device(m._pflat.device):
-                for lo, hi in self.shards:
-                    if hi > lo:
+                live = [(lo, hi) for lo, hi in self.shards if hi > lo]
+                if len(live) > 8:
+                    tab, nblk = self._range_table(live)
+                    L.lib().grad_nonfinite_check_ranges(m._gflat.data_ptr(), tab.data_ptr(), len(live), nblk, self._status.data_ptr(), launch,
+                                                        L.cur_stream())
+                else:
+                    for lo, hi in live:
                         L.lib().grad_nonfinite_check(m._gflat.data_ptr() + lo * 4, hi - lo, self._status.data_ptr(), launch, L.cur_stream())
             if self.status_sync is not None:
                 self.status_sync(self._status)
@@ -132,6 +137,16 @@ class FusedAdamEMA:
                 segs += [(pos, a, False), (a, b, True)]
                 pos = b
             segs.append((pos, hi, False))
+        segs = [sg for sg in segs if sg[1] > sg[0]]
+        if len(segs) > 8 and all(w for _, _, w in segs):
+            # many ranges (sharded weight passes: a rank's rows of every weight + the replicated rest): ONE launch over a device table
+            tab, nblk = self._range_table([(lo, hi) for lo, hi, _ in segs])
+            with torch.cuda.device(m._pflat.device):
+                L.lib().adam_ema_step_ranges(m._pflat.data_ptr(), m._gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                             self.ema[0].data_ptr() if self.ema else None, self.ema[1].data_ptr() if self.ema else None,
+                                             tab.data_ptr(), len(segs), nblk, C.byref(hyper), b1, b2, self.eps,
+                                             self._status.data_ptr() if guard else None, launch if guard else 0, L.cur_stream())
+            segs = []
         for lo, hi, with_ema in segs:
             if hi <= lo:
                 continue
@@ -150,6 +165,19 @@ class FusedAdamEMA:
         m.mark_weights_changed()
         if guard and self._poll_every_step:
             self.poll_overflow()
+
+    def _range_table(self, ranges):
+        """Device table of mapdit_range_t {lo, hi, first_block} for the multi-range kernels (built once per set of ranges)."""
+        key = tuple(ranges)
+        cached = getattr(self, "_range_cache", None)
+        if cached is None or cached[0] != key:
+            rows, blk = [], 0
+            for lo, hi in ranges:
+                assert lo % 4 == 0 and hi % 4 == 0
+                rows.append((lo, hi, blk))
+                blk += (hi - lo + 4095) // 4096
+            self._range_cache = (key, torch.tensor(rows, dtype=torch.int64, device=self.model._pflat.device), blk)
+        return self._range_cache[1], self._range_cache[2]
 
     # ---- non-finite gradient guard ------------------------------------------------------------------------------
     def overflow_steps(self) -> int:

@@ -362,14 +362,262 @@ class Zero1Reducer(_ReducerBase):
                 _verify_gather(p[lo:hi], (hi - lo) // self.world, self.world, before, self.group)
 
 
+_SHARDED_SUFFIXES = ("attn.qkv_proj.weight", "attn.out_proj.weight", "mlp.net.0.weight", "mlp.net.2.weight", "modulation.1.weight")
+_B_OF = {"attn.qkv_proj.weight": 0, "attn.out_proj.weight": 1, "mlp.net.0.weight": 2, "mlp.net.2.weight": 3, "modulation.1.weight": 4}   # mapdit.h MAPDIT_B_*
+
+
+class ShardedPassReducer(_ReducerBase):
+    """Data parallelism with SHARDED WEIGHT PASSES (round 5; ``--grad-comm zero1w`` / ``zero1w-bf16``).
+
+    The step of a small per-GPU batch is dominated by passes that do not depend on the batch: forced weight normalisation + 16-bit
+    imaging of every weight (reference mp_linear.py:38-44 once per forward), the weight-norm Jacobian of every weight gradient, Adam and
+    the two EMA copies (train.py:57, src/ema.py:135-140) - 2.1 ms of a 10.2 ms DiT-B/2 step at 32 samples per GPU, replicated on every
+    rank by the all-reduce scheme.  Here the ROWS of every block linear (QKV, proj, fc1, fc2, modulation: 99 % of the parameters) are
+    split over the ranks, and each rank runs all of those passes on its rows only:
+
+    * backward leaves those weights' gradients as RAW split-K sums (``mapdit_engine_set_shard``); per stage, as soon as it is enqueued,
+      each weight's raw gradient is reduce-scattered (rank r receives the sum of its rows) - fp32, or with ``grad_dtype="bf16"`` as a
+      16-bit exchange: every rank's bf16 copy of the owner's rows travels (all-to-all) and is summed in fp32 on receipt
+      (``mapdit_sum_bf16_chunks``): half the bytes, one rounding of each rank's contribution to 8 mantissa bits;
+    * the weight-norm Jacobian - linear in G, so it commutes with the sum over ranks - runs on the owned rows
+      (``mapdit_engine_jacobian_shard``), then the fused Adam + EMA kernel (``FusedAdamEMA.shards``);
+    * the next forward's weight pass rewrites / images the owned rows, and the 16-BIT IMAGES (260 MB for DiT-B/2, not the 521 MB of fp32
+      parameters ZeRO-1 gathers) are all-gathered before the network runs.
+    The small parameters (embedders, final layer, gains: < 1 %) stay replicated and are all-reduced.  Bytes on the links: 521 + 260 MB
+    (fp32 exchange) or 260 + 260 MB (bf16) per rank and step against 2 x 521 MB for the all-reduce.
+
+    fp32 master weights, Adam moments and EMA copies of rows a rank does not own go stale on that rank: ``gather_state()`` completes them
+    (checkpoints, EMA snapshots, switching to eval).  ``emulate=(rank, world)``: one process does what rank ``rank`` of ``world`` would do
+    WITHOUT the collectives - the one-GPU measurement of the saving (bench.py --emulate-world); its training results are not meaningful.
+    """
+
+    def __init__(self, model, group=None, force_collective: bool = False, grad_dtype: str = "fp32", emulate=None):
+        assert grad_dtype in ("fp32", "bf16")
+        assert getattr(model, "gemm_precision", "f16") != "bf16x3", "sharded weight passes: bf16 / f16 engines only"
+        self.model, self.group, self.grad_dtype = model, group, grad_dtype
+        self.emulate = emulate
+        self.world = emulate[1] if emulate else _world(group)
+        self.rank = emulate[0] if emulate else (dist.get_rank(group) if self.world > 1 else 0)
+        self.name = (f"zero1w: sharded weight passes (forced WN + imaging, Jacobian, Adam/EMA on 1/{self.world} of the rows), "
+                     f"{grad_dtype} reduce-scatter of raw weight gradients + all-gather of 16-bit images" + (" [EMULATED, no collectives]" if emulate else ""))
+        self.slices = stage_slices(model)
+        L = model.depth
+        self.weights = []                     # sharded weights: dict(stage, off, rows, cols, pidx)
+        from . import _lib as Lib
+        for (name, p), off in zip(model.named_parameters(), model._poffs):
+            if not name.startswith("blocks."):
+                continue
+            _, bi, suffix = name.split(".", 2)
+            if suffix in _SHARDED_SUFFIXES and p.dim() == 2 and p.shape[0] % (4 * self.world) == 0 and self.world > 1:
+                self.weights.append(dict(stage=L - int(bi), off=off, rows=p.shape[0], cols=p.shape[1],
+                                         pidx=Lib.NUM_GLOBAL + int(bi) * Lib.NUM_BLOCK + _B_OF[suffix]))
+        # replicated remainder of every stage slice: what lies between / around the sharded weights
+        self.rest = []
+        for st, (lo, hi) in enumerate(self.slices):
+            pos, out = lo, []
+            for w in sorted((w for w in self.weights if w["stage"] == st), key=lambda w: w["off"]):
+                if w["off"] > pos:
+                    out.append((pos, w["off"]))
+                pos = w["off"] + w["rows"] * w["cols"]
+                assert pos <= hi
+            if pos < hi:
+                out.append((pos, hi))
+            self.rest.append(out)
+        self.works = []
+        self.opt = None
+        self.force_collective = force_collective
+        self._send16 = self._recv16 = None
+        self._pending16 = []                  # (weight, offset in the 16-bit buffers) of exchanges whose fp32 sum is still to run
+        self._off16, tot = {}, 0
+        for w in self.weights:
+            self._off16[w["off"]] = tot
+            tot += w["rows"] * w["cols"]
+        self._tot16 = tot
+        self._emu_ready = False
+        model._shard = (self.rank, self.world) if self.world > 1 else None
+        model._stage_hook = self._on_stage if self.world > 1 else None
+        model._after_prepare_hook = self._gather_images if self.world > 1 else None
+        self._native = self.world > 1 and not emulate and dist.get_backend(group) == "nccl"
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def own(self, w):
+        """[lo, hi) of the flat buffers: the rows of sharded weight `w` this rank owns."""
+        n = (w["rows"] // self.world) * w["cols"]
+        return w["off"] + self.rank * n, w["off"] + (self.rank + 1) * n
+
+    def parts(self):
+        """Element ranges of the flat buffers this rank's optimiser steps: its rows of every sharded weight + everything replicated."""
+        out = [self.own(w) for w in self.weights] + [r for rs in self.rest for r in rs]
+        return sorted(out)
+
+    def attach(self, opt):
+        self.opt = opt
+        if self.world > 1:
+            opt.shards = self.parts()
+            opt.ema_ranges = None
+            if not self.emulate:
+                opt.status_sync = self._sync_status
+
+    def _sync_status(self, status):
+        if _host_staged(self.group, status):               # (rehearsal groups only: see Zero1Reducer._sync_status)
+            h = status.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            status.copy_(h)
+        else:
+            dist.all_reduce(status, op=dist.ReduceOp.MAX, group=self.group)
+
+    # ---- gradient exchange, per backward stage -------------------------------------------------------------------------------------
+    def _on_stage(self, stage: int):
+        if self.emulate:
+            return
+        g = self.model._gflat
+        for lo, hi in self.rest[stage]:
+            self.works.append(_all_reduce_sum(g[lo:hi], self.group))
+        for w in (w for w in self.weights if w["stage"] == stage):
+            lo, hi = w["off"], w["off"] + w["rows"] * w["cols"]
+            mlo, mhi = self.own(w)
+            if self.grad_dtype == "bf16":
+                self._exchange16(g, w, lo, hi)
+            elif self._native:
+                # in place: the output is the rank-th part of the input (RCCL's in-place reduce-scatter layout)
+                self.works.append(dist.reduce_scatter_tensor(g[mlo:mhi], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:                               # gloo has no reduce-scatter: all-reduce the weight, the rank then uses its own rows
+                self.works.append(_all_reduce_sum(g[lo:hi], self.group))
+
+    def _exchange16(self, g, w, lo, hi):
+        """16-bit exchange of one weight's raw gradient: bf16 copies of every owner's rows travel (asynchronously, under the backward of
+        the earlier blocks); the owner sums them in fp32 in finish()."""
+        from . import _lib as Lib
+        n = hi - lo
+        per = n // self.world
+        if self._send16 is None:
+            self._send16 = torch.empty(self._tot16, dtype=torch.bfloat16, device=g.device)
+            self._recv16 = torch.empty(self._tot16, dtype=torch.bfloat16, device=g.device)
+        o = self._off16[w["off"]]
+        send, recv = self._send16[o:o + n], self._recv16[o:o + n]
+        with torch.cuda.device(g.device):
+            Lib.lib().f32_to_bf16(g[lo:hi].data_ptr(), send.data_ptr(), n, 1.0, Lib.cur_stream())
+        if _host_staged(self.group, g):
+            parts = [torch.empty(2 * n, dtype=torch.uint8) for _ in range(self.world)]          # (as bytes: any backend)
+            dist.all_gather(parts, send.cpu().view(torch.uint8), group=self.group)
+            recv.copy_(torch.cat([p_.view(torch.bfloat16)[self.rank * per:(self.rank + 1) * per] for p_ in parts]))
+        else:       # chunk r of every rank's copy -> rank r, received in rank order
+            self.works.append(dist.all_to_all_single(recv, send, group=self.group, async_op=True))
+        self._pending16.append((w, o))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if self.world > 1:
+            from . import _lib as Lib
+            rt = self._train_rt()
+            g = self.model._gflat
+            with torch.cuda.device(self.model._pflat.device):
+                for w, o in self._pending16:  # 16-bit exchange: the owner's fp32 sum of every rank's bf16 copy of its rows
+                    mlo, mhi = self.own(w)
+                    per = mhi - mlo
+                    Lib.lib().sum_bf16_chunks(g[mlo:mhi].data_ptr(), self._recv16[o:o + per * self.world].data_ptr(), self.world, per, per,
+                                              Lib.cur_stream())
+                self._pending16.clear()
+                # the Jacobian on the owned rows (in place in the gradient buffer)
+                Lib.lib().engine_jacobian_shard(rt.handle, Lib.cur_stream())
+
+    reduce = lambda self, flat=None: self.finish()
+
+    def _train_rt(self):
+        m = self.model
+        precision = getattr(m, "gemm_precision", "f16")
+        rt = m._rt.get(True if precision == "bf16" else (precision, True))
+        assert rt is not None, "no training engine yet: run a training forward first"
+        return rt
+
+    # ---- all-gather of the 16-bit weight images, after the (sharded) weight pass of a training forward --------------------------------
+    def _image_views(self, rt):
+        """Flat byte views of every sharded weight's 16-bit image (and split image) inside the engine's workspace."""
+        import ctypes as C
+        if getattr(self, "_views_of", None) is rt:
+            return self._views
+        ws, base, out = rt.workspace, rt.workspace.data_ptr(), []
+        for w in self.weights:
+            img, img3, rows, cols, sh = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+            rt.lib.engine_weight_image(rt.handle, w["pidx"], C.byref(img), C.byref(img3), C.byref(rows), C.byref(cols), C.byref(sh))
+            assert sh.value == 1 and rows.value == w["rows"] and cols.value == w["cols"], f"engine and reducer disagree on the sharding of weight {w}"
+            for ptr, width in ((img.value, cols.value), (img3.value, 3 * cols.value)):
+                if ptr:
+                    o = ptr - base
+                    assert 0 <= o and o + rows.value * width * 2 <= ws.numel()
+                    out.append(ws[o:o + rows.value * width * 2])          # (bytes: every backend moves uint8)
+        self._views_of, self._views = rt, out
+        return out
+
+    def _gather_images(self, rt):
+        if self.emulate:
+            # one-GPU measurement: nothing is gathered, so the other ranks' rows of the images would be whatever the workspace held.  Once,
+            # image EVERY row (unsharded pass, no rewrite) so that the network computes on finite numbers; they go stale, the timing does not care.
+            if not self._emu_ready:
+                from . import _lib as Lib
+                with torch.cuda.device(self.model._pflat.device):
+                    rt.lib.engine_set_shard(rt.handle, 0, 1)
+                    rt.lib.engine_prepare_weights(rt.handle, 0, Lib.cur_stream())
+                    rt.lib.engine_set_shard(rt.handle, self.rank, self.world)
+                self._emu_ready = True
+            return
+        works = []
+        for whole in self._image_views(rt):
+            n = whole.numel() // self.world
+            mine = whole[self.rank * n:(self.rank + 1) * n]
+            if self._native:
+                works.append(dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True))      # in place
+            elif _host_staged(self.group, whole):
+                parts = [torch.empty(n, dtype=whole.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, mine.detach().cpu(), group=self.group)
+                whole.copy_(torch.cat(parts))
+            else:
+                works.append(dist.all_gather(list(whole.chunk(self.world)), mine.clone(), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    # ---- completing the sharded state (checkpoints, EMA snapshots, evaluation) ------------------------------------------------------
+    def gather_state(self):
+        if self.world == 1 or self.emulate:
+            return
+        bufs = [self.model._pflat]
+        if self.opt is not None:
+            bufs += [self.opt.exp_avg, self.opt.exp_avg_sq] + list(self.opt.ema)
+        for buf in bufs:
+            for w in self.weights:
+                lo, hi = w["off"], w["off"] + w["rows"] * w["cols"]
+                mlo, mhi = self.own(w)
+                whole, mine = buf[lo:hi], buf[mlo:mhi]
+                before = _range_checksum(mine)
+                if self._native:
+                    dist.all_gather_into_tensor(whole, mine, group=self.group)
+                elif _host_staged(self.group, buf):
+                    parts = [torch.empty(mhi - mlo, dtype=buf.dtype) for _ in range(self.world)]
+                    dist.all_gather(parts, mine.detach().cpu(), group=self.group)
+                    whole.copy_(torch.cat(parts))
+                    torch.cuda.synchronize(buf.device)
+                else:
+                    dist.all_gather(list(whole.chunk(self.world)), mine.clone(), group=self.group)
+                _verify_gather(whole, mhi - mlo, self.world, before, self.group)
+        self.model.mark_weights_changed()
+
+
 def make_reducer(model, mode: str | None = None, group=None):
-    """``allreduce`` (default; per-stage all-reduce overlapped with backward, replicated optimiser) or ``zero1``."""
+    """``allreduce`` (default; per-stage all-reduce overlapped with backward, replicated optimiser), ``zero1``, or ``zero1w`` /
+    ``zero1w-bf16`` (sharded weight passes with an fp32 / 16-bit gradient exchange; round 5)."""
     mode = mode or os.environ.get("MAPDIT_GRAD_COMM") or "allreduce"
     if mode == "allreduce":
         return OverlappedGradReducer(model, group)
     if mode == "zero1":
         return Zero1Reducer(model, group)
-    raise ValueError(f"unknown gradient exchange {mode!r} (allreduce | zero1)")
+    if mode in ("zero1w", "zero1w-bf16"):
+        return ShardedPassReducer(model, group, grad_dtype="bf16" if mode.endswith("bf16") else "fp32")
+    raise ValueError(f"unknown gradient exchange {mode!r} (allreduce | zero1 | zero1w | zero1w-bf16)")
 
 
 def shard_batch(global_batch: int, rank: int, world: int):

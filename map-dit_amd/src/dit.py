@@ -421,6 +421,11 @@ class DiT(nn.Module):
             rt = _Runtime(self, max(batch, 1), train, precision)
             self._rt[slot] = rt
         rt.bind(self)
+        # data parallelism with sharded weight passes (parallel.ShardedPassReducer): the training engine works on this rank's rows
+        shard = getattr(self, "_shard", None) if train and precision != "bf16x3" else None
+        if (shard or (0, 1)) != getattr(rt, "shard", (0, 1)):
+            rt.lib.engine_set_shard(rt.handle, *(shard or (0, 1)))
+            rt.shard = shard or (0, 1)
         return rt
 
     # "f16" only: the power of two the backward multiplies the incoming gradient by (mapdit_config_t.loss_scale); 0 = chosen per
@@ -509,6 +514,9 @@ class DiT(nn.Module):
                 rt.weights_key = None
                 for other in self._rt.values():
                     other.weights_key = None
+                hook = getattr(self, "_after_prepare_hook", None)          # sharded weight passes: all-gather of the 16-bit images
+                if hook is not None and need_grad:
+                    hook(rt)
             else:
                 key = self._weights_key()
                 if rt.weights_key != key:

@@ -101,9 +101,10 @@ def build_parser():
                         "loss scale, steps with non-finite gradients are refused and the scale halved), bf16 (the same engine with bf16 "
                         "operands: 2 %% faster, ~6e-3) or bf16x3 (fp32-accurate forward and backward, the reference's numerics to ~1e-5, "
                         "several times slower)")
-    p.add_argument("--grad-comm", choices=["allreduce", "zero1"], default=None,
+    p.add_argument("--grad-comm", choices=["allreduce", "zero1", "zero1w", "zero1w-bf16"], default=None,
                    help="data-parallel gradient exchange: per-stage all-reduce overlapped with backward (default), or "
-                        "reduce-scatter + sharded optimiser + all-gather")
+                        "reduce-scatter + sharded optimiser + all-gather (zero1), or sharded weight passes - forced weight norm, imaging, "
+                        "Jacobian, Adam / EMA on 1/world of the rows, 16-bit images all-gathered (zero1w; -bf16: 16-bit gradient exchange)")
     for f in MP_FLAGS:
         p.add_argument(f"--use-{f}", dest="use_" + f.replace("-", "_"), action=argparse.BooleanOptionalAction, default=True)
     p.add_argument("--use-rotation-modulation", action=argparse.BooleanOptionalAction, default=False,

@@ -230,7 +230,7 @@ def _run_dp(tmp_path, tag, world, mode, precision, steps=3, rccl=False):
     return [torch.load(out / f"rank{i}.pt", weights_only=False) for i in range(world)]
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "zero1"])
+@pytest.mark.parametrize("mode", ["allreduce", "zero1", "zero1w"])
 def test_two_rank_overflow_is_refused_on_every_rank(tmp_path, monkeypatch, mode):
     """fp16 engine, two data-parallel ranks: the SECOND rank's loss is blown up in the second of three steps, its gradients overflow.
     The non-finite guard looks at the REDUCED gradients (all-reduce: inf / NaN reaches every rank with the sum; ZeRO-1: each rank checks
@@ -291,6 +291,34 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
         e = rel_err(ar[0][k].numpy(), single3[k].numpy())
         print(f"{precision}: 2-rank all-reduce vs single process after 3 steps, {k}: {e:.2e}")
         assert e < tol, (k, e)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_two_rank_sharded_weight_passes(tmp_path, precision):
+    """--grad-comm zero1w / zero1w-bf16 (round 5): two ranks (gloo collectives, both on this box's GPU), the rows of every block linear
+    split between them - each rank rewrites / images, differentiates (Jacobian), steps (Adam + EMA) ITS rows only; raw weight gradients are
+    exchanged per stage, 16-bit images all-gathered before the next forward.  After gather_state the replicas hold the same bits, and the run
+    equals the replicated all-reduce run up to the order of Jacobian and rank sum (a linear map: fp32 rounding only) - resp., for the 16-bit
+    exchange, up to one bf16 rounding of each rank's raw gradient."""
+    ar = _run_dp(tmp_path, "ar", 2, "allreduce", precision, steps=1)
+    for mode, tol in (("zero1w", 2e-5), ("zero1w-bf16", 2e-3)):
+        zw = _run_dp(tmp_path, mode, 2, mode, precision, steps=1)
+        for k in ("p", "m", "v", "e0", "e1"):
+            assert torch.equal(zw[0][k], zw[1][k]), f"{mode}: replicas differ in {k} after gather_state"
+            assert torch.isfinite(zw[0][k]).all(), k
+            e = rel_err(zw[0][k].numpy(), ar[0][k].numpy())
+            print(f"{precision} {mode} vs all-reduce after 1 step, {k}: {e:.2e}")
+            assert e < tol, (mode, k, e)
+        assert zw[0]["shards"] != zw[1]["shards"]
+    # three steps: the sharded run keeps training like the replicated one (bf16 re-rounding of re-normalised weights amplifies 1e-7: loose)
+    ar3 = _run_dp(tmp_path, "ar3", 2, "allreduce", precision)
+    zw3 = _run_dp(tmp_path, "zw3", 2, "zero1w", precision)
+    for k in ("p", "m", "e0"):
+        assert torch.equal(zw3[0][k], zw3[1][k])
+        e = rel_err(zw3[0][k].numpy(), ar3[0][k].numpy())
+        print(f"{precision} zero1w vs all-reduce after 3 steps, {k}: {e:.2e}")
+        assert e < 2e-2, (k, e)
+    assert abs(zw3[0]["loss"] - zw3[1]["loss"]) < 1.0 and zw3[0]["refused"] == 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL with more than one rank")
