@@ -2205,6 +2205,7 @@ struct GemmEnv {
     int nsplit = 1;          // MAPDIT_GEMM_NSPLIT = 0: no column split of results whose width is an odd multiple of 128
     int w3 = 0;              // MAPDIT_GEMM_W3 = 1 (experiment builds only): the three-deep A ring variant of the round-4 kernel
     int fast_epi = 1;        // MAPDIT_GEMM_FE = 0: never the straight-line epilogue instantiation (RESID; A/B)
+    int band768 = 3;         // MAPDIT_GEMM_BAND768 = column tiles per band of the K <= 768 forward (NT) GEMMs (fc1, QKV)
     int stagger = -1;        // MAPDIT_GEMM_STAGGER = late start of every second workgroup, units of 8,128 cycles (persistent launches); -1: by epilogue
     GemmEnv() {
         if (const char* e = getenv("MAPDIT_GEMM_PERSIST")) persist = atoi(e);
@@ -2212,6 +2213,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_NSPLIT")) nsplit = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_W3")) w3 = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_STAGGER")) stagger = atoi(e);
+        if (const char* e = getenv("MAPDIT_GEMM_BAND768")) band768 = atoi(e) > 0 ? atoi(e) : 3;
         if (const char* e = getenv("MAPDIT_GEMM_FE")) fast_epi = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
@@ -2336,7 +2338,8 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         // 380 us): the XCD's share of the tile order (an eighth of it) then lies inside one band, and the A panels of its 32
         // concurrent tiles (11 x 393 KB) are what the L2 keeps, the three B tiles with them.  The NN dX GEMM of the same shape
         // (fc2-dX, 346 vs 355 us) keeps six.
-        if (!be && layout == MAPDIT_NT && split_k == 1 && K <= 768 && p.tiles_n >= 6 && p.tiles_n % 3 == 0) band = 3;
+        // (MAPDIT_GEMM_BAND768 = another width for exactly this rule: A/B runs, round 5)
+        if (!be && layout == MAPDIT_NT && split_k == 1 && K <= 768 && p.tiles_n >= 6 && p.tiles_n % gemm_env().band768 == 0) band = gemm_env().band768;
         if (band < 1 || band > p.tiles_n) band = p.tiles_n;
         p.band = (int)band;
         int grid = p.tiles * split_k;
