@@ -851,7 +851,7 @@ extern "C" __global__ void mapdit_debug_set_stamps_kernel(long long* p, int bloc
 #define G256_STAMPS_OUT()
 #endif
 
-// Ablation builds (tools/gemm_ablate.py; timing experiments, results are garbage): MAPDIT_GEMM_ABLATE bit 0 drops the K loop's
+// Ablation builds (tools/attic/gemm_ablate.py; timing experiments, results are garbage): MAPDIT_GEMM_ABLATE bit 0 drops the K loop's
 // LDS-DMA (after the prologue), bit 1 its fragment reads (after the first K-tile).
 #ifndef MAPDIT_GEMM_ABLATE
 #define MAPDIT_GEMM_ABLATE 0
@@ -1031,7 +1031,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmP& p, const Epi& epi, cha
         // operands were read one step earlier: the fragment reads of the next step are issued first, then the MFMAs of the current
         // one.  Both waves of a SIMD offer MFMAs all the time, so the matrix pipe only idles at the ONE barrier per K-tile (the
         // two-phase loop has four, and at any time only one of its two wave groups issues MFMAs: 77 % pipe occupancy even with empty
-        // LOAD intervals, tools/gemm_ablate.py).  LDS and staging as in the one-phase loop: three A and two B buffers of two 16 KiB
+        // LOAD intervals, tools/attic/gemm_ablate.py).  LDS and staging as in the one-phase loop: three A and two B buffers of two 16 KiB
         // slots; group g stages B_g of tile t+2 and then A_g of tile t+3 right after the barrier of tile t.
         //   RAW  the barrier of iteration t follows every wave's vmcnt(4) (its pieces of tile t+1 have landed; the four youngest,
         //        A of tile t+2, stay in flight) and precedes the first read of tile t+1.

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mapdit_amd  # noqa: E402
 from tools.gemm_bench import run  # noqa: E402
 
