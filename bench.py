@@ -140,7 +140,7 @@ def pmc_traffic(model, batch):
     here = os.path.dirname(os.path.abspath(__file__))
     src = os.path.join(here, "map-dit_amd", "csrc", "gemm.hip")
     sha = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
-    for name in ("r04_fc1_pmc_traffic.json", "r03_fc1_pmc_traffic.json", "r02_fc1_pmc_traffic.json", "r01_fc1_pmc_traffic.json"):
+    for name in ("r05_fc1_pmc_traffic.json", "r04_fc1_pmc_traffic.json", "r03_fc1_pmc_traffic.json", "r02_fc1_pmc_traffic.json", "r01_fc1_pmc_traffic.json"):
         path = os.path.join(here, "profiles", name)
         if not os.path.exists(path):
             continue

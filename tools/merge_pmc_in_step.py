@@ -4,7 +4,7 @@ tools/pmc_in_step.sh (top-level figures = the launch inside the training step, w
     python tools/merge_pmc_in_step.py [tag = r04]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 path = os.path.join(ROOT, "profiles", f"{tag}_fc1_pmc_traffic.json")
 iso = json.load(open(path))
 if "isolated" in iso:

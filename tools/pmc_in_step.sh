@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_instep[_band<b>]/pmc_<counters>/step_counter_collection.csv ; summarised by tools/pmc_in_step_summary.py
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-tag=${1:-r04}; band=${2:-}
+tag=${1:-r05}; band=${2:-}
 out=gpurun_out/${tag}_instep${band:+_band$band}
 mkdir -p $out
 [ -n "$band" ] && export MAPDIT_GEMM_BAND=$band

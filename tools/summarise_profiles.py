@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", TAG + "_final")
 DST = os.path.join(ROOT, "profiles")
 
@@ -55,7 +55,8 @@ d = {
 json.dump(d, open(os.path.join(DST, TAG + "_fc1_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: d[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "l2_hit_rate", "mfma_busy_over_sq_busy")}))
 with open(os.path.join(DST, TAG + "_bench_lines.jsonl"), "w") as f:
-    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_f16", "bench_under_rocprof",
+    for name in ("bench_default", "bench_b128", "bench_b64", "bench_b32", "bench_b128_emulated_zero1w", "bench_b64_emulated_zero1w",
+                 "bench_b32_emulated_zero1w", "bench_mp_off", "bench_rotation", "bench_S2", "bench_XL2_b64", "bench_f16", "bench_under_rocprof",
                  "sample_XL2_bf16", "sample_XL2_f16", "sample_B2_f16"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 10:
@@ -66,4 +67,7 @@ for name in ("S2", "XL2_b64", "XL2_sample", "B2_rotation"):              # kerne
     for cand in (os.path.join(SRC, f"prof_{name}", f"{name}_kernel_stats.csv"),):
         if os.path.exists(cand):
             shutil.copy(cand, os.path.join(DST, f"{TAG}_kernel_stats_{name}.csv"))
+for src, dst in (("prof32e/bench32e_kernel_stats.csv", "_kernel_stats_bench_batch32_emulated_zero1w.csv"), ("step_by_dispatch.txt", "_step_by_dispatch.txt")):
+    if os.path.exists(os.path.join(SRC, src)):
+        shutil.copy(os.path.join(SRC, src), os.path.join(DST, TAG + dst))
 print(f"wrote profiles/{TAG}_*")
