@@ -456,6 +456,109 @@ def test_adam_ema(L):
     assert rel_err(d[5].cpu().numpy(), e2.numpy()) < 1e-6
 
 
+def test_round5_weight_pass_kernels(L):
+    """The kernels behind the sharded weight passes and the side-stream Jacobian (abi 5), each against the entry point it replaces:
+    * mapdit_weightnorm_bwd_slim (48 registers, no LDS): the bits of mapdit_weightnorm_bwd, for 1 / 3 / 7 / 9 split-K slabs;
+    * mapdit_reduce_slabs + an in-place one-slab mapdit_weightnorm_bwd on a ROW RANGE == the whole-weight Jacobian on those rows
+      (the raw sum is what a reduce-scatter moves; the Jacobian of a row needs that row only);
+    * mapdit_weightnorm_bwd_batch (row ranges of several weights in one launch, in place) == per-weight launches, bit for bit;
+    * mapdit_adam_ema_step_ranges / mapdit_grad_nonfinite_check_ranges == the contiguous entry points on each range, bit for bit,
+      elements outside the ranges untouched, a NaN inside a range flagged and outside it ignored;
+    * mapdit_sum_bf16_chunks == the fp32 sum of the bf16 values in chunk order; mapdit_scale_copy."""
+    import numpy as np
+    if MODE["f16"]:
+        pytest.skip("fp32 kernels: one copy in the library")
+    g = torch.Generator().manual_seed(77)
+    rows, cols = 96, 768
+    W = torch.randn(rows, cols, generator=g).to(DEV)
+    for S in (1, 3, 7, 9):
+        slabs = torch.randn(S, rows, cols, generator=g).to(DEV)
+        a, b = slabs.clone(), slabs.clone()
+        da, db = torch.zeros(rows, cols, device=DEV), torch.zeros(rows, cols, device=DEV)
+        L.lib().weightnorm_bwd(p(W), p(a), cols, S, rows * cols, p(da), rows, cols, 1.0, 0, st())
+        L.lib().weightnorm_bwd_slim(p(W), p(b), cols, S, rows * cols, p(db), rows, cols, 1.0, 0, st())
+        torch.cuda.synchronize()
+        assert torch.equal(da, db) and torch.equal(a[0], b[0]), S
+        # raw sum, then the Jacobian of rows [32, 64) in place
+        raw = torch.full((rows, cols), float("nan"), device=DEV)
+        L.lib().reduce_slabs(p(raw), p(slabs), S, rows * cols, rows * cols, st())
+        torch.cuda.synchronize()
+        assert torch.equal(raw, a[0] if S > 1 else slabs[0])                     # (the Jacobian parks the same ordered sum in slab 0)
+        lo, hi = 32, 64
+        L.lib().weightnorm_bwd(W.data_ptr() + lo * cols * 4, raw.data_ptr() + lo * cols * 4, cols, 1, 0, raw.data_ptr() + lo * cols * 4,
+                               hi - lo, cols, 1.0, 0, st())
+        torch.cuda.synchronize()
+        assert torch.equal(raw[lo:hi], da[lo:hi]) and torch.equal(raw[:lo], (a[0] if S > 1 else slabs[0])[:lo])
+    # batch of row ranges
+    shapes = [(64, 256), (24, 768), (7, 128)]
+    Ws = [torch.randn(r, c, generator=g).to(DEV) for r, c in shapes]
+    Gs = [torch.randn(r, c, generator=g).to(DEV) for r, c in shapes]
+    single = []
+    for Wt, Gt, (r, c) in zip(Ws, Gs, shapes):
+        d = torch.zeros(r, c, device=DEV)
+        L.lib().weightnorm_bwd(p(Wt), p(Gt.clone()), c, 1, 0, p(d), r, c, 1.0, 0, st())
+        single.append(d)
+    jobs = (L.WnJob * len(shapes))()
+    blocks = 0
+    Gb = [t.clone() for t in Gs]
+    for j, (Wt, Gt, (r, c)) in enumerate(zip(Ws, Gb, shapes)):
+        jobs[j] = L.WnJob(W=p(Wt), rows=r, cols=c, out_scale=1.0, first_block=blocks, w_bf16=None, w_f32=p(Gt))
+        blocks += (r + 3) // 4
+    raw = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(DEV)
+    L.lib().weightnorm_bwd_batch(p(raw), len(shapes), blocks, st())
+    torch.cuda.synchronize()
+    for a, b in zip(single, Gb):
+        assert torch.equal(a, b)
+    # multi-range optimiser step and check
+    n = 40_000
+    ranges = [(0, 4096), (8192, 8192 + 5000), (20_000, 20_004), (30_000, 39_996)]
+    init = [torch.randn(n, generator=g) for _ in range(6)]
+    init[3] = init[3].abs()                                                      # second moment
+    hyper = L.AdamScalars(1e-2 / (1 - 0.9), 1 / math.sqrt(1 - 0.99), 0.3, 0.6, 0.5)
+    A = [t.to(DEV).clone() for t in init]
+    B = [t.to(DEV).clone() for t in init]
+    for lo, hi in ranges:
+        L.lib().adam_ema_step_scalars(*(t.data_ptr() + 4 * lo for t in (A[0], A[1], A[2], A[3], A[4], A[5])), hi - lo, C.byref(hyper), 0.9, 0.99,
+                                      1e-8, st())
+    tab, blk = [], 0
+    for lo, hi in ranges:
+        tab.append((lo, hi, blk))
+        blk += (hi - lo + 4095) // 4096
+    tabd = torch.tensor(tab, dtype=torch.int64, device=DEV)
+    status = torch.zeros(2, dtype=torch.int32, device=DEV)
+    L.lib().grad_nonfinite_check_ranges(p(B[1]), p(tabd), len(ranges), blk, p(status), 5, st())
+    L.lib().adam_ema_step_ranges(p(B[0]), p(B[1]), p(B[2]), p(B[3]), p(B[4]), p(B[5]), p(tabd), len(ranges), blk, C.byref(hyper), 0.9, 0.99, 1e-8,
+                                 p(status), 5, st())
+    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0]
+    for a, b, i0 in zip(A, B, init):
+        assert torch.equal(a, b)
+        assert torch.equal(b[4096:8192].cpu(), i0[4096:8192])                    # outside every range: untouched
+    assert not torch.equal(B[0][:4096].cpu(), init[0][:4096])
+    B[1][5000] = float("nan")                                                    # outside the ranges: ignored
+    L.lib().grad_nonfinite_check_ranges(p(B[1]), p(tabd), len(ranges), blk, p(status), 6, st())
+    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0]
+    B[1][8192 + 4999] = float("inf")                                             # last element of a range: flagged, and the step is refused
+    keep = B[0].clone()
+    L.lib().grad_nonfinite_check_ranges(p(B[1]), p(tabd), len(ranges), blk, p(status), 7, st())
+    L.lib().adam_ema_step_ranges(p(B[0]), p(B[1]), p(B[2]), p(B[3]), p(B[4]), p(B[5]), p(tabd), len(ranges), blk, C.byref(hyper), 0.9, 0.99, 1e-8,
+                                 p(status), 7, st())
+    torch.cuda.synchronize()
+    assert status.tolist() == [7, 1] and torch.equal(B[0], keep)
+    # 16-bit exchange, receiving side; scale copy
+    chunks = torch.randn(4, 1024, generator=g).bfloat16().to(DEV)
+    out = torch.zeros(1024, device=DEV)
+    L.lib().sum_bf16_chunks(p(out), p(chunks), 4, 1024, 1024, st())
+    want = chunks[0].float()
+    for c_ in chunks[1:]:
+        want = want + c_.float()
+    sc = torch.zeros(1024, device=DEV)
+    L.lib().scale_copy(p(sc), p(out), 1024, 0.25, st())
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(sc, out * 0.25)
+
+
 # ---------------------------------------------------------------------------------------------------
 # token-stream kernels
 # ---------------------------------------------------------------------------------------------------

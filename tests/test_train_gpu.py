@@ -293,6 +293,20 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
         assert e < tol, (k, e)
 
 
+def test_side_stream_jacobians_give_the_same_bits(tmp_path, monkeypatch):
+    """MAPDIT_SIDE_JAC=1 (round 5, opt-in: measured slower): the weight-norm Jacobians on the engine's side stream
+    (48-register kernel, ping-pong slab buffers, event hand-over, join at the end of every backward call) must be an ordering change
+    only - the same gradients, weights and optimiser state bit for bit after three steps, single process and staged (two-rank) backward."""
+    base = _run_dp(tmp_path, "base", 1, "allreduce", "bf16")[0]
+    base2 = _run_dp(tmp_path, "base2", 2, "allreduce", "f16")
+    monkeypatch.setenv("MAPDIT_SIDE_JAC", "1")
+    side = _run_dp(tmp_path, "side", 1, "allreduce", "bf16")[0]
+    side2 = _run_dp(tmp_path, "side2", 2, "allreduce", "f16")
+    for k in ("p", "g", "m", "v", "e0", "e1"):
+        assert torch.equal(base[k], side[k]), k
+        assert torch.equal(base2[0][k], side2[0][k]) and torch.equal(side2[0][k], side2[1][k]), k
+
+
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_two_rank_sharded_weight_passes(tmp_path, precision):
     """--grad-comm zero1w / zero1w-bf16 (round 5): two ranks (gloo collectives, both on this box's GPU), the rows of every block linear
