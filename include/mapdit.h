@@ -460,6 +460,9 @@ int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* dout, int sta
  * only (the host all-gathers the images: mapdit_engine_weight_image), backward leaves those weights' gradients as RAW sums (no weight-
  * norm Jacobian) for a reduce-scatter, and jacobian_shard applies the Jacobian to the owned rows in place.  world = 1 undoes it. */
 int mapdit_engine_set_shard(mapdit_engine_t* e, int rank, int world);
+/* One-shot: the next forward waits for events[i] (hipEvent_t) on its stream before block i reads its weight images (events[0] before the
+ * batched modulation GEMM too: gather every block's modulation image with block 0).  n = depth, or 0 to clear. */
+int mapdit_engine_set_block_fences(mapdit_engine_t* e, void* const* events, int n);
 int mapdit_engine_weight_image(mapdit_engine_t* e, int pidx, void** img, void** img3, int* rows, int* cols, int* sharded);
 int mapdit_engine_jacobian_shard(mapdit_engine_t* e, void* stream);
 int mapdit_engine_set_loss_scale(mapdit_engine_t* e, float loss_scale);

@@ -134,6 +134,7 @@ _SIGS = {
     "mapdit_engine_backward": [vp, vp, vp],
     "mapdit_engine_backward_stages": [vp, vp, ci, ci, vp],
     "mapdit_engine_set_shard": [vp, ci, ci],
+    "mapdit_engine_set_block_fences": [vp, C.POINTER(vp), ci],
     "mapdit_engine_weight_image": [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)],
     "mapdit_engine_jacobian_shard": [vp, vp],
     "mapdit_engine_set_loss_scale": [vp, cf],

@@ -144,6 +144,8 @@ struct mapdit_engine {
     // EMA - the batch-independent passes, 2.1 ms of a 10.2 ms step at 32 samples per GPU - shrink by the number of ranks.
     int shard_rank = 0, shard_world = 1;
     std::vector<char> sharded;            // indexed like the parameter table: rows split over the ranks
+    std::vector<hipEvent_t> fences;       // one-shot: the next training forward waits for fences[i] before block i (fences[0]: before anything
+                                          // that reads a block weight): the host's per-block all-gathers of the images
     std::vector<mapdit_wn_job_t> jac_jobs;   // the Jacobians of the owned rows as ONE launch (mapdit_weightnorm_bwd_batch)
     mapdit_wn_job_t* jac_jobs_dev = nullptr;
     int jac_blocks = 0;
@@ -887,6 +889,18 @@ extern "C" int mapdit_engine_set_shard(mapdit_engine_t* e, int rank, int world) 
     return MAPDIT_OK;
 }
 
+// The next forward on `stream` waits for events[i] before it touches block i's weight images (events[0] also guards the batched modulation
+// GEMM, which reads every block's modulation image: the host gathers those with block 0).  One-shot: consumed by that forward.
+extern "C" int mapdit_engine_set_block_fences(mapdit_engine_t* e, void* const* events, int n) {
+    MD_CHECK(e && (n == 0 || (events && n == e->cfg.depth)), "engine_set_block_fences: n must be 0 or the depth (%d)", e ? e->cfg.depth : 0);
+    e->fences.clear();
+    for (int i = 0; i < n; ++i) {
+        MD_CHECK(events[i], "engine_set_block_fences: event %d is null", i);
+        e->fences.push_back((hipEvent_t)events[i]);
+    }
+    return MAPDIT_OK;
+}
+
 // 16-bit image (and, for a conditioning weight, its [hi | lo | hi] split image with 3 x cols columns) of a linear's effective weight:
 // what the host all-gathers when the weight passes are sharded.  sharded = the rows are split over the ranks of mapdit_engine_set_shard.
 extern "C" int mapdit_engine_weight_image(mapdit_engine_t* e, int pidx, void** img, void** img3, int* rows, int* cols, int* sharded) {
@@ -1178,6 +1192,9 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     // contiguous [L*6D, D] weight image, plus the final layer's (shift, scale); all later modulate()s are fused into
     // the residual GEMM epilogues that produce their inputs.
     const int ldm = e->ldm;
+    std::vector<hipEvent_t> fences;
+    fences.swap(e->fences);                                // one-shot (sharded weight passes: the host's per-block image gathers)
+    if (!fences.empty()) HIP_TRY(hipStreamWaitEvent((hipStream_t)st, fences[0], 0), "engine_forward: block fence");
     TRY(mapdit_split3(e->c, D, e->cp.As, N, D, MAPDIT_SPLIT_A, MAPDIT_SPLIT_OP_MPSILU, st));
     TRY(gemm(MAPDIT_NT, N, ldm, 3 * D, e->cp.As, 3 * D, e->cp.img3[pidx_block(0, MAPDIT_B_MOD)], 3 * D, epi_f32(e->mod_all, ldm, sa), st));
     TRY(gemm(MAPDIT_NT, N, 2 * D, 3 * D, e->cp.As, 3 * D, e->cp.img3[MAPDIT_P_F_MOD], 3 * D, epi_f32(e->fmod, 2 * D, sa), st));
@@ -1216,6 +1233,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
     else TRY(DT_FN(e, mapdit_modulate_fwd)(e->X[0], sh_of(0, 0), sc_of(0, 0), ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)), e->blk[0].xm,
                                            N, T, D, st));
     for (int i = 0; i < L; ++i) {
+        if (i > 0 && !fences.empty()) HIP_TRY(hipStreamWaitEvent((hipStream_t)st, fences[i], 0), "engine_forward: block fence");
         BlockBufs& b = e->blk[save ? i : 0];
         const float* mod = e->mod_all + (size_t)i * e->MW;
         float* xin = e->X[save ? 2 * i : (2 * i) % 3];

@@ -438,6 +438,11 @@ class ShardedPassReducer(_ReducerBase):
         model._stage_hook = self._on_stage if self.world > 1 else None
         model._after_prepare_hook = self._gather_images if self.world > 1 else None
         self._native = self.world > 1 and not emulate and dist.get_backend(group) == "nccl"
+        # MAPDIT_ZERO1W_COALESCE=0: one collective per weight (the form the two-rank rehearsals run); default on RCCL: one grouped launch
+        # per backward stage, one grouped all-gather per block, the forward fenced per block (see _gather_images)
+        self._coalesce = os.environ.get("MAPDIT_ZERO1W_COALESCE", "1") != "0"
+        self._fence_stream = None
+        self._fence_events = None
 
     @property
     def grad_scale(self) -> float:
@@ -476,7 +481,18 @@ class ShardedPassReducer(_ReducerBase):
         g = self.model._gflat
         for lo, hi in self.rest[stage]:
             self.works.append(_all_reduce_sum(g[lo:hi], self.group))
-        for w in (w for w in self.weights if w["stage"] == stage):
+        mine = [w for w in self.weights if w["stage"] == stage]
+        if self._native and self.grad_dtype == "fp32" and self._coalesce and len(mine) > 1:
+            # RCCL: the stage's reduce-scatters as ONE grouped launch (torch's coalescing manager: ncclGroupStart / End around them) -
+            # five collectives of 2 ... 9 MB each pay their launch latency once
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(group=self.group, device=g.device, async_ops=True) as cm:
+                for w in mine:
+                    mlo, mhi = self.own(w)
+                    dist.reduce_scatter_tensor(g[mlo:mhi], g[w["off"]:w["off"] + w["rows"] * w["cols"]], op=dist.ReduceOp.SUM, group=self.group)
+            self.works.append(cm)
+            return
+        for w in mine:
             lo, hi = w["off"], w["off"] + w["rows"] * w["cols"]
             mlo, mhi = self.own(w)
             if self.grad_dtype == "bf16":
@@ -542,7 +558,11 @@ class ShardedPassReducer(_ReducerBase):
         if getattr(self, "_views_of", None) is rt:
             return self._views
         ws, base, out = rt.workspace, rt.workspace.data_ptr(), []
+        self._views_per_weight = []
+        from . import _lib as Lib
+        self._num_global, self._num_block = Lib.NUM_GLOBAL, Lib.NUM_BLOCK
         for w in self.weights:
+            n_before = len(out)
             img, img3, rows, cols, sh = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
             rt.lib.engine_weight_image(rt.handle, w["pidx"], C.byref(img), C.byref(img3), C.byref(rows), C.byref(cols), C.byref(sh))
             assert sh.value == 1 and rows.value == w["rows"] and cols.value == w["cols"], f"engine and reducer disagree on the sharding of weight {w}"
@@ -551,10 +571,49 @@ class ShardedPassReducer(_ReducerBase):
                     o = ptr - base
                     assert 0 <= o and o + rows.value * width * 2 <= ws.numel()
                     out.append(ws[o:o + rows.value * width * 2])          # (bytes: every backend moves uint8)
+            self._views_per_weight.append(len(out) - n_before)
         self._views_of, self._views = rt, out
         return out
 
+    def _gather_images_fenced(self, rt):
+        """RCCL: one grouped all-gather per block (its four linears' images, the modulation image and split image), issued in block order
+        right after the weight pass; the engine's forward waits for block i's gather just before block i (mapdit_engine_set_block_fences),
+        so every gather but the first runs under the blocks before it.  Modulation images feed the ONE batched modulation GEMM at the
+        start of the forward: they travel with block 0's group."""
+        import ctypes as C
+        from torch.distributed.distributed_c10d import _coalescing_manager
+        views = self._image_views(rt)                      # per sharded weight: [image] or [image, split image], in self.weights order
+        L = self.model.depth
+        per_block = [[] for _ in range(L)]
+        k = 0
+        for w, nv in zip(self.weights, self._views_per_weight):
+            blk = L - w["stage"]
+            is_mod = (w["pidx"] - self._num_global) % self._num_block == 4
+            for _ in range(nv):
+                per_block[0 if is_mod else blk].append(views[k])
+                k += 1
+        dev = self.model._pflat.device
+        if self._fence_stream is None:
+            self._fence_stream = torch.cuda.Stream(device=dev)
+            self._fence_events = [torch.cuda.Event() for _ in range(L)]
+        handles = (C.c_void_p * L)()
+        for b in range(L):
+            if per_block[b]:
+                with _coalescing_manager(group=self.group, device=dev, async_ops=True) as cm:
+                    for whole in per_block[b]:
+                        n = whole.numel() // self.world
+                        dist.all_gather_into_tensor(whole, whole[self.rank * n:(self.rank + 1) * n], group=self.group)
+                with torch.cuda.stream(self._fence_stream):
+                    cm.wait()                              # the fence stream waits for the collective; the compute stream does not
+                    self._fence_events[b].record(self._fence_stream)
+            else:
+                self._fence_events[b].record(torch.cuda.current_stream(dev))
+            handles[b] = self._fence_events[b].cuda_event
+        rt.lib.engine_set_block_fences(rt.handle, handles, L)
+
     def _gather_images(self, rt):
+        if self._native and self._coalesce:
+            return self._gather_images_fenced(rt)
         if self.emulate:
             # one-GPU measurement: nothing is gathered, so the other ranks' rows of the images would be whatever the workspace held.  Once,
             # image EVERY row (unsharded pass, no rewrite) so that the network computes on finite numbers; they go stale, the timing does not care.

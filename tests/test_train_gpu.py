@@ -293,6 +293,75 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, precision):
         assert e < tol, (k, e)
 
 
+def test_block_fences_order_the_forward_behind_the_host_s_gathers():
+    """mapdit_engine_set_block_fences (round 5: under sharded weight passes the host all-gathers the weight images block by block and the
+    forward waits for block i's gather just before block i).  Mechanics on one GPU: a side stream REWRITES block 1's fc1 image late - after
+    a delay - and records that block's event; the fenced forward must see the rewritten image (it waited), must equal the forward that
+    ran after a full synchronise, and the fences are one-shot (the next forward does not wait for anything)."""
+    import ctypes as C
+    import time
+    from oracle import dit_oracle as O
+    from mapdit_amd import _lib as Lib
+    from mapdit_amd.src.dit import DiT
+    cfg = O.DiTConfig(depth=3, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
+    m = DiT(**cfg.to_dict())
+    m.load_state_dict(O.init_state_dict(cfg, seed=3, gains=0.3))
+    m = m.to(DEV).train()
+    m.gemm_precision = "bf16"
+    m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
+    g = torch.Generator().manual_seed(1)
+    x, t, y = torch.randn(4, 4, 16, 16, generator=g).to(DEV), torch.randint(0, 1000, (4,), generator=g).to(DEV), torch.randint(0, 10, (4,), generator=g).to(DEV)
+    m(x, t, y)                                              # builds the training runtime (and normalises the masters once)
+    rt = m._rt[True]
+    img, img3, rows, cols, sh = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+    pidx = Lib.NUM_GLOBAL + 1 * Lib.NUM_BLOCK + Lib.B_FC1
+    rt.lib.engine_weight_image(rt.handle, pidx, C.byref(img), C.byref(img3), C.byref(rows), C.byref(cols), C.byref(sh))
+    off = img.value - rt.workspace.data_ptr()
+    view = rt.workspace[off:off + rows.value * cols.value * 2].view(torch.bfloat16)
+    assert sh.value == 0 and rows.value == 512 and cols.value == 128
+
+    def plain_forward():
+        with torch.cuda.device(DEV):
+            rt.lib.engine_prepare_weights(rt.handle, 0, Lib.cur_stream())       # (no rewrite: the same images every time)
+            out = torch.empty(4, 8, 16, 16, device=DEV)
+            rt.lib.engine_forward(rt.handle, x.data_ptr(), t.data_ptr(), y.data_ptr(), 4, 0, out.data_ptr(), Lib.cur_stream())
+        torch.cuda.synchronize()
+        return out
+
+    base = plain_forward()
+
+    def forward_with_late_rewrite(fenced):
+        # the weight pass of this forward re-images everything first (hook-free: call it here, then run the network only)
+        with torch.cuda.device(DEV):
+            rt.lib.engine_prepare_weights(rt.handle, 0, Lib.cur_stream())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        evs = [torch.cuda.Event() for _ in range(3)]
+        with torch.cuda.stream(side):
+            evs[0].record(side)
+            torch.cuda._sleep(200_000_000)                   # ~0.1 s: far longer than the whole tiny forward
+            view.mul_(2.0)                                   # "the gather of block 1 lands"
+            evs[1].record(side)
+            evs[2].record(side)
+        if fenced:
+            handles = (C.c_void_p * 3)(*[e.cuda_event for e in evs])
+            rt.lib.engine_set_block_fences(rt.handle, handles, 3)
+        else:
+            torch.cuda.synchronize()
+        out = torch.empty(4, 8, 16, 16, device=DEV)
+        with torch.cuda.device(DEV):
+            rt.lib.engine_forward(rt.handle, x.data_ptr(), t.data_ptr(), y.data_ptr(), 4, 0, out.data_ptr(), Lib.cur_stream())
+        torch.cuda.synchronize()
+        return out
+
+    late = forward_with_late_rewrite(fenced=True)
+    ref = forward_with_late_rewrite(fenced=False)
+    assert torch.equal(late, ref) and not torch.equal(late, base), "the fenced forward must have waited for block 1's image"
+    t0 = time.time()
+    again = plain_forward()                                  # one-shot: nothing left to wait for, and the images are the plain ones again
+    assert torch.equal(again, base) and time.time() - t0 < 5.0
+
+
 def test_side_stream_jacobians_give_the_same_bits(tmp_path, monkeypatch):
     """MAPDIT_SIDE_JAC=1 (round 5, opt-in: measured slower): the weight-norm Jacobians on the engine's side stream
     (48-register kernel, ping-pong slab buffers, event hand-over, join at the end of every backward call) must be an ordering change
