@@ -336,7 +336,9 @@ def main():
             step()
         fence()
         rt = model._rt[True if precision == "bf16" else (precision, True)]
-        L.lib().engine_profile_begin(rt.handle, L.PROF_FC1_FWD, model.depth * steps)
+        # every FOURTH fc1 launch is bracketed by HIP events on the launch stream (an event costs the queue a ~6 us bubble: all 12 per step
+        # were 0.14 ms of measurement inside the measured step); 3 launches per step x steps is still hundreds of samples
+        L.lib().engine_profile_begin_strided(rt.handle, L.PROF_FC1_FWD, model.depth * steps // 4 + 8, 4)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         marks[0].record()

@@ -472,6 +472,7 @@ int mapdit_engine_loss_scale(mapdit_engine_t* e, float* out);
  * MAPDIT_PROF_FC1_FWD = the block-MLP fc1 GEMM (gemm NT + SILU2 epilogue, [N*T, 4D] = [N*T, D] x [4D, D]^T). */
 enum { MAPDIT_PROF_FC1_FWD = 0 };
 int mapdit_engine_profile_begin(mapdit_engine_t* e, int which, int max_events);
+int mapdit_engine_profile_begin_strided(mapdit_engine_t* e, int which, int max_events, int stride); /* abi 5: every stride-th launch only */
 int mapdit_engine_profile_end(mapdit_engine_t* e, int* count, double* total_ms); /* synchronises on the events */
 
 /* Diagnostics: device address of an intermediate of the LAST forward that ran with save=1 (training engines keep every

@@ -140,6 +140,7 @@ _SIGS = {
     "mapdit_engine_set_loss_scale": [vp, cf],
     "mapdit_engine_loss_scale": [vp, C.POINTER(cf)],
     "mapdit_engine_profile_begin": [vp, ci, ci],
+    "mapdit_engine_profile_begin_strided": [vp, ci, ci, ci],
     "mapdit_engine_profile_end": [vp, C.POINTER(ci), C.POINTER(C.c_double)],
     "mapdit_engine_peek": [vp, ci, ci, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(ci), C.POINTER(ci)],
 }
