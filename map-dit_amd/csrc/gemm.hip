@@ -2154,6 +2154,119 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP p, Epi epi) {
 }
 #endif   // MAPDIT_GEMM_EXPERIMENTS
 
+
+#ifdef MAPDIT_GEMM_EXPERIMENTS
+// ---- round 5 experiment: the 256x128 geometry of "two tiles in flight per CU" - K LOOP ONLY ------------------------------------------------
+// VERDICT r04 item 2(b) asks for a 256x128 tile whose waves hold 64 accumulator registers for the current tile beside the previous tile's 64,
+// with that tile's epilogue issued inside this tile's K loop.  Before any epilogue is placed there, the geometry's K loop has to hold the
+// 256^2 loop's rate - this kernel measures exactly that: 8 waves as 4 (M) x 2 (N), 64 x 64 per wave (16 accumulator tiles = 64 registers),
+// a three-deep ring of {A 256 x 64 | B 128 x 64} K-tile stages (144 KiB), one phase per K-tile (LOAD: 16 fragment reads + 6 LDS-DMA
+// pieces; MFMA: 32), the two wave groups alternating LOAD and MFMA intervals one barrier apart as in the shipped kernels, DMA two K-tiles
+// ahead.  Results are correct (plain 16-bit store straight from the accumulator layout: 8-byte pieces, slow but once per tile).
+// gemm_tuning phases = 8 selects it for the plain 16-bit store (tools/gemm_bench.py --x128).  Not part of the product.
+template <int KIND>
+__device__ __forceinline__ void stage_id128(const bf16_t* __restrict__ G, int ld, int idx0, int idx_max, int k0, char* slot, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int seg = wave * 2 + j;
+        const bf16_t* src;
+        if (KIND == OP_ROW) {
+            const int row = seg * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            int g = idx0 + row;
+            g = g < idx_max ? g : idx_max - 1;
+            src = G + (size_t)g * ld + k0 + c * 8;
+        } else {
+            const int krow = seg * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (kswz(krow) << 1);
+            int col = idx0 + c * 8;
+            col = col < idx_max ? col : 0;
+            src = G + (size_t)(k0 + krow) * ld + col;
+        }
+        __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(slot + seg * 1024), 16, 0, 0);
+    }
+}
+
+template <int AK, int BK, class Epi>
+__global__ __launch_bounds__(512, 2) void gemm_x128_kernel(GemmP p, Epi epi) {
+    constexpr int STAGE = 3 * SLOT_BYTES;                  // A rows 0..127 | A rows 128..255 | B 128 columns
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave >> 2;                              // stagger group (waves 4-7 run one interval behind)
+    const int wm = wave & 3, wn = wave >> 2;               // 4 x 2 wave grid: group 0 = column half 0, group 1 = column half 1
+    const int tiles_n = p.N / 128;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+    const int nk = p.K / BKT;
+    constexpr bool TR_ASM2 = AK == OP_KMAJ;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int t) {
+        char* b = smem + (t % 3) * STAGE;
+        stage_id128<AK>(p.A, p.lda, m0, p.M, t * BKT, b, wave, lane);
+        stage_id128<AK>(p.A, p.lda, m0 + 128, p.M, t * BKT, b + SLOT_BYTES, wave, lane);
+        stage_id128<BK>(p.B, p.ldb, n0, p.N, t * BKT, b + 2 * SLOT_BYTES, wave, lane);
+    };
+    stage(0);
+    if (nk > 1) { stage(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wg == 1) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8_t fa[4][2], fb[4][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* b = smem + (t % 3) * STAGE;
+        const char* as = b + (wm >> 1) * SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<AK, TR_ASM2>(as, (wm & 1) * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = read_frag<BK, TR_ASM2>(b + 2 * SLOT_BYTES, wn * 64 + j * 16, ks, lane);
+        // buffer (t + 2) % 3 = (t - 1) % 3 was last read in LOAD(t - 1) of both groups, which ended before this interval began
+        if (t + 2 < nk) { stage(t + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      // tile t + 1 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G256_END_LOAD();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fb[j][ks], fa[i][ks], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        G256_END_MFMA();
+    }
+    if (wg == 0) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (kDirectOuts<Epi> == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int R = m0 + wm * 64 + i * 16 + (lane & 15), Cc = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+                u32x2_t o[1];
+                epi.pw(acc[i][j], o, 1);
+                if (R < p.M && Cc < p.N) *(u32x2_t*)(epi.dst(0) + (size_t)R * epi.ldo + Cc) = o[0];
+            }
+    }
+}
+#endif   // MAPDIT_GEMM_EXPERIMENTS (256x128 K loop)
+
 // ---- generic fallback for shapes the MFMA tiling does not take (K % 8 != 0, unaligned operands) --------------
 // One thread per (row, 8-column chunk); strides are in elements.  Only used for negligible-FLOP shapes.
 template <class Epi>
@@ -2217,7 +2330,7 @@ struct GemmEnv {
         if (const char* e = getenv("MAPDIT_GEMM_FE")) fast_epi = atoi(e);
         if (const char* e = getenv("MAPDIT_GEMM_TILE_RULE")) old_tile_rule = e[0] == 'o';
         if (const char* e = getenv("MAPDIT_GEMM_TILE")) tile = atoi(e);
-        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : 2;
+        if (const char* e = getenv("MAPDIT_GEMM_PHASES")) phases = atoi(e) == 4 ? 4 : atoi(e) == 1 ? 1 : atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : atoi(e) == 7 ? 7 : atoi(e) == 6 ? 6 : atoi(e) == 8 ? 8 : 2;
         if (const char* e = getenv("MAPDIT_GEMM_BAND")) band = atol(e);
     }
 };
@@ -2233,7 +2346,7 @@ GemmEnv& mapdit_gemm_env_ref() {
 extern "C" void mapdit_gemm_tuning(int tile, int phases, long band) {
     GemmEnv& e = gemm_env();
     e.tile = tile;
-    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : phases == 7 ? 7 : phases == 6 ? 6 : 2;
+    e.phases = phases == 4 ? 4 : phases == 1 ? 1 : phases == 3 ? 3 : phases == 5 ? 5 : phases == 7 ? 7 : phases == 6 ? 6 : phases == 8 ? 8 : 2;
     e.band = band;
 }
 
@@ -2403,6 +2516,17 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
         }
         if (p.phases == 7 || p.phases == 6) p.phases = 2;
 #ifdef MAPDIT_GEMM_EXPERIMENTS
+        if constexpr (kDirectOuts<Epi> == 1) {
+            if (p.phases == 8 && !ktail && split_k == 1 && N % 128 == 0 && M % 256 == 0) {      // round 5: the 256x128 K-loop experiment
+                const int g8 = (M / 256) * (N / 128);
+                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_x128_kernel<OP_ROW, OP_ROW, Epi>), dim3(g8), dim3(512), 0, st, p, epi);
+                else if (layout == MAPDIT_NN) hipLaunchKernelGGL((gemm_x128_kernel<OP_ROW, OP_KMAJ, Epi>), dim3(g8), dim3(512), 0, st, p, epi);
+                else hipLaunchKernelGGL((gemm_x128_kernel<OP_KMAJ, OP_KMAJ, Epi>), dim3(g8), dim3(512), 0, st, p, epi);
+                MD_LAUNCH_CHECK();
+                return MAPDIT_OK;
+            }
+        }
+        if (p.phases == 8) p.phases = 2;                     // (the experiment applies to the plain 16-bit store only)
         if constexpr (!kReduce<Epi>) {
             if (p.phases == 5 && !ktail) {                 // the 4-wave kernel (one wave per SIMD): a rejected experiment, see its comment
                 if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_w4_kernel<OP_ROW, OP_ROW, Epi>), dim3(grid), dim3(256), 0, st, p, epi);
