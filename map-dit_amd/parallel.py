@@ -463,6 +463,9 @@ class ShardedPassReducer(_ReducerBase):
         if self.world > 1:
             opt.shards = self.parts()
             opt.ema_ranges = None
+            # after a step this rank's copy of the OTHER ranks' master rows is stale: anything but the next training forward (which uses
+            # the gathered images) must call gather_state() first - the model refuses an inference forward until then
+            opt.after_step = lambda: setattr(self.model, "_shard_stale", not self.emulate)
             if not self.emulate:
                 opt.status_sync = self._sync_status
 
@@ -663,6 +666,7 @@ class ShardedPassReducer(_ReducerBase):
                 else:
                     dist.all_gather(list(whole.chunk(self.world)), mine.clone(), group=self.group)
                 _verify_gather(whole, mhi - mlo, self.world, before, self.group)
+        self.model._shard_stale = False
         self.model.mark_weights_changed()
 
 

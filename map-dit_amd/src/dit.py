@@ -506,6 +506,9 @@ class DiT(nn.Module):
         if self.training and self.class_dropout_prob > 0:
             y = self.y_embedder.token_drop(y)                                   # label_embedder.py:19-34
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not need_grad and getattr(self, "_shard_stale", False):
+            raise L.MapditError("sharded weight passes (--grad-comm zero1w): this rank holds stale master rows of the other ranks after an "
+                                "optimiser step - call reducer.gather_state() before an inference forward, a checkpoint or an EMA snapshot")
         rt = self._runtime(x.shape[0], train=need_grad)
         with torch.cuda.device(x.device):
             if self.training:

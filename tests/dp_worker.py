@@ -62,7 +62,20 @@ def main():
         loss.backward()
         red.finish()
         opt.step()
+    if mode.startswith("zero1w") and world > 1:              # stale foreign rows: an inference forward must be refused until the state is gathered
+        from mapdit_amd._lib import MapditError
+        m.eval()                                            # (eval: no forced rewrite of the masters - the saved state stays comparable)
+        try:
+            with torch.no_grad():
+                m(x, t, y)
+            raise AssertionError("an inference forward on stale sharded masters was not refused")
+        except MapditError:
+            pass
     red.gather_state()
+    if mode.startswith("zero1w") and world > 1:
+        with torch.no_grad():
+            assert torch.isfinite(m(x, t, y)).all()
+        m.train()
     torch.cuda.synchronize()
     parts = getattr(opt, "shards", None)
     torch.save({"p": m._pflat.cpu(), "g": m._gflat.cpu() * red.grad_scale, "m": opt.exp_avg.cpu(), "v": opt.exp_avg_sq.cpu(),
