@@ -362,6 +362,19 @@ def test_block_fences_order_the_forward_behind_the_host_s_gathers():
     assert torch.equal(again, base) and time.time() - t0 < 5.0
 
 
+def test_rccl_calls_of_the_sharded_pass_path_run_with_one_rank():
+    """What a one-GPU box CAN run of parallel.ShardedPassReducer's RCCL path (tools/rccl_api_probe.py, own process): the grouped in-place
+    reduce_scatter_tensor of a stage, the grouped all_gather_into_tensor on byte views with a side stream turning its completion into an
+    event, the asynchronous all_to_all_single of the 16-bit exchange and the MAX all-reduce of the verdict words - through RCCL and torch's
+    coalescing manager with world size 1 (identities).  More than one rank has never run: no multi-GPU node was available to any round."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_api_probe.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl api probe ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_side_stream_jacobians_give_the_same_bits(tmp_path, monkeypatch):
     """MAPDIT_SIDE_JAC=1 (round 5, opt-in: measured slower): the weight-norm Jacobians on the engine's side stream
     (48-register kernel, ping-pong slab buffers, event hand-over, join at the end of every backward call) must be an ordering change
