@@ -122,7 +122,11 @@ void mapdit_gemm_tuning(int tile, int phases, long band);
  * place (training-mode forced weight norm); then the effective weight w = out_scale * W/(|W row|+eps) is written
  * as bf16 (w_bf16) and/or fp32 (w_f32) — either may be NULL — and inv[row] = 1/(|W row|+eps) (may be NULL).
  * out_scale = 1 for linears (normalize(W)/sqrt(in)), sqrt(cols) for the embedding table (normalize(W)).
+ * MAPDIT_WN_PLAIN (bit 1 of `forced` here and of `accumulate` in the backward forms, mapdit_wn_job_t.flags in the batch forms; README.md:60
+ * --no-use-weight-normalization, PARITY UNPINNED - the snapshot has no such form): the effective weight is out_scale * W / sqrt(cols),
+ * i.e. mp_linear.py:44 without its normalize(), and the backward is dW = out_scale * G / sqrt(cols); bit 0 keeps its meaning.
  * ------------------------------------------------------------------------------------------------------------ */
+enum { MAPDIT_WN_PLAIN = 2 };
 int mapdit_weightnorm_fwd(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_bf16, float* w_f32,
                           float* inv, void* stream);
 /* The same pass for many weights in one launch (the engine's per-step re-imaging of every linear: ~70 weights).  jobs_dev is a
@@ -135,6 +139,7 @@ typedef struct {
     uint16_t* w_bf16; /* may be NULL */
     float* w_f32;     /* may be NULL */
     uint16_t* w_split3; /* may be NULL: [rows][3 cols] two-term bf16 split [hi | lo | hi] of the effective weight (fp32-accurate GEMMs) */
+    int flags;          /* 0 or MAPDIT_WN_PLAIN: this job's weight is imaged (and, in the backward batch, differentiated) without normalize() */
 } mapdit_wn_job_t;
 int mapdit_weightnorm_fwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream);
 /* Autograd of the above: dW = out_scale * (G/(n+eps) - W (G.W)/(n (n+eps)^2)).  G rows have stride ldg; G may be
@@ -390,7 +395,8 @@ int mapdit_ddim_step(const float* model_out, const float* x, const float* noise,
 /* ------------------------------------------------------------------------------------------------------------
  * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).
  * ------------------------------------------------------------------------------------------------------------ */
-enum { MAPDIT_OFF_MP_SILU = 1, MAPDIT_OFF_MP_RESIDUAL = 2, MAPDIT_OFF_MP_POS_ENC = 4, MAPDIT_OFF_MP_EMBEDDING = 8 };
+enum { MAPDIT_OFF_MP_SILU = 1, MAPDIT_OFF_MP_RESIDUAL = 2, MAPDIT_OFF_MP_POS_ENC = 4, MAPDIT_OFF_MP_EMBEDDING = 8,
+       MAPDIT_OFF_WEIGHT_NORM = 16 };
 typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
@@ -409,7 +415,10 @@ typedef struct {
      *   MAPDIT_OFF_MP_RESIDUAL  x + gate * branch instead of mp_sum(x, gate * branch, 0.3) (dit_block.py:35-36)
      *   MAPDIT_OFF_MP_POS_ENC   x_embedder(x) + pos_embed instead of mp_sum(., ., 0.5) (dit.py:84)
      *   MAPDIT_OFF_MP_EMBEDDING nn.Embedding for the labels: plain row gather, no row normalisation, no in-place rewrite
-     *                           (mp_embedding.py:15-24) */
+     *                           (mp_embedding.py:15-24)
+     *   MAPDIT_OFF_WEIGHT_NORM  every MPLinear / MPLinearChunk multiplies by W * gain / sqrt(in_dim): mp_linear.py:44,74 without their
+     *                           normalize() (MAPDIT_WN_PLAIN in the weight passes); the training forward's in-place rewrite
+     *                           (mp_linear.py:38-40, its own flag) is untouched */
     int mp_off;
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is

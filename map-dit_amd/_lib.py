@@ -37,7 +37,7 @@ class ResidModBwd(C.Structure):
 
 class WnJob(C.Structure):          # mapdit_wn_job_t
     _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp),
-                ("w_split3", vp)]
+                ("w_split3", vp), ("flags", ci)]
 
 
 class AdamScalars(C.Structure):    # mapdit_adam_scalars_t
@@ -50,8 +50,10 @@ class Config(C.Structure):
                 ("mp_off", ci), ("loss_scale", cf)]
 
 
-# mapdit_config_t.mp_off bits (mapdit.h MAPDIT_OFF_*): off forms of four README --use-* flags (parity unpinned)
-MP_OFF = {"mp_silu": 1, "mp_residual": 2, "mp_pos_enc": 4, "mp_embedding": 8}
+# mapdit_config_t.mp_off bits (mapdit.h MAPDIT_OFF_*): off forms of the README's --use-* flags (parity unpinned); key = the facade's
+# constructor argument, True (the default) = the snapshot's arithmetic
+MP_OFF = {"mp_silu": 1, "mp_residual": 2, "mp_pos_enc": 4, "mp_embedding": 8, "weight_normalization": 16}
+WN_PLAIN = 2          # mapdit.h MAPDIT_WN_PLAIN
 
 
 # engine precisions (mapdit.h MAPDIT_PREC_*).  "f16": the bf16 engine with IEEE fp16 operands - same speed, 10 mantissa bits

@@ -72,6 +72,7 @@ struct mapdit_engine {
     //  * nn.Embedding: the label table is used as stored (no normalised copy, no rewrite) and its gradient is the scattered rows.
     float ca = 0.f, cb_attn = 0.f, cb_mlp = 0.f, s_act = 1.f, c5 = 0.70710678118654752f;
     bool plain_embedding = false;
+    int wn_plain = 0;          // MAPDIT_WN_PLAIN under MAPDIT_OFF_WEIGHT_NORM: OR-ed into the flags of every linear's weight pass
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
     float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
     int last_N = 0;
@@ -388,7 +389,7 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(loss_scale_ok(c->loss_scale), "engine: loss_scale=%g must be 0 (automatic) or a finite power of two", (double)c->loss_scale);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
-    MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING)) == 0,
+    MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING | MAPDIT_OFF_WEIGHT_NORM)) == 0,
              "engine: unknown bits in mp_off=%d", c->mp_off);
     MD_CHECK(!c->mp_off || c->precision != MAPDIT_PREC_BF16X3, "engine: the --use-* off forms are not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
@@ -437,6 +438,7 @@ void init_dims(mapdit_engine* e) {
     e->cb_mlp = e->cb_attn * e->s_act;                                        // the MLP branch enters only as cb * gate * fc2(act)
     e->c5 = (c.mp_off & MAPDIT_OFF_MP_POS_ENC) ? 1.f : 0.70710678118654752f;
     e->plain_embedding = (c.mp_off & MAPDIT_OFF_MP_EMBEDDING) != 0;
+    e->wn_plain = (c.mp_off & MAPDIT_OFF_WEIGHT_NORM) ? MAPDIT_WN_PLAIN : 0;
     {   // 16-bit engines: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream, for A/B runs; =f: fp16 engine only)
         const char* v = getenv("MAPDIT_DX16");
         e->dx16 = c.precision != MAPDIT_PREC_BF16X3 && !(v && v[0] == '0') && (e->f16 || !(v && v[0] == 'f'));
@@ -651,7 +653,7 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
         TRY(g_claim(e, 0, st));
         TRY(gemm16(e, MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
         if (e->grads[pidx])
-            TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, st));
+            TRY(mapdit_weightnorm_bwd(e->params[pidx], e->G, w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, e->wn_plain, st));
         return MAPDIT_OK;
     }
     // the GEMM on the caller's stream into the buffer whose previous Jacobian has finished, the Jacobian behind it on the side stream
@@ -662,7 +664,7 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
     TRY(gemm16(e, MAPDIT_TN, w.rows, w.cols, K, dy, ld_dy, x, ld_x, ep, st));
     HIP_TRY(hipEventRecord(e->ev_gemm[b], (hipStream_t)st), "linear_dw: event record");
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_gemm[b], 0), "linear_dw: side stream wait");
-    TRY(mapdit_weightnorm_bwd_slim(e->params[pidx], e->Gbuf[b], w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, 0, e->side));
+    TRY(mapdit_weightnorm_bwd_slim(e->params[pidx], e->Gbuf[b], w.cols, split, slab, e->grads[pidx], w.rows, w.cols, 1.f, e->wn_plain, e->side));
     HIP_TRY(hipEventRecord(e->ev_jac[b], e->side), "linear_dw: event record (side)");
     e->jac_pending[b] = true;
     return MAPDIT_OK;
@@ -824,10 +826,11 @@ static void build_wn_jobs(mapdit_engine* e) {
     e->wn_jobs.clear();
     e->wn_blocks = 0;
     e->wn_table_ready = false;
-    auto job = [&](float* W, int rows, int cols, float out_scale, bf16_t* wb, float* wf, bf16_t* w3 = nullptr) {
+    auto job = [&](float* W, int rows, int cols, float out_scale, bf16_t* wb, float* wf, bf16_t* w3 = nullptr, int flags = -1) {
         mapdit_wn_job_t j;
         j.W = W; j.rows = rows; j.cols = cols; j.out_scale = out_scale; j.first_block = e->wn_blocks; j.w_bf16 = wb; j.w_f32 = wf;
         j.w_split3 = w3;
+        j.flags = flags < 0 ? e->wn_plain : flags;      // (every linear; the label table's normalisation is its own flag)
         e->wn_jobs.push_back(j);
         e->wn_blocks += (rows + 3) / 4;
     };
@@ -845,7 +848,7 @@ static void build_wn_jobs(mapdit_engine* e) {
             }
         job(e->params[MAPDIT_P_X_EMB], e->D, e->P1, 1.f, nullptr, e->wx_eff);
         if (!e->plain_embedding)            // (nn.Embedding: the stored table is what the forward gathers from)
-            job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff);
+            job(e->params[MAPDIT_P_Y_EMB], e->cfg.table_rows, e->D, sqrtf((float)e->D), nullptr, e->table_eff, nullptr, 0);
     }
     // the Jacobians of the owned rows of every sharded weight (in place in the gradient buffers)
     e->jac_jobs.clear();
@@ -858,7 +861,7 @@ static void build_wn_jobs(mapdit_engine* e) {
             const size_t c = (size_t)e->wimg[pi].cols;
             mapdit_wn_job_t j;
             j.W = e->params[pi] + lo * c; j.rows = per; j.cols = (int)c; j.out_scale = 1.f; j.first_block = e->jac_blocks;
-            j.w_bf16 = nullptr; j.w_f32 = e->grads[pi] + lo * c; j.w_split3 = nullptr;
+            j.w_bf16 = nullptr; j.w_f32 = e->grads[pi] + lo * c; j.w_split3 = nullptr; j.flags = e->wn_plain;
             e->jac_jobs.push_back(j);
             e->jac_blocks += (per + 3) / 4;
         }
@@ -962,9 +965,9 @@ extern "C" int mapdit_engine_prepare_weights(mapdit_engine_t* e, int forced, voi
                 TRY(mapdit_split3_stack(e->px.wtmp, w.cols, e->imgT[i], w.cols, w.rows, w.cols, MAPDIT_SPLIT_B, MAPDIT_SPLIT_OP_NONE, st));
             continue;
         }
-        TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced, 1.f, w.img, nullptr, nullptr, st));
+        TRY(mapdit_weightnorm_fwd(e->params[i], w.rows, w.cols, forced | e->wn_plain, 1.f, w.img, nullptr, nullptr, st));
     }
-    TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_X_EMB], e->D, e->P1, forced, 1.f, nullptr, e->wx_eff, nullptr, st));
+    TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_X_EMB], e->D, e->P1, forced | e->wn_plain, 1.f, nullptr, e->wx_eff, nullptr, st));
     TRY(mapdit_weightnorm_fwd(e->params[MAPDIT_P_Y_EMB], c.table_rows, e->D, forced, sqrtf((float)e->D), nullptr, e->table_eff,
                               nullptr, st));
     return MAPDIT_OK;
@@ -1514,7 +1517,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         ep.split_k = pick_split_k(D, e->ldp, M, e->G_cap / slab);
         ep.slab_stride = slab;
         TRY(gemm16(e, MAPDIT_TN, D, e->ldp, M, e->dx0_bf, D, e->patches, e->ldp, ep, st));
-        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, 0, st));
+        TRY(mapdit_weightnorm_bwd(e->params[MAPDIT_P_X_EMB], e->G, e->ldp, ep.split_k, slab, G(MAPDIT_P_X_EMB), D, e->P1, 1.f, e->wn_plain, st));
     }
     // ---- conditioning path ------------------------------------------------------------------------------------------
     TRY(DT_FN(e, mapdit_cond_combine_bwd)(e->c, e->dcs, e->dcd, e->y_copy, e->dtemb_bf, e->dtable, N, D, c.table_rows, st));

@@ -15,6 +15,10 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
                                                    bf16_t* __restrict__ w3 = nullptr) {
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    // bit 1 of `forced` (MAPDIT_WN_PLAIN; README.md:60 --no-use-weight-normalization, parity unpinned): the effective weight is
+    // out_scale * W / sqrt(cols) - mp_linear.py:44 without its normalize(); the in-place rewrite of bit 0 stays what it is
+    const bool plain = (forced & MAPDIT_WN_PLAIN) != 0;
+    forced &= 1;
     float* w = W + (size_t)row * cols;
     float ss = 0.f;
     const bool vec = (cols & 3) == 0;
@@ -34,7 +38,7 @@ __device__ __forceinline__ void weightnorm_fwd_row(float* __restrict__ W, int ro
         f = sqrtf((float)cols) / (n + NORM_EPS);
         n = n * f;                       // norm of the rewritten row
     }
-    const float s = 1.f / (n + NORM_EPS);
+    const float s = plain ? 1.f / sqrtf((float)cols) : 1.f / (n + NORM_EPS);
     const float e = f * s * out_scale;   // w_eff = W_old * f * s * out_scale
     if (inv && lane == 0) inv[row] = s;
     if (vec) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_batch_kernel(const mapdit_
         if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
     }
     const mapdit_wn_job_t j = jobs[lo];
-    weightnorm_fwd_row(j.W, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, forced, j.out_scale, j.w_bf16, j.w_f32,
+    weightnorm_fwd_row(j.W, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, (forced & 1) | (j.flags & MAPDIT_WN_PLAIN), j.out_scale, j.w_bf16, j.w_f32,
                        nullptr, j.w_split3);
 }
 
@@ -167,8 +171,11 @@ __device__ __forceinline__ void weightnorm_bwd_row(const float* __restrict__ W, 
     ss = wave_sum(ss);
     gw = wave_sum(gw);
     const float n = sqrtf(ss);
-    const float a1 = out_scale / (n + NORM_EPS);
-    const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
+    // bit 1 of `accumulate` (MAPDIT_WN_PLAIN): w = out_scale * W / sqrt(cols), so dW = out_scale * G / sqrt(cols) and nothing is projected out
+    const bool plain = (accumulate & MAPDIT_WN_PLAIN) != 0;
+    accumulate &= 1;
+    const float a1 = plain ? out_scale / sqrtf((float)cols) : out_scale / (n + NORM_EPS);
+    const float a2 = plain ? 0.f : out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
 #ifdef MAPDIT_WN_DEBUG
     if (g_wn_dbg && lane == 0) { float* q = g_wn_dbg + (size_t)row * 132; q[0] = ss; q[1] = gw; q[2] = a1; q[3] = a2; }
 #endif
@@ -210,7 +217,8 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_batch_kernel(const mapdit_
         if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
     }
     const mapdit_wn_job_t j = jobs[lo];
-    weightnorm_bwd_row<true>(j.W, j.w_f32, j.cols, 1, 0, j.w_f32, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, j.out_scale, 0);
+    weightnorm_bwd_row<true>(j.W, j.w_f32, j.cols, 1, 0, j.w_f32, (blk - j.first_block) * 4 + (threadIdx.x >> 6), j.rows, j.cols, j.out_scale,
+                             j.flags & MAPDIT_WN_PLAIN);
 }
 
 // The same pass for a SIDE STREAM (round 5): the engine runs the Jacobian of weight i beside the weight-gradient GEMM of weight i + 1.
@@ -258,8 +266,10 @@ void weightnorm_bwd_slim_kernel(const float* __restrict__ W, float* __restrict__
     ss = wave_sum(ss);
     gw = wave_sum(gw);
     const float n = sqrtf(ss);
-    const float a1 = out_scale / (n + NORM_EPS);
-    const float a2 = out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
+    const bool plain = (accumulate & MAPDIT_WN_PLAIN) != 0;      // (as weightnorm_bwd_row)
+    accumulate &= 1;
+    const float a1 = plain ? out_scale / sqrtf((float)cols) : out_scale / (n + NORM_EPS);
+    const float a2 = plain ? 0.f : out_scale * gw / (fmaxf(n, 1e-30f) * (n + NORM_EPS) * (n + NORM_EPS));
 #pragma unroll 1
     for (int c = lane * 4; c < cols; c += 256) {
         const float4 b = *(const float4*)(g + c), a = *(const float4*)(w + c);

@@ -279,7 +279,8 @@ class DiT(nn.Module):
     def __init__(self, depth: int, hidden_size: int, patch_size: int, input_size: int = 32, in_channels: int = 3,
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
                  learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True,
-                 mp_silu: bool = True, mp_residual: bool = True, mp_pos_enc: bool = True, mp_embedding: bool = True):
+                 mp_silu: bool = True, mp_residual: bool = True, mp_pos_enc: bool = True, mp_embedding: bool = True,
+                 weight_normalization: bool = True):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -306,6 +307,9 @@ class DiT(nn.Module):
         # nn.Linear, plain SDPA) name layers with parameters / kernels the snapshot does not have and stay refused (train.py).
         self.mp_silu, self.mp_residual = bool(mp_silu), bool(mp_residual)
         self.mp_pos_enc, self.mp_embedding = bool(mp_pos_enc), bool(mp_embedding)
+        # README.md:60 --use-weight-normalization off (unpinned like the four above): MPLinear / MPLinearChunk multiply by
+        # W * gain / sqrt(in_dim), i.e. mp_linear.py:44,74 without their normalize(); the weight passes run with MAPDIT_WN_PLAIN
+        self.weight_normalization = bool(weight_normalization)
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
@@ -558,7 +562,8 @@ class DiT(nn.Module):
                   in_channels=self.in_channels, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
                   class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
                   rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization,
-                  mp_silu=self.mp_silu, mp_residual=self.mp_residual, mp_pos_enc=self.mp_pos_enc, mp_embedding=self.mp_embedding)
+                  mp_silu=self.mp_silu, mp_residual=self.mp_residual, mp_pos_enc=self.mp_pos_enc, mp_embedding=self.mp_embedding,
+                  weight_normalization=self.weight_normalization)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

@@ -52,6 +52,9 @@ class DiTConfig:
     mp_residual: bool = True      # False: x + gate * branch  instead of  mp_sum(x, gate * branch, 0.3)
     mp_pos_enc: bool = True       # False: x_embedder(x) + pos_embed with the raw sin-cos table instead of mp_sum(.., normalize(table), 0.5)
     mp_embedding: bool = True     # False: nn.Embedding (plain row gather, no row normalisation) for the class labels
+    # README.md:60 --use-weight-normalization off (same status: unpinned): MPLinear / MPLinearChunk multiply by W * gain / sqrt(in_dim) -
+    # mp_linear.py:44,74 without their normalize(); the training forward's in-place rewrite (mp_linear.py:38-40) is its own flag and stays
+    weight_normalization: bool = True
 
     @property
     def grid(self) -> int:
@@ -78,7 +81,7 @@ class DiTConfig:
         d = asdict(self)
         if not d["rotation_modulation"]:
             del d["rotation_modulation"]
-        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding"):      # (likewise: only when switched off)
+        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization"):      # (likewise: only when switched off)
             if d[k]:
                 del d[k]
         return d
@@ -242,14 +245,15 @@ def _layer_of(key: str) -> str:
     return "other"
 
 
-def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_ident) -> Tensor:
+def mp_linear(x: Tensor, sd: Dict[str, Tensor], key: str, train: bool, rnd=_ident, wn: bool = True) -> Tensor:
     """MPLinear / MPLinearChunk forward (src/basic/mp_linear.py:31-46, 67-75), gain == 1.
-    Training forward first overwrites the stored weight with its normalised value (F9)."""
+    Training forward first overwrites the stored weight with its normalised value (F9).
+    ``wn=False`` (README.md:60 off form; unpinned): line 44 / 74 without normalize() - the stored weight over sqrt(in_dim)."""
     w = sd[key]
     if train:
         with torch.no_grad():
             w.copy_(normalize(w))
-    w_eff = normalize(w) / math.sqrt(w.shape[1])
+    w_eff = (normalize(w) if wn else w) / math.sqrt(w.shape[1])
     layer = _layer_of(key)
     return torch.nn.functional.linear(_at(rnd, "x:" + layer)(x), _at(rnd, "w:" + layer)(w_eff))
 
@@ -365,7 +369,7 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
     """src/layers/attention.py:29-51: cosine attention, logits = sqrt(hd)*cos(q,k)."""
     B, T, D = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
-    qkv = mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd)
+    qkv = mp_linear(x, sd, prefix + "qkv_proj.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
     # engine: head_dim 64 with 64/128/256 tokens normalises q, k from the fp32 accumulators inside the QKV GEMM's epilogue
     # (one rounding, after the normalisation); the generic attention path stores qkv in bf16 first
     if not (hd == 64 and T in (64, 128, 256)):
@@ -386,14 +390,14 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
         out = (_at(rnd, "p")(p) @ v) / p.sum(-1, keepdim=True)
     out = out.transpose(1, 2).reshape(B, T, D)
     _rec(trace, prefix + "o", _at(rnd, "x:proj")(out))
-    return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd)
+    return mp_linear(out, sd, prefix + "out_proj.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
 
 
-def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None, act=mp_silu) -> Tensor:
+def mlp(x: Tensor, sd, prefix: str, train: bool, rnd=_ident, trace=None, act=mp_silu, wn: bool = True) -> Tensor:
     """src/layers/mlp.py:16-25."""
-    h = act(mp_linear(x, sd, prefix + "net.0.weight", train, rnd))
+    h = act(mp_linear(x, sd, prefix + "net.0.weight", train, rnd, wn=wn))
     _rec(trace, prefix + "hact", _at(rnd, "x:fc2")(h))
-    return mp_linear(h, sd, prefix + "net.2.weight", train, rnd)
+    return mp_linear(h, sd, prefix + "net.2.weight", train, rnd, wn=wn)
 
 
 class _WithFull:
@@ -406,7 +410,7 @@ class _WithFull:
 def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
-    mod = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd)
+    mod = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
     _rec(trace, p + "mod", mod)
     if cfg.rotation_modulation:             # (theta, scale, gate) x 2 with D/2-wide angle chunks; see modulate_rot
         D = x.shape[-1]
@@ -428,15 +432,15 @@ def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd
     _rec(trace, p + "xmid", x)
     xm2 = mod_m(x_full)
     _rec(trace, p + "xm2", _at(rnd, "x:fc1")(xm2))
-    x_full = residual_sum(cfg, x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace, act=act_fn(cfg)))
+    x_full = residual_sum(cfg, x, g_m.unsqueeze(1) * mlp(xm2, sd, p + "mlp.", train, rnd, trace, act=act_fn(cfg), wn=getattr(cfg, "weight_normalization", True)))
     x = _at(rnd, "res")(x_full)
     _rec(trace, p + "xout", x)
     return _WithFull(x, x_full) if x is not x_full else x
 
 
-def mp_scale(c: Tensor, sd, prefix: str, train: bool, rnd=_ident) -> Tensor:
+def mp_scale(c: Tensor, sd, prefix: str, train: bool, rnd=_ident, wn: bool = True) -> Tensor:
     """src/blocks/final_layer.py:20-22."""
-    angle = torch.matmul(mp_linear(c, sd, prefix + "linear.weight", train, rnd), sd[prefix + "reference"]) / math.sqrt(SCALE_DIM)
+    angle = torch.matmul(mp_linear(c, sd, prefix + "linear.weight", train, rnd, wn=wn), sd[prefix + "reference"]) / math.sqrt(SCALE_DIM)
     return torch.sigmoid(angle)
 
 
@@ -445,16 +449,16 @@ def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_iden
     (modulation, linear, mean_scale, sigma_scale) — it matters only for forced-WN side effects,
     which are per-weight and order independent."""
     p = "final_layer."
-    shift, scale = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd).chunk(2, dim=-1)
+    shift, scale = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True)).chunk(2, dim=-1)
     x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
     _rec(trace, p + "xmod", _at(rnd, "x:flin")(x_mod))
-    out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd)
+    out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
     _rec(trace, p + "lin", out)
     if cfg.learn_sigma:
         mean, sigma = out.chunk(2, dim=-1)
-        return (mean * mp_scale(c, sd, p + "mean_scale.", train, rnd).view(-1, 1, 1),
-                sigma * mp_scale(c, sd, p + "sigma_scale.", train, rnd).view(-1, 1, 1))
-    return out * mp_scale(c, sd, p + "mean_scale.", train, rnd)
+        return (mean * mp_scale(c, sd, p + "mean_scale.", train, rnd, wn=getattr(cfg, "weight_normalization", True)).view(-1, 1, 1),
+                sigma * mp_scale(c, sd, p + "sigma_scale.", train, rnd, wn=getattr(cfg, "weight_normalization", True)).view(-1, 1, 1))
+    return out * mp_scale(c, sd, p + "mean_scale.", train, rnd, wn=getattr(cfg, "weight_normalization", True))
 
 
 def effective_labels(y: Tensor, cfg: DiTConfig, train: bool, drop: Optional[Tensor]) -> Tensor:
@@ -475,15 +479,15 @@ def dit_forward(sd: Dict[str, Tensor], cfg: DiTConfig, x: Tensor, t: Tensor, y: 
     h = patchify(x.to(dt), cfg.patch_size)
     h = torch.cat([h, torch.ones_like(h[:, :, :1])], dim=-1)
     if cfg.mp_pos_enc:
-        h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train), sd["pos_embed"], EMBED_T)      # fp32 kernel in the engine
+        h = mp_sum(mp_linear(h, sd, "x_embedder.weight", train, wn=getattr(cfg, "weight_normalization", True)), sd["pos_embed"], EMBED_T)      # fp32 kernel in the engine
     else:                                                        # README.md:65 off form (unpinned): upstream DiT's plain addition
-        h = mp_linear(h, sd, "x_embedder.weight", train) + sd["pos_embed"]
+        h = mp_linear(h, sd, "x_embedder.weight", train, wn=getattr(cfg, "weight_normalization", True)) + sd["pos_embed"]
 
     four = torch.cos(torch.outer(t.to(dt), sd["t_embedder.embedding.scale"]) + sd["t_embedder.embedding.shift"])
     four = math.sqrt(2) * four                                   # timestep_embedder.py:18-21
     _rec(trace, "x0", h); _rec(trace, "four", _at(rnd, "x:t0")(four))
-    temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd)
-    temb = mp_linear(act_fn(cfg)(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd)
+    temb = mp_linear(four, sd, "t_embedder.mlp.net.0.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
+    temb = mp_linear(act_fn(cfg)(temb), sd, "t_embedder.mlp.net.2.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
     yemb = mp_embedding(effective_labels(y, cfg, train, drop), sd, "y_embedder.embedding.weight", train, mp=cfg.mp_embedding)
     c = mp_sum(temb, yemb, EMBED_T)
     _rec(trace, "temb", temb); _rec(trace, "c", c)

@@ -387,6 +387,48 @@ def test_weightnorm(L, rows, cols, forced):
     assert rel_err(dW.cpu().numpy(), Wr.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("rows,cols", [(384, 128), (16, 17), (768, 3072)])
+@pytest.mark.parametrize("forced", [0, 1])
+def test_weightnorm_plain_flag(L, rows, cols, forced):
+    """MAPDIT_WN_PLAIN (bit 1 of `forced` / `accumulate` / job.flags; README.md:60 off form, parity unpinned): image = W / sqrt(cols) of the (optionally
+    rewritten) master, backward dW = G / sqrt(cols) (+ the accumulate bit), slim and batch forms the same bits as the plain launch."""
+    import numpy as np
+    from oracle.dit_oracle import normalize
+    PLAIN = L.WN_PLAIN
+    g = torch.Generator().manual_seed(6)
+    W = torch.randn(rows, cols, generator=g) * 1.7
+    Wd = W.to(DEV).clone()
+    wf = torch.zeros(rows, cols, device=DEV)
+    L.lib().weightnorm_fwd(p(Wd), rows, cols, forced | PLAIN, 1.0, None, p(wf), None, st())
+    torch.cuda.synchronize()
+    Wn = normalize(W) if forced else W
+    assert rel_err(Wd.cpu().numpy(), Wn.numpy()) < 1e-6
+    assert rel_err(wf.cpu().numpy(), (Wn / math.sqrt(cols)).numpy()) < 1e-6
+    G = torch.randn(3, rows, cols, generator=g)               # three split-K slabs
+    want = G.sum(0) / math.sqrt(cols)
+    outs = []
+    for fn in ("weightnorm_bwd", "weightnorm_bwd_slim"):
+        if fn.endswith("slim") and cols % 4:
+            continue
+        Gd = G.to(DEV).contiguous()
+        dW = torch.ones(rows, cols, device=DEV)
+        getattr(L.lib(), fn)(p(Wd), p(Gd), cols, 3, rows * cols, p(dW), rows, cols, 1.0, PLAIN | 1, st())
+        torch.cuda.synchronize()
+        assert rel_err(dW.cpu().numpy(), (want + 1.0).numpy()) < 1e-6, fn
+        outs.append(dW.cpu())
+    assert len(outs) < 2 or torch.equal(outs[0], outs[1])
+    if cols % 4 == 0:                                         # the in-place batch form on one summed slab
+        Gs = G.sum(0).to(DEV).contiguous()
+        ref = torch.zeros(rows, cols, device=DEV)
+        L.lib().weightnorm_bwd(p(Wd), p(Gs.clone()), cols, 1, 0, p(ref), rows, cols, 1.0, PLAIN, st())
+        jobs = (L.WnJob * 1)()
+        jobs[0] = L.WnJob(W=p(Wd), rows=rows, cols=cols, out_scale=1.0, first_block=0, w_bf16=None, w_f32=p(Gs), flags=PLAIN)
+        raw = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).to(DEV)
+        L.lib().weightnorm_bwd_batch(p(raw), 1, (rows + 3) // 4, st())
+        torch.cuda.synchronize()
+        assert torch.equal(Gs, ref)
+
+
 def test_weightnorm_batch_equals_single_launches(L):
     """mapdit_weightnorm_fwd_batch (one launch for every weight, device job table) against one launch per weight: bit-equal
     rewritten masters and images, for ragged row counts (rows % 4 != 0) and both output kinds."""

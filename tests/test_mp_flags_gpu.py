@@ -19,7 +19,7 @@ from conftest import rel_err, sub
 from oracle import dit_oracle as O
 
 TINY = dict(depth=2, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
-FLAGS = ["mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding"]
+FLAGS = ["mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization"]
 
 
 # ---- CPU: what each off form IS (the restatement's own invariants) -----------------------------------------------------------------------
@@ -49,6 +49,12 @@ def test_off_forms_of_the_restatement():
     assert torch.allclose(O.residual_sum(on, a, b), (0.7 * a + 0.3 * b) / math.sqrt(0.58), rtol=1e-6, atol=1e-6)
     tab = {"w": torch.randn(11, 16)}
     assert torch.equal(O.mp_embedding(torch.tensor([3, 3, 10]), tab, "w", train=True, mp=False), tab["w"][[3, 3, 10]])
+    # weight normalisation off: the stored weight over sqrt(in_dim); equal to the on form exactly when the rows are already normalised
+    lin = {"w": torch.randn(6, 16) * 1.7}
+    xin = torch.randn(5, 16)
+    assert torch.allclose(O.mp_linear(xin, lin, "w", train=False, wn=False), xin @ lin["w"].T / 4.0, rtol=1e-6, atol=1e-6)
+    nrm = {"w": O.normalize(lin["w"])}
+    assert torch.allclose(O.mp_linear(xin, nrm, "w", False, wn=False), O.mp_linear(xin, lin, "w", False), rtol=1e-4, atol=1e-5)
     raw = O.init_state_dict(O.DiTConfig(**TINY, mp_pos_enc=False), seed=5)["pos_embed"]
     assert float(raw.abs().max()) <= 1.0 and not torch.allclose(raw, sd["pos_embed"])        # sines and cosines, not normalised rows
 
@@ -56,10 +62,13 @@ def test_off_forms_of_the_restatement():
 def test_train_cli_accepts_the_built_off_forms_and_refuses_the_rest():
     from mapdit_amd import train
     p = train.build_parser()
-    a = p.parse_args(["--synthetic", "--results-dir", "/tmp/x", "--no-use-mp-silu", "--no-use-mp-residual", "--no-use-mp-pos-enc", "--no-use-mp-embedding"])
-    assert (a.use_mp_silu, a.use_mp_residual, a.use_mp_pos_enc, a.use_mp_embedding) == (False,) * 4 and a.use_cosine_attention
-    assert set(train.BUILT_OFF_FORMS) == {"mp-silu", "mp-residual", "mp-pos-enc", "mp-embedding"}
-    for flag in ("cosine-attention", "weight-normalization", "no-layernorm"):
+    a = p.parse_args(["--synthetic", "--results-dir", "/tmp/x", "--no-use-mp-silu", "--no-use-mp-residual", "--no-use-mp-pos-enc", "--no-use-mp-embedding",
+                      "--no-use-weight-normalization"])
+    assert (a.use_mp_silu, a.use_mp_residual, a.use_mp_pos_enc, a.use_mp_embedding, a.use_weight_normalization) == (False,) * 5 and a.use_cosine_attention
+    assert set(train.BUILT_OFF_FORMS) == {"mp-silu", "mp-residual", "mp-pos-enc", "mp-embedding", "weight-normalization"}
+    a.in_channels, a.input_size = 4, 32                # (main() fills these in from the data set / --synthetic)
+    assert train.get_model(a).weight_normalization is False
+    for flag in ("cosine-attention", "no-layernorm"):
         with pytest.raises(NotImplementedError):
             train.main(["--synthetic", "--results-dir", "/tmp/x", f"--no-use-{flag}", "--num-steps", "1"])
 
@@ -87,7 +96,7 @@ LIMITS = {  # logits, loss, gradient tensor (>= 64 entries), scalar gains (of th
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-@pytest.mark.parametrize("off", [("mp_silu",), ("mp_residual",), ("mp_pos_enc",), ("mp_embedding",), tuple(FLAGS)])
+@pytest.mark.parametrize("off", [("mp_silu",), ("mp_residual",), ("mp_pos_enc",), ("mp_embedding",), ("weight_normalization",), tuple(FLAGS)])
 def test_engine_off_forms_match_the_restatement(off, precision):
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.dit import DiT
@@ -96,6 +105,11 @@ def test_engine_off_forms_match_the_restatement(off, precision):
     dev = "cuda"
     cfg = O.DiTConfig(**TINY, **{f: False for f in off})
     sd = O.init_state_dict(cfg, seed=11, gains=0.35, perturb_reference=0.3)
+    if "weight_normalization" in off:                 # rows of other lengths than sqrt(in_dim): the off form is then another network (eval reads them as stored)
+        gs = torch.Generator().manual_seed(13)
+        for k in sd:
+            if k.endswith(".weight") and "y_embedder" not in k:
+                sd[k] = sd[k] * (0.6 + 0.8 * torch.rand(sd[k].shape[0], 1, generator=gs))
     g = torch.Generator().manual_seed(12)
     n = 4
     x, t, y = torch.randn(n, 4, 16, 16, generator=g), torch.randint(0, 1000, (n,), generator=g), torch.randint(0, 10, (n,), generator=g)
