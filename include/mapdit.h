@@ -316,6 +316,15 @@ int mapdit_attn_cos_fwd_rawqk(const uint16_t* q, const uint16_t* k, const uint16
  * head_dim-64 models do through MAPDIT_EPI_QKV_HEADS (reference attention.py:37-47 and its autograd). */
 int mapdit_attn_cos_fwd_rawqk_save(uint16_t* q, uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, float* scales, int B, int T,
                                    int H, int head_dim, void* stream);
+/* Plain scaled-dot-product attention (abi 5; README.md:58 --no-use-cosine-attention, PARITY UNPINNED: the snapshot always normalises q, k):
+ * o = softmax(q k^T / sqrt(head_dim)) v on q, k as they are, the row maximum subtracted inside the softmax (the logits of unnormalised rows
+ * are unbounded); lse = log sum exp of the scaled logits.  Same layouts and shape dispatch as mapdit_attn_cos_fwd, T <= 256.  Its backward IS
+ * mapdit_attn_cos_bwd (which recomputes exp(s - lse) and knows nothing of the normalisation), followed by mapdit_heads_merge_bwd. */
+int mapdit_attn_sdpa_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                         int head_dim, void* stream);
+/* dqn, dkn, dv [B*H][T][head_dim] -> dqkv [B*T, 3*H*head_dim]: the head merge alone (no normalisation Jacobian); head_dim % 8 == 0 */
+int mapdit_heads_merge_bwd(const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv, int B, int T, int H, int head_dim, uint16_t* dqkv,
+                           void* stream);
 /* backward; also writes delta [B*H][T] = rowsum(dO * O) */
 int mapdit_attn_cos_bwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                         const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
@@ -396,7 +405,7 @@ int mapdit_ddim_step(const float* model_out, const float* x, const float* noise,
  * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).
  * ------------------------------------------------------------------------------------------------------------ */
 enum { MAPDIT_OFF_MP_SILU = 1, MAPDIT_OFF_MP_RESIDUAL = 2, MAPDIT_OFF_MP_POS_ENC = 4, MAPDIT_OFF_MP_EMBEDDING = 8,
-       MAPDIT_OFF_WEIGHT_NORM = 16 };
+       MAPDIT_OFF_WEIGHT_NORM = 16, MAPDIT_OFF_COSINE_ATTN = 32 };
 typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
@@ -418,7 +427,10 @@ typedef struct {
      *                           (mp_embedding.py:15-24)
      *   MAPDIT_OFF_WEIGHT_NORM  every MPLinear / MPLinearChunk multiplies by W * gain / sqrt(in_dim): mp_linear.py:44,74 without their
      *                           normalize() (MAPDIT_WN_PLAIN in the weight passes); the training forward's in-place rewrite
-     *                           (mp_linear.py:38-40, its own flag) is untouched */
+     *                           (mp_linear.py:38-40, its own flag) is untouched
+     *   MAPDIT_OFF_COSINE_ATTN  attention.py:42-43 dropped: q, k enter F.scaled_dot_product_attention as the projection gave them (scale
+     *                           1/sqrt(head_dim) unchanged) - mapdit_attn_sdpa_fwd, the unfused backward, mapdit_heads_merge_bwd; <= 256
+     *                           tokens, head_dim % 8 == 0 */
     int mp_off;
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
@@ -543,6 +555,10 @@ int mapdit_attn_cos_fwd_rawqk_f16(const uint16_t* q, const uint16_t* k, const ui
                                   int head_dim, void* stream);
 int mapdit_attn_cos_fwd_rawqk_save_f16(uint16_t* q, uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, float* scales, int B, int T,
                                        int H, int head_dim, void* stream);
+int mapdit_attn_sdpa_fwd_f16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                             int head_dim, void* stream);
+int mapdit_heads_merge_bwd_f16(const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv, int B, int T, int H, int head_dim, uint16_t* dqkv,
+                               void* stream);
 int mapdit_attn_cos_bwd_f16(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, const uint16_t* dO, const uint16_t* O,
                             const float* lse, float* delta, uint16_t* dqn, uint16_t* dkn, uint16_t* dv, int B, int T, int H,
                             int head_dim, void* stream);

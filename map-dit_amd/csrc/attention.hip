@@ -190,7 +190,9 @@ template <int T> struct Geo {
 };
 
 // ---- forward -----------------------------------------------------------------------------------------------
-template <int T, bool MULTI>
+// MAXSUB (mapdit_attn_sdpa_fwd; q, k NOT normalised - README.md:58 --no-use-cosine-attention, parity unpinned; single key tile only): a first
+// sweep of the S products finds each query's largest logit, the second subtracts it; lse = max + log(sum).
+template <int T, bool MULTI, bool MAXSUB = false>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                               const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                               float* __restrict__ lse, int H, float scale, int Ttot) {
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     // 32-key tile goes S -> exp -> P V straight from registers; nothing but the 32x64 output tile and the row sum is carried -
     // also across the key tiles of a head with more than 256 tokens (no rescaling between tiles: there is no maximum to track)
     f32x16_t oa0 = {}, oa1 = {};                       // (named, not an array: carried across the tile loop an array went to scratch)
-    float lsum = 0.f;
+    float lsum = 0.f, mrow = 0.f;
     for (int kt0 = 0; kt0 < ntiles; ++kt0) {           // (the staging registers live inside one iteration: carried across the
     if (MULTI && kt0) __syncthreads();                 //  loop or a barrier, hipcc parked them in scratch memory)
     if (MULTI) {                                       // (barrier: every wave is done with the previous tile's images)
@@ -231,13 +233,25 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
         sv1_.store(vs_, nullptr, tid);
     }
     __syncthreads();
+    if (MAXSUB && !MULTI) {                            // the lane's query is column r of every S^T tile; its keys are split over lanes r, r + 32
+        float mx = -3.0e38f;
+        for (int kt = 0; kt < G::NT; ++kt) {
+            f32x16_t a = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, a[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mrow = mx * scale;
+    }
 #pragma unroll 2
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a = MFMA32(frag_rows(ks_, 32 * kt, ks, lane), qf[ks], a);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(MAXSUB ? a[i] * scale - mrow : a[i] * scale); lsum += a[i]; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa = pack8(a, 8 * s2);
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn_fwd_kernel(const bf16_t* __r
     }
     __syncthreads();                                   // K / V images are dead: reuse them as store buffers
     store_wave_tile(smem + wave * WT_BYTES, c0, c1, o + ((size_t)b * Ttot + q0) * D + hh * 64, D, lane);
-    if (lane < 32) lse[bh * Ttot + q0 + r] = __logf(lsum);
+    if (lane < 32) lse[bh * Ttot + q0 + r] = mrow + __logf(lsum);
 }
 
 // ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
@@ -1105,6 +1119,26 @@ extern "C" int MD_SYM(attn_cos_fwd)(const uint16_t* qn, const uint16_t* kn, cons
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(T, hipLaunchKernelGGL((attn_fwd_kernel<TT, MT>), dim3(T / TT, B * H), dim3(Geo<TT>::NTH), 0, st,
                                         qn, kn, v, o, lse, H, scale, T));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+// Plain scaled-dot-product attention (F.scaled_dot_product_attention of attention.py:45 on q, k that were NOT normalised: README.md:58
+// --no-use-cosine-attention; parity unpinned): same layouts and scale as mapdit_attn_cos_fwd, the softmax with its row maximum taken out.
+int MD_SYM(attn72_fwd_max)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, void*);
+int MD_SYM(attn_generic_fwd_max)(const uint16_t*, const uint16_t*, const uint16_t*, uint16_t*, float*, int, int, int, int, void*);
+extern "C" int MD_SYM(attn_sdpa_fwd)(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H,
+                                    int head_dim, void* stream) {
+    MD_CHECK(q && k && v && o && lse, "attn_sdpa_fwd: null argument");
+    if (mfma72_shape(T, head_dim)) return MD_SYM(attn72_fwd_max)(q, k, v, o, lse, B, T, H, stream);
+    if (!(mfma_shape(T, head_dim) && T <= 256)) return MD_SYM(attn_generic_fwd_max)(q, k, v, o, lse, B, T, H, head_dim, stream);
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    switch (T) {
+        case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, false, true>), dim3(1, B * H), dim3(Geo<64>::NTH), 0, st, q, k, v, o, lse, H, scale, T); break;
+        case 128: hipLaunchKernelGGL((attn_fwd_kernel<128, false, true>), dim3(1, B * H), dim3(Geo<128>::NTH), 0, st, q, k, v, o, lse, H, scale, T); break;
+        default: hipLaunchKernelGGL((attn_fwd_kernel<256, false, true>), dim3(1, B * H), dim3(Geo<256>::NTH), 0, st, q, k, v, o, lse, H, scale, T); break;
+    }
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

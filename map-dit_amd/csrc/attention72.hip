@@ -234,7 +234,9 @@ __device__ __forceinline__ bf16x8_t frag_tr_rows2(const char* tile, int d0, int 
 // SAVE (round 4, training): the normalised rows go back IN PLACE over the raw ones (a query row belongs to exactly one wave, a head's
 // key rows to exactly one workgroup) together with their scales s = sqrt(72) / (|row| + eps) [2][B*H][T]: what the backward needs
 // (mapdit_attn_cos_bwd_fused, head_dim 72).  The separate split / normalise pass over a [M, 3D] QKV result is gone in training too.
-template <int T, bool RAW, bool SAVE = false>
+// MAXSUB (mapdit_attn_sdpa_fwd, head_dim 72: q, k stay unnormalised - README.md:58 off form, parity unpinned): the row maximum is found in a
+// first sweep of the S products and subtracted in the second; lse = max + log(sum).
+template <int T, bool RAW, bool SAVE = false, bool MAXSUB = false>
 __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* qn, const bf16_t* kn,
                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                 float* __restrict__ lse, int H, float scale, float* __restrict__ sq_out = nullptr,
@@ -323,14 +325,26 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* q
     }
 
     f32x16_t oa[DT] = {};
-    float lsum = 0.f;
+    float lsum = 0.f, mrow = 0.f;
+    if (MAXSUB) {
+        float mx = -3.0e38f;
+        for (int kt = 0; kt < G::NT; ++kt) {
+            f32x16_t a = {};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a = MFMA32(frag_rows2(ks_, 32 * kt, ks, lane), qf[ks], a);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, a[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mrow = mx * scale;
+    }
 #pragma unroll 2
     for (int kt = 0; kt < G::NT; ++kt) {
         f32x16_t a = {};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a = MFMA32(frag_rows2(ks_, 32 * kt, ks, lane), qf[ks], a);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] * scale); lsum += a[i]; }
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(MAXSUB ? a[i] * scale - mrow : a[i] * scale); lsum += a[i]; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t pa = pack8(a, 8 * s2);
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(Geo<T>::NTH) void attn72_fwd_kernel(const bf16_t* q
     for (int i = 0; i < 16; ++i) rs[i] = __shfl(inv_l, acc_row(i, lane), 64);
     __syncthreads();                                   // K / V tiles are dead: reuse them as store buffers
     store_wave_tile(smem + wave * WT_BYTES, oa, rs, o + ((size_t)b * T + q0) * D + hh * HD, D, lane);
-    if (lane < 32) lse[bh * T + q0 + r] = __logf(lsum);
+    if (lane < 32) lse[bh * T + q0 + r] = mrow + __logf(lsum);
 }
 
 // ---- backward, pass A: dQ^ (wave owns 32 queries) ----------------------------------------------------------------
@@ -647,6 +661,15 @@ int MD_SYM(attn72_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v
     const float scale = 1.f / sqrtf((float)HD);
     hipStream_t st = (hipStream_t)stream;
     ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, false>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, qn, kn, v, o, lse, H, scale));
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+int MD_SYM(attn72_fwd_max)(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H, void* stream) {
+    const float scale = 1.f / sqrtf((float)HD);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN72_DISPATCH(T, hipLaunchKernelGGL((attn72_fwd_kernel<TT, false, false, true>), dim3(B * H), dim3(Geo<TT>::NTH), 0, st, q, k, v, o, lse, H, scale,
+                                          (float*)nullptr, (float*)nullptr));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

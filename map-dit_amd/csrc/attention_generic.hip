@@ -62,6 +62,23 @@ __global__ void qkv_merge_bwd_generic_kernel(const bf16_t* __restrict__ qkv, int
     }
 }
 
+// dqn, dkn, dv [B*H][T][hd] -> dqkv [M, 3D], nothing else (the head merge of plain scaled-dot-product attention: q, k were not
+// normalised, so there is no Jacobian).  One thread per 8 consecutive elements of a (token, which, head) row.
+__global__ void heads_merge_kernel(const bf16_t* __restrict__ dqn, const bf16_t* __restrict__ dkn, const bf16_t* __restrict__ dv, int B, int T,
+                                   int H, int hd, bf16_t* __restrict__ dqkv) {
+    const int ch = hd / 8;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)B * T * 3 * H * ch) return;
+    const int c = (int)(id % ch);
+    long r = id / ch;
+    const int h = (int)(r % H); r /= H;
+    const int which = (int)(r % 3);
+    const long m = r / 3;
+    const int t = (int)(m % T), b = (int)(m / T);
+    const bf16_t* src = (which == 0 ? dqn : which == 1 ? dkn : dv) + (((size_t)b * H + h) * T + t) * hd + 8 * c;
+    *(uint4*)(dqkv + (size_t)m * 3 * H * hd + (size_t)which * H * hd + h * hd + 8 * c) = *(const uint4*)src;
+}
+
 // Stage `rows` rows of `hd` bf16 (row stride ld elements) into LDS as fp32 [rows][HD], zero padded to the compile-time
 // row length HD (a multiple of 4), so the sweeps below are branch-free and read LDS 16 bytes at a time.
 template <int HD>
@@ -89,10 +106,12 @@ template <int HD> __device__ __forceinline__ void axpy_row(float (&acc)[HD], flo
 }
 
 // forward: o_i = sum_j softmax_j(q_i.k_j / sqrt(hd)) v_j ; cosine logits are bounded, so no running maximum.
+// maxsub != 0 (mapdit_attn_sdpa_fwd: q, k NOT normalised - README.md:58 --no-use-cosine-attention, parity unpinned): the row maximum is
+// found in a first sweep and subtracted, lse = max + log(sum) - the backward kernels recompute p = exp(s - lse) and need no change.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __restrict__ qn, const bf16_t* __restrict__ kn,
                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
-                                                             float* __restrict__ lse, int T, int H, int hd, float scale) {
+                                                             float* __restrict__ lse, int T, int H, int hd, float scale, int maxsub) {
     extern __shared__ float sm[];
     float* ks = sm;
     float* vs = sm + (size_t)T * HD;
@@ -105,16 +124,20 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const bf16_t* __r
         float q[HD], acc[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) { q[d] = d < hd ? up16(qn[(bh * T + i) * hd + d]) : 0.f; acc[d] = 0.f; }
-        float l = 0.f;
+        float l = 0.f, mx = 0.f;
+        if (maxsub) {
+            mx = -3.0e38f;
+            for (int j = 0; j < T; ++j) mx = fmaxf(mx, dot_row<HD>(q, ks + j * HD) * scale);
+        }
         for (int j = 0; j < T; ++j) {
-            const float p = __expf(dot_row<HD>(q, ks + j * HD) * scale);
+            const float p = __expf(dot_row<HD>(q, ks + j * HD) * scale - mx);
             l += p;
             axpy_row<HD>(acc, p, vs + j * HD);
         }
         const float il = 1.f / l;
 #pragma unroll
         for (int d = 0; d < HD; ++d) if (d < hd) o[((size_t)b * T + i) * D + hh * hd + d] = cvt16(acc[d] * il);
-        lse[bh * T + i] = __logf(l);
+        lse[bh * T + i] = mx + __logf(l);
     }
 }
 
@@ -225,8 +248,29 @@ extern "C" int MD_SYM(qkv_merge_bwd_generic)(const uint16_t* qkv, int B, int T, 
     return MAPDIT_OK;
 }
 
+extern "C" int MD_SYM(heads_merge_bwd)(const uint16_t* dqn, const uint16_t* dkn, const uint16_t* dv, int B, int T, int H, int head_dim,
+                                      uint16_t* dqkv, void* stream) {
+    MD_CHECK(dqn && dkn && dv && dqkv && B > 0 && T > 0 && H > 0, "heads_merge_bwd: null/empty argument");
+    MD_CHECK(head_dim > 0 && head_dim % 8 == 0, "heads_merge_bwd: head_dim=%d must be a multiple of 8", head_dim);
+    const long n = (long)B * T * 3 * H * (head_dim / 8);
+    hipLaunchKernelGGL(heads_merge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dqn, dkn, dv, B, T, H, head_dim, dqkv);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+static int generic_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H, int head_dim,
+                       int maxsub, void* stream);
 extern "C" int MD_SYM(attn_generic_fwd)(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B,
                                        int T, int H, int head_dim, void* stream) {
+    return generic_fwd(qn, kn, v, o, lse, B, T, H, head_dim, 0, stream);
+}
+// (internal, C++ linkage: the generic leg of mapdit_attn_sdpa_fwd, attention.hip)
+int MD_SYM(attn_generic_fwd_max)(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B,
+                                           int T, int H, int head_dim, void* stream) {
+    return generic_fwd(q, k, v, o, lse, B, T, H, head_dim, 1, stream);
+}
+static int generic_fwd(const uint16_t* qn, const uint16_t* kn, const uint16_t* v, uint16_t* o, float* lse, int B, int T, int H, int head_dim,
+                       int maxsub, void* stream) {
     MD_CHECK(qn && kn && v && o && lse, "attn_generic_fwd: null argument");
     if (check(T, head_dim) != MAPDIT_OK) return MAPDIT_ERR_ARG;
     const float scale = 1.f / sqrtf((float)head_dim);
@@ -236,7 +280,7 @@ extern "C" int MD_SYM(attn_generic_fwd)(const uint16_t* qn, const uint16_t* kn, 
     GEN_DISPATCH(head_dim, (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<HDT>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     GEN_DISPATCH(head_dim, hipLaunchKernelGGL((attn_generic_fwd_kernel<HDT>), dim3(B * H), dim3(nth), shm, (hipStream_t)stream, qn, kn,
-                                              v, o, lse, T, H, head_dim, scale));
+                                              v, o, lse, T, H, head_dim, scale, maxsub));
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

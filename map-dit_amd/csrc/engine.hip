@@ -72,6 +72,7 @@ struct mapdit_engine {
     //  * nn.Embedding: the label table is used as stored (no normalised copy, no rewrite) and its gradient is the scattered rows.
     float ca = 0.f, cb_attn = 0.f, cb_mlp = 0.f, s_act = 1.f, c5 = 0.70710678118654752f;
     bool plain_embedding = false;
+    bool sdpa = false;         // MAPDIT_OFF_COSINE_ATTN: q, k go into the attention unnormalised (raw head-major epilogue, mapdit_attn_sdpa_fwd, unfused backward)
     int wn_plain = 0;          // MAPDIT_WN_PLAIN under MAPDIT_OFF_WEIGHT_NORM: OR-ed into the flags of every linear's weight pass
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
     float lscale = 1.f, ginv = 1.f;       // fp16 backward: loss scale of the running backward and its inverse (1 otherwise)
@@ -236,8 +237,8 @@ size_t carve(mapdit_engine* e, void* base) {
         b.xm = cv.take<bf16_t>(M * D);
         // the fused QKV epilogue never writes qkv; nor does the head_dim-72 path without split / merge passes (raw72: q, k, v head-major
         // straight from the GEMM) - DiT-XL/2: 113 MB x 28 blocks at 64 samples that were carved and never touched
-        b.qkv = (e->generic_attn && !e->raw72) ? cv.take<bf16_t>(M * 3 * D) : nullptr;
-        b.qks = (e->generic_attn && !e->raw72) ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
+        b.qkv = (e->generic_attn && !e->raw72 && !e->sdpa) ? cv.take<bf16_t>(M * 3 * D) : nullptr;
+        b.qks = ((e->generic_attn && !e->raw72) || e->sdpa) ? nullptr : cv.take<float>((size_t)2 * N * c.num_heads * T);
         b.qn = cv.take<bf16_t>(M * D);
         b.kn = cv.take<bf16_t>(M * D);
         b.v = cv.take<bf16_t>(M * D);
@@ -389,7 +390,8 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(loss_scale_ok(c->loss_scale), "engine: loss_scale=%g must be 0 (automatic) or a finite power of two", (double)c->loss_scale);
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
-    MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING | MAPDIT_OFF_WEIGHT_NORM)) == 0,
+    MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING | MAPDIT_OFF_WEIGHT_NORM |
+                         MAPDIT_OFF_COSINE_ATTN)) == 0,
              "engine: unknown bits in mp_off=%d", c->mp_off);
     MD_CHECK(!c->mp_off || c->precision != MAPDIT_PREC_BF16X3, "engine: the --use-* off forms are not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
@@ -401,6 +403,8 @@ int check_cfg(const mapdit_config_t* c) {
     const int hd_ = c->hidden / c->num_heads;
     MD_CHECK(T >= 1 && (T <= 256 || (T % 256 == 0 && T <= 16384 && hd_ == 64 && c->precision != MAPDIT_PREC_BF16X3)),
              "engine: %d tokens per sample unsupported (<= 256; a multiple of 256 with head_dim 64 in bf16 / f16 precision)", T);
+    MD_CHECK(!(c->mp_off & MAPDIT_OFF_COSINE_ATTN) || (T <= 256 && hd_ % 8 == 0),
+             "engine: plain scaled-dot-product attention (cosine attention off) is built for <= 256 tokens and head_dim %% 8 == 0 (T=%d, head_dim=%d)", T, hd_);
     MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
     MD_CHECK(c->patch * c->patch * c->in_channels <= 256 && (c->patch * c->patch * c->in_channels) % 4 == 0,
              "engine: patch dim %d unsupported", c->patch * c->patch * c->in_channels);
@@ -439,6 +443,8 @@ void init_dims(mapdit_engine* e) {
     e->c5 = (c.mp_off & MAPDIT_OFF_MP_POS_ENC) ? 1.f : 0.70710678118654752f;
     e->plain_embedding = (c.mp_off & MAPDIT_OFF_MP_EMBEDDING) != 0;
     e->wn_plain = (c.mp_off & MAPDIT_OFF_WEIGHT_NORM) ? MAPDIT_WN_PLAIN : 0;
+    e->sdpa = (c.mp_off & MAPDIT_OFF_COSINE_ATTN) != 0;
+    if (e->sdpa) e->raw72 = false;          // (that path normalises q, k while it stages them)
     {   // 16-bit engines: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream, for A/B runs; =f: fp16 engine only)
         const char* v = getenv("MAPDIT_DX16");
         e->dx16 = c.precision != MAPDIT_PREC_BF16X3 && !(v && v[0] == '0') && (e->f16 || !(v && v[0] == 'f'));
@@ -1259,7 +1265,7 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         // inference at head_dim 72 (DiT-XL sampling): the GEMM epilogue writes q, k, v head-major and the attention kernel normalises
         // q, k while it stages them - no split / normalise pass over the QKV result (219 us of a 2.4 ms block at 256 x 256 tokens)
         const bool raw72 = e->raw72;
-        if (raw72) {
+        if (raw72 || e->sdpa) {      // (sdpa: README.md:58 off form - q, k stay as the projection gave them, for any head_dim % 8 == 0)
             mapdit_epilogue_t ep;
             memset(&ep, 0, sizeof(ep));
             ep.kind = MAPDIT_EPI_QKV_HEADS_RAW;
@@ -1279,7 +1285,8 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
             ep.alpha = 1.f;
             TRY(gemm16(e, MAPDIT_NT, M, 3 * D, D, b.xm, D, W(pidx_block(i, MAPDIT_B_QKV)), D, ep, st));
         }
-        if (raw72 && save) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk_save)(b.qn, b.kn, b.v, b.o, b.lse, b.qks, N, T, H, e->hd, st));
+        if (e->sdpa) TRY(DT_FN(e, mapdit_attn_sdpa_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
+        else if (raw72 && save) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk_save)(b.qn, b.kn, b.v, b.o, b.lse, b.qks, N, T, H, e->hd, st));
         else if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         else TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
@@ -1464,7 +1471,10 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
         // attention branch: dy now holds the grad of the attention branch output y_i
         TRY(gemm16(e, MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
         TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
-        if (e->generic_attn && !e->raw72) {
+        if (e->sdpa) {               // the unfused backward knows nothing of a normalisation: p = exp(s - lse); then the head merge alone
+            TRY(DT_FN(e, mapdit_attn_cos_bwd)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
+            TRY(DT_FN(e, mapdit_heads_merge_bwd)(e->dqn, e->dkn, e->dv, N, T, H, e->hd, e->dqkv, st));
+        } else if (e->generic_attn && !e->raw72) {
             TRY(DT_FN(e, mapdit_attn_cos_bwd)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
             TRY(DT_FN(e, mapdit_qkv_merge_bwd)(b.qkv, N, T, H, e->hd, e->dqn, e->dkn, e->dv, e->dqkv, st));
         } else {   // normalisation Jacobian + head merge inside the attention backward passes

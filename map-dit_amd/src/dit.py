@@ -280,7 +280,7 @@ class DiT(nn.Module):
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
                  learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True,
                  mp_silu: bool = True, mp_residual: bool = True, mp_pos_enc: bool = True, mp_embedding: bool = True,
-                 weight_normalization: bool = True):
+                 weight_normalization: bool = True, cosine_attention: bool = True):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -310,6 +310,8 @@ class DiT(nn.Module):
         # README.md:60 --use-weight-normalization off (unpinned like the four above): MPLinear / MPLinearChunk multiply by
         # W * gain / sqrt(in_dim), i.e. mp_linear.py:44,74 without their normalize(); the weight passes run with MAPDIT_WN_PLAIN
         self.weight_normalization = bool(weight_normalization)
+        # README.md:58 --use-cosine-attention off (unpinned): attention.py:42-43 dropped - q, k enter the scaled-dot-product attention unnormalised
+        self.cosine_attention = bool(cosine_attention)
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
@@ -563,7 +565,7 @@ class DiT(nn.Module):
                   class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
                   rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization,
                   mp_silu=self.mp_silu, mp_residual=self.mp_residual, mp_pos_enc=self.mp_pos_enc, mp_embedding=self.mp_embedding,
-                  weight_normalization=self.weight_normalization)
+                  weight_normalization=self.weight_normalization, cosine_attention=self.cosine_attention)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

@@ -32,7 +32,7 @@ MP_FLAGS = ["cosine-attention", "weight-normalization", "forced-weight-normaliza
 # Off forms this engine builds besides --no-use-forced-weight-normalization (DiT(..., mp_silu=False) etc.; src/dit.py).  The other
 # three (--no-use-cosine-attention, --no-use-weight-normalization, --no-use-no-layernorm) name layers the snapshot does not contain
 # (plain SDPA with learnt scale, biased nn.Linear, LayerNorm) and are refused.
-BUILT_OFF_FORMS = ["mp-residual", "mp-silu", "mp-pos-enc", "mp-embedding", "weight-normalization"]
+BUILT_OFF_FORMS = ["mp-residual", "mp-silu", "mp-pos-enc", "mp-embedding", "weight-normalization", "cosine-attention"]
 
 
 def get_model(args):

@@ -55,6 +55,8 @@ class DiTConfig:
     # README.md:60 --use-weight-normalization off (same status: unpinned): MPLinear / MPLinearChunk multiply by W * gain / sqrt(in_dim) -
     # mp_linear.py:44,74 without their normalize(); the training forward's in-place rewrite (mp_linear.py:38-40) is its own flag and stays
     weight_normalization: bool = True
+    # README.md:58 --use-cosine-attention off (unpinned): attention.py:42-43 (normalize(q), normalize(k)) dropped, the SDPA scale unchanged
+    cosine_attention: bool = True
 
     @property
     def grid(self) -> int:
@@ -81,7 +83,7 @@ class DiTConfig:
         d = asdict(self)
         if not d["rotation_modulation"]:
             del d["rotation_modulation"]
-        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization"):      # (likewise: only when switched off)
+        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention"):      # (likewise: only when switched off)
             if d[k]:
                 del d[k]
         return d
@@ -380,13 +382,16 @@ def attention(x: Tensor, sd, prefix: str, cfg: DiTConfig, train: bool, rnd=_iden
     q = q.view(B, T, H, hd).transpose(1, 2)
     k = k.view(B, T, H, hd).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)
-    q, k = _at(rnd, "qk")(normalize(q)), _at(rnd, "qk")(normalize(k))
+    cosine = getattr(cfg, "cosine_attention", True)
+    if cosine:                                        # attention.py:42-43; the off form (README.md:58, unpinned) feeds q, k as they are
+        q, k = normalize(q), normalize(k)
+    q, k = _at(rnd, "qk")(q), _at(rnd, "qk")(k)
     _rec(trace, prefix + "qn", q); _rec(trace, prefix + "kn", k); _rec(trace, prefix + "v", v)
     logits = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
     if rnd is _ident:
         out = torch.softmax(logits, dim=-1) @ v
-    else:   # the kernels keep exp(logit) un-normalised (cosine logits are bounded), round it for the PV product
-        p = torch.exp(logits)
+    else:   # the kernels keep exp(logit) un-normalised (cosine logits are bounded; off form: the row maximum taken out), round it for the PV product
+        p = torch.exp(logits if cosine else logits - logits.amax(-1, keepdim=True).detach())
         out = (_at(rnd, "p")(p) @ v) / p.sum(-1, keepdim=True)
     out = out.transpose(1, 2).reshape(B, T, D)
     _rec(trace, prefix + "o", _at(rnd, "x:proj")(out))

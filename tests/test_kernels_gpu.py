@@ -867,6 +867,47 @@ def test_attention_fwd_bwd(L, B, T, H):
     assert rel_err(got[:, 1].numpy(), ref[:, 1].numpy()) < 3e-2       # dK
 
 
+@pytest.mark.parametrize("B,T,H,hd,amp", [(2, 64, 2, 64, 1.0), (1, 256, 3, 64, 5.0), (3, 128, 1, 64, 5.0), (2, 256, 2, 72, 5.0), (1, 128, 2, 72, 1.0),
+                                            (2, 16, 4, 32, 3.0), (1, 200, 2, 96, 5.0)])
+def test_plain_sdpa_attention_fwd_bwd(L, B, T, H, hd, amp):
+    """mapdit_attn_sdpa_fwd (README.md:58 off form, parity unpinned): F.scaled_dot_product_attention on q, k that were NOT normalised - logits up to
+    a hundred and more (amp = 5: q.k / sqrt(hd) has standard deviation 25), which the cosine kernels' max-free exponentials would overflow on.
+    MFMA kernels for head_dim 64 / 72, the generic fp32 kernel otherwise; backward = mapdit_attn_cos_bwd (exp(s - lse)) + mapdit_heads_merge_bwd,
+    against autograd."""
+    D = H * hd
+    g = torch.Generator().manual_seed(20 + T + hd)
+    rb = lambda *s, a=1.0: (torch.randn(*s, generator=g) * a).to(MODE["dt"]).float()          # (exact in the operand format)
+    q, k, v = rb(B, H, T, hd, a=amp), rb(B, H, T, hd, a=amp), rb(B, H, T, hd)
+    dO = rb(B * T, D)
+    leaves = [z.clone().requires_grad_(True) for z in (q, k, v)]
+    logits = leaves[0] @ leaves[1].transpose(-1, -2) / math.sqrt(hd)
+    o_ref = (torch.softmax(logits, dim=-1) @ leaves[2]).transpose(1, 2).reshape(B * T, D)
+    o_ref.backward(dO)
+    assert amp < 5 or float(logits.detach().max()) > 89.0                # exp() of these overflows fp32 without the maximum taken out
+    dev = lambda z: z.to(DEV).to(MODE["dt"]).reshape(B * H, T, hd).contiguous()
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    mk = lambda *s: torch.zeros(*s, device=DEV, dtype=MODE["dt"])
+    o_d, lse = mk(B * T, D), torch.zeros(B * H, T, device=DEV)
+    lib = L.lib()
+    lib.attn_sdpa_fwd(p(qd), p(kd), p(vd), p(o_d), p(lse), B, T, H, hd, st())
+    torch.cuda.synchronize()
+    assert torch.isfinite(o_d.float()).all() and torch.isfinite(lse).all()
+    assert rel_err(lse.cpu().numpy(), torch.logsumexp(logits.detach(), -1).reshape(B * H, T).numpy()) < 1e-5
+    assert rel_err(o_d.float().cpu().numpy(), o_ref.detach().numpy()) < 1e-2
+    dOd = dO.to(DEV).to(MODE["dt"])
+    delta = torch.zeros(B * H, T, device=DEV)
+    dqn, dkn, dv = mk(B * H, T, hd), mk(B * H, T, hd), mk(B * H, T, hd)
+    lib.attn_cos_bwd(p(qd), p(kd), p(vd), p(dOd), p(o_d), p(lse), p(delta), p(dqn), p(dkn), p(dv), B, T, H, hd, st())
+    dqkv = mk(B * T, 3 * D)
+    lib.heads_merge_bwd(p(dqn), p(dkn), p(dv), B, T, H, hd, p(dqkv), st())
+    torch.cuda.synchronize()
+    got = dqkv.float().cpu().view(B, T, 3, H, hd)
+    for i, name in enumerate("qkv"):
+        ref = leaves[i].grad.transpose(1, 2)                     # [B, T, H, hd]
+        assert rel_err(got[:, :, i].numpy(), ref.numpy()) < (1.5e-2 if name == "v" else 3e-2), name
+        assert torch.equal(dqkv.view(B, T, 3, H, hd)[:, :, i].cpu(), (dqn, dkn, dv)[i].view(B, H, T, hd).transpose(1, 2).cpu()), "the merge moves bits"
+
+
 @pytest.mark.parametrize("B,T,H,K", [(2, 64, 2, 128), (1, 256, 3, 192), (8, 128, 4, 256), (3, 64, 1, 64), (1, 512, 2, 128), (1, 1024, 1, 64)])
 def test_fused_qkv_epilogue_and_fused_attention_backward(L, B, T, H, K):
     """QKV GEMM with the head split + cosine normalisation in its epilogue (MAPDIT_EPI_QKV_HEADS), attention forward, and

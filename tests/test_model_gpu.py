@@ -667,4 +667,4 @@ def test_forced_weight_normalization_off(precision, ltol, gtol):
     args.in_channels, args.input_size = 4, 32
     assert train.get_model(args).forced_weight_normalization is False
     with pytest.raises(NotImplementedError):
-        train.main(["--synthetic", "--results-dir", "unused", "--no-use-cosine-attention", "--num-steps", "2"])
+        train.main(["--synthetic", "--results-dir", "unused", "--no-use-no-layernorm", "--num-steps", "2"])
