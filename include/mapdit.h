@@ -205,6 +205,18 @@ int mapdit_grad_nonfinite_check_ranges(const float* grads, const mapdit_range_t*
 int mapdit_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
                         uint16_t* out, int n_samples, int T, int D, void* stream);
 
+/* LayerNorm in front of modulate (abi 5; README.md:64 --no-use-no-layernorm = the transformer layer normalisation the snapshot disabled;
+ * PARITY UNPINNED: the snapshot has no such layer - restated as upstream DiT's nn.LayerNorm(D, elementwise_affine=False, eps=1e-6)):
+ *   xhat = (x - mean) / sqrt(var + 1e-6) over the D features of each token (biased variance),  out = modulate(xhat, shift, scale, gain) in
+ * the 16-bit operand format.  xhat [rows, D] fp32 and rstd [rows] are kept when given (training); both may be NULL.  D % 4 == 0, D <= 2048. */
+int mapdit_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int ldmod, const float* gain, float* xhat, float* rstd,
+                           uint16_t* out, int n_samples, int T, int D, void* stream);
+/* Its backward, merged with the residual stream's pass-through: out = ca * dxo + rstd * (g - mean(g) - xhat * mean(g * xhat)) with g = dxhat,
+ * the gradient wrt xhat (mapdit_resid_mod_bwd in its modulate-only form: dxo = NULL, y_up = NULL, x = xhat leaves it in dx).  dxo (fp32) or
+ * dxo16 (the 16-bit stream) or neither.  The residual backward above the site then runs on `out` with ca = 1 and dxm = NULL. */
+int mapdit_ln_bwd_merge(const float* dxhat, const float* xhat, const float* rstd, const float* dxo, const uint16_t* dxo16, float ca, float* out,
+                        long rows, int D, void* stream);
+
 /* Fused backward of  x' = mp_sum(x_up, g_up*y_up, 0.3)  followed by  u = modulate(x', shift, scale, gain):
  * see map-dit_amd/csrc/pointwise.hip for the formulas.  NULL pointers switch the corresponding part off. */
 typedef struct {
@@ -405,7 +417,7 @@ int mapdit_ddim_step(const float* model_out, const float* x, const float* noise,
  * Engine: the whole DiT forward / backward sequenced from C++ on one stream (src/dit.py:70-105 and its autograd).
  * ------------------------------------------------------------------------------------------------------------ */
 enum { MAPDIT_OFF_MP_SILU = 1, MAPDIT_OFF_MP_RESIDUAL = 2, MAPDIT_OFF_MP_POS_ENC = 4, MAPDIT_OFF_MP_EMBEDDING = 8,
-       MAPDIT_OFF_WEIGHT_NORM = 16, MAPDIT_OFF_COSINE_ATTN = 32 };
+       MAPDIT_OFF_WEIGHT_NORM = 16, MAPDIT_OFF_COSINE_ATTN = 32, MAPDIT_OFF_NO_LAYERNORM = 64 };
 typedef struct {
     int depth, hidden, patch, input_size, in_channels, num_heads, mlp_hidden;
     int table_rows; /* num_classes + 1 when class_dropout_prob > 0 */
@@ -430,7 +442,11 @@ typedef struct {
      *                           (mp_linear.py:38-40, its own flag) is untouched
      *   MAPDIT_OFF_COSINE_ATTN  attention.py:42-43 dropped: q, k enter F.scaled_dot_product_attention as the projection gave them (scale
      *                           1/sqrt(head_dim) unchanged) - mapdit_attn_sdpa_fwd, the unfused backward, mapdit_heads_merge_bwd; <= 256
-     *                           tokens, head_dim % 8 == 0 */
+     *                           tokens, head_dim % 8 == 0
+     *   MAPDIT_OFF_NO_LAYERNORM "no layernorm" off = a LayerNorm (no affine, eps 1e-6: upstream DiT's norm1 / norm2 / norm_final) in front of
+     *                           every modulate() (dit_block.py:35-36, final_layer.py:55): mapdit_ln_modulate_fwd after each residual GEMM instead
+     *                           of the modulate fused into its epilogue; backward = modulate-only pass, mapdit_ln_bwd_merge, residual-only
+     *                           pass.  Not with rotation modulation. */
     int mp_off;
     float loss_scale; /* MAPDIT_PREC_F16 only: the power of two the backward multiplies the incoming gradient by, so that activation
                        * gradients (~1e-6 for a batch-mean loss over 256 samples) sit in fp16's normal range; every parameter gradient is
@@ -540,6 +556,10 @@ int mapdit_weightnorm_fwd_batch_f16(const mapdit_wn_job_t* jobs_dev, int njobs, 
 int mapdit_modulate_fwd_f16(const float* x, const float* shift, const float* scale, int ldmod, const float* gain,
                             uint16_t* out, int n_samples, int T, int D, void* stream);
 int mapdit_resid_mod_bwd_f16(const mapdit_resid_mod_bwd_t* args, void* stream);
+int mapdit_ln_modulate_fwd_f16(const float* x, const float* shift, const float* scale, int ldmod, const float* gain, float* xhat, float* rstd,
+                               uint16_t* out, int n_samples, int T, int D, void* stream);
+int mapdit_ln_bwd_merge_f16(const float* dxhat, const float* xhat, const float* rstd, const float* dxo, const uint16_t* dxo16, float ca, float* out,
+                            long rows, int D, void* stream);
 int mapdit_rot_modulate_fwd_f16(const float* x, const float* A, const float* B, int ldc, uint16_t* out, int n_samples, int T, int D,
                                 void* stream);
 int mapdit_mpsilu_to_f16(const float* x, uint16_t* out, long n, void* stream);

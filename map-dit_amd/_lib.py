@@ -52,7 +52,7 @@ class Config(C.Structure):
 
 # mapdit_config_t.mp_off bits (mapdit.h MAPDIT_OFF_*): off forms of the README's --use-* flags (parity unpinned); key = the facade's
 # constructor argument, True (the default) = the snapshot's arithmetic
-MP_OFF = {"mp_silu": 1, "mp_residual": 2, "mp_pos_enc": 4, "mp_embedding": 8, "weight_normalization": 16, "cosine_attention": 32}
+MP_OFF = {"mp_silu": 1, "mp_residual": 2, "mp_pos_enc": 4, "mp_embedding": 8, "weight_normalization": 16, "cosine_attention": 32, "no_layernorm": 64}
 WN_PLAIN = 2          # mapdit.h MAPDIT_WN_PLAIN
 
 
@@ -104,6 +104,8 @@ _SIGS = {
     "mapdit_qkv_merge_bwd": [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp],
     "mapdit_attn_cos_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_sdpa_fwd": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "mapdit_ln_modulate_fwd": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, vp],
+    "mapdit_ln_bwd_merge": [vp, vp, vp, vp, vp, cf, vp, cl, ci, vp],
     "mapdit_heads_merge_bwd": [vp, vp, vp, ci, ci, ci, ci, vp, vp],
     "mapdit_attn_cos_fwd_rawqk": [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "mapdit_attn_cos_fwd_rawqk_save": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
@@ -150,7 +152,7 @@ _SIGS = {
 }
 # IEEE fp16 operand forms: same signatures (mapdit.h, "16-bit operand format")
 for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_bwd", "rot_modulate_fwd", "qkv_split",
-           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_fwd_rawqk_save", "attn_cos_bwd", "attn_cos_bwd_fused", "attn_sdpa_fwd", "heads_merge_bwd", "qkv_split_generic", "qkv_merge_bwd_generic",
+           "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_fwd_rawqk_save", "attn_cos_bwd", "attn_cos_bwd_fused", "attn_sdpa_fwd", "heads_merge_bwd", "ln_modulate_fwd", "ln_bwd_merge", "qkv_split_generic", "qkv_merge_bwd_generic",
            "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
     _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]
 for _b, _h in (("gemm_bf16", "gemm_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),

@@ -72,6 +72,11 @@ struct mapdit_engine {
     //  * nn.Embedding: the label table is used as stored (no normalised copy, no rewrite) and its gradient is the scattered rows.
     float ca = 0.f, cb_attn = 0.f, cb_mlp = 0.f, s_act = 1.f, c5 = 0.70710678118654752f;
     bool plain_embedding = false;
+    // MAPDIT_OFF_NO_LAYERNORM: a LayerNorm in front of every modulate().  XH[j] / rstd[j] = normalised X[j] and its 1/sigma (training: kept
+    // for the backward; inference: none), ln_g / ln_s = the backward's two fp32 row buffers (grad wrt XH[j]; pass-through + LayerNorm backward)
+    bool ln = false;
+    std::vector<float*> XH, rstd;
+    float *ln_g = nullptr, *ln_s = nullptr;
     bool sdpa = false;         // MAPDIT_OFF_COSINE_ATTN: q, k go into the attention unnormalised (raw head-major epilogue, mapdit_attn_sdpa_fwd, unfused backward)
     int wn_plain = 0;          // MAPDIT_WN_PLAIN under MAPDIT_OFF_WEIGHT_NORM: OR-ed into the flags of every linear's weight pass
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
@@ -229,6 +234,13 @@ size_t carve(mapdit_engine* e, void* base) {
     const int nx = e->train ? 2 * L + 1 : 3;
     e->X.assign(nx, nullptr);
     for (int i = 0; i < nx; ++i) e->X[i] = cv.take<float>(M * D);
+    e->XH.assign(2 * L + 1, nullptr);
+    e->rstd.assign(2 * L + 1, nullptr);
+    if (e->ln && e->train) {
+        for (int j = 0; j <= 2 * L; ++j) { e->XH[j] = cv.take<float>(M * D); e->rstd[j] = cv.take<float>(M); }
+        e->ln_g = cv.take<float>(M * D);
+        e->ln_s = cv.take<float>(M * D);
+    }
     // bf16 activations of the fast path (a bf16x3 engine keeps fp32 ones instead: px / pblk below)
     const int nb = precise ? 0 : (e->train ? L : 1);
     e->blk.assign(nb, BlockBufs());
@@ -391,7 +403,7 @@ int check_cfg(const mapdit_config_t* c) {
     MD_CHECK(c->hidden % 128 == 0, "engine: hidden=%d must be a multiple of 128", c->hidden);
     MD_CHECK(!c->rotation || c->precision != MAPDIT_PREC_BF16X3, "engine: rotation modulation is not built for the bf16x3 engine");
     MD_CHECK((c->mp_off & ~(MAPDIT_OFF_MP_SILU | MAPDIT_OFF_MP_RESIDUAL | MAPDIT_OFF_MP_POS_ENC | MAPDIT_OFF_MP_EMBEDDING | MAPDIT_OFF_WEIGHT_NORM |
-                         MAPDIT_OFF_COSINE_ATTN)) == 0,
+                         MAPDIT_OFF_COSINE_ATTN | MAPDIT_OFF_NO_LAYERNORM)) == 0,
              "engine: unknown bits in mp_off=%d", c->mp_off);
     MD_CHECK(!c->mp_off || c->precision != MAPDIT_PREC_BF16X3, "engine: the --use-* off forms are not built for the bf16x3 engine");
     MD_CHECK(c->num_heads > 0 && c->hidden % c->num_heads == 0 && c->hidden / c->num_heads <= 96,
@@ -403,6 +415,8 @@ int check_cfg(const mapdit_config_t* c) {
     const int hd_ = c->hidden / c->num_heads;
     MD_CHECK(T >= 1 && (T <= 256 || (T % 256 == 0 && T <= 16384 && hd_ == 64 && c->precision != MAPDIT_PREC_BF16X3)),
              "engine: %d tokens per sample unsupported (<= 256; a multiple of 256 with head_dim 64 in bf16 / f16 precision)", T);
+    MD_CHECK(!(c->mp_off & MAPDIT_OFF_NO_LAYERNORM) || (!c->rotation && c->hidden <= 2048),
+             "engine: the LayerNorm form (no-layernorm off) is built for the AdaLN modulation and hidden <= 2048");
     MD_CHECK(!(c->mp_off & MAPDIT_OFF_COSINE_ATTN) || (T <= 256 && hd_ % 8 == 0),
              "engine: plain scaled-dot-product attention (cosine attention off) is built for <= 256 tokens and head_dim %% 8 == 0 (T=%d, head_dim=%d)", T, hd_);
     MD_CHECK(c->mlp_hidden % 64 == 0, "engine: mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
@@ -444,6 +458,7 @@ void init_dims(mapdit_engine* e) {
     e->plain_embedding = (c.mp_off & MAPDIT_OFF_MP_EMBEDDING) != 0;
     e->wn_plain = (c.mp_off & MAPDIT_OFF_WEIGHT_NORM) ? MAPDIT_WN_PLAIN : 0;
     e->sdpa = (c.mp_off & MAPDIT_OFF_COSINE_ATTN) != 0;
+    e->ln = (c.mp_off & MAPDIT_OFF_NO_LAYERNORM) != 0;
     if (e->sdpa) e->raw72 = false;          // (that path normalises q, k while it stages them)
     {   // 16-bit engines: 16-bit gradient stream between the blocks (MAPDIT_DX16=0: the fp32 stream, for A/B runs; =f: fp16 engine only)
         const char* v = getenv("MAPDIT_DX16");
@@ -557,6 +572,24 @@ int dx_resid_mod_bwd(mapdit_engine* e, int M, int K, const bf16_t* dy, int ld_dy
     a.part_scratch_bytes = (size_t)8 * e->cfg.max_batch * 3 * D * sizeof(float);
     a.gain_partials_out = &npart;
     a.dgain_scale = e->ginv;                            // fp16: the gradients carry the loss scale, the gain gradient must not
+    if (e->ln) {
+        // LayerNorm form: u = modulate(LN(x')).  (1) the pass in its modulate-only form on xh = LN(x'): the conditioning gradients and g = grad
+        // wrt xh;  (2) s = ca * dxo + LN-backward(g);  (3) the pass in its residual-only form on s (ca = 1): dx, dy_up, dg_up as ever.
+        int site = -1;
+        for (size_t j = 0; j < e->X.size(); ++j) if (a.x == e->X[j]) site = (int)j;
+        MD_CHECK(site >= 0 && site < (int)e->XH.size() && e->XH[site] && e->ln_g, "engine_backward: no saved LayerNorm output for this site");
+        TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
+        mapdit_resid_mod_bwd_t m = a;
+        m.dxo = nullptr; m.dxo_bf = nullptr; m.y_up = nullptr; m.g_up = nullptr; m.dy_up = nullptr; m.dg_up = nullptr;
+        m.x = e->XH[site]; m.dxm = e->dxm; m.dx = e->ln_g; m.dx_bf = nullptr; m.dgain_out = dgain;
+        TRY(DT_FN(e, mapdit_resid_mod_bwd)(&m, st));
+        if (npart) TRY(mapdit_reduce_partials(e->gain_part, npart, dgain, 0, st));
+        TRY(DT_FN(e, mapdit_ln_bwd_merge)(e->ln_g, e->XH[site], e->rstd[site], a.dxo, a.dxo_bf, a.ca, e->ln_s, (long)M, D, st));
+        mapdit_resid_mod_bwd_t r = a;
+        int npart_r = 0;
+        r.dxm = nullptr; r.dxo = e->ln_s; r.dxo_bf = nullptr; r.ca = 1.f; r.dgain_out = nullptr; r.gain_partials_out = &npart_r;
+        return DT_FN(e, mapdit_resid_mod_bwd)(&r, st);
+    }
     if (rot) {
         TRY(gemm16(e, MAPDIT_NN, M, D, K, dy, ld_dy, wimg, D, epi_bf16(e->dxm, D), st));
         a.dxm = e->dxm;
@@ -1250,7 +1283,13 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         return e->rot ? e->rotB + (size_t)(2 * i + br) * D : e->mod_all + (size_t)i * e->MW + (br ? e->o_shm : e->o_sha);
     };
     auto gain_of = [&](int pidx) -> const float* { return e->rot ? e->zero_gain : e->params[pidx]; };
-    if (e->rot) TRY(DT_FN(e, mapdit_rot_modulate_fwd)(e->X[0], sc_of(0, 0), sh_of(0, 0), ldn, e->blk[0].xm, N, T, D, st));
+    // LayerNorm form: site j = X[j] -> LN -> modulate -> the branch's operand, one launch after the GEMM that wrote X[j] (whose epilogue then
+    // writes no modulated output)
+    auto ln_site = [&](int j, const float* xj, const float* sh, const float* sc, int ld, const float* gain, bf16_t* dst) -> int {
+        return DT_FN(e, mapdit_ln_modulate_fwd)(xj, sh, sc, ld, gain, save ? e->XH[j] : nullptr, save ? e->rstd[j] : nullptr, dst, N, T, D, st);
+    };
+    if (e->ln) TRY(ln_site(0, e->X[0], sh_of(0, 0), sc_of(0, 0), ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)), e->blk[0].xm));
+    else if (e->rot) TRY(DT_FN(e, mapdit_rot_modulate_fwd)(e->X[0], sc_of(0, 0), sh_of(0, 0), ldn, e->blk[0].xm, N, T, D, st));
     else TRY(DT_FN(e, mapdit_modulate_fwd)(e->X[0], sh_of(0, 0), sc_of(0, 0), ldm, gain_of(pidx_block(0, MAPDIT_B_GAIN_MSA)), e->blk[0].xm,
                                            N, T, D, st));
     for (int i = 0; i < L; ++i) {
@@ -1290,17 +1329,24 @@ extern "C" int mapdit_engine_forward(mapdit_engine_t* e, const float* x, const i
         else if (raw72) TRY(DT_FN(e, mapdit_attn_cos_fwd_rawqk)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         else TRY(DT_FN(e, mapdit_attn_cos_fwd)(b.qn, b.kn, b.v, b.o, b.lse, N, T, H, e->hd, st));
         TRY(gemm16(e, MAPDIT_NT, M, D, D, b.o, D, W(pidx_block(i, MAPDIT_B_PROJ)), D,
-                 epi_resid(e->ca, e->cb_attn, save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, b.xm2, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, rot), st));
+                 epi_resid(e->ca, e->cb_attn, save ? b.y : nullptr, xin, xmid, mod + e->o_ga, ldm, T, D, e->ln ? nullptr : b.xm2, sh_of(i, 1), sc_of(i, 1), ldn,
+                           gmlp, rot), st));
+        if (e->ln) TRY(ln_site(2 * i + 1, xmid, sh_of(i, 1), sc_of(i, 1), ldn, gmlp, b.xm2));
         // MLP branch (dit_block.py:36); b.xm2 = modulate(xmid, shift_mlp, scale_mlp, gain_mlp) came out of the epilogue above
         const bool timed = e->prof_which == MAPDIT_PROF_FC1_FWD && e->prof_used < e->prof_start.size() && (e->prof_seen++ % e->prof_stride) == 0;
         if (timed) (void)hipEventRecord(e->prof_start[e->prof_used], (hipStream_t)st);
         TRY(gemm16(e, MAPDIT_NT, M, Hm, D, b.xm2, D, W(pidx_block(i, MAPDIT_B_FC1)), D, epi_silu2_grad(save ? b.hdact : nullptr, b.hact, Hm), st));
         if (timed) (void)hipEventRecord(e->prof_stop[e->prof_used++], (hipStream_t)st);
         TRY(gemm16(e, MAPDIT_NT, M, D, Hm, b.hact, Hm, W(pidx_block(i, MAPDIT_B_FC2)), Hm,
-                 i + 1 < L ? epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->blk[save ? i + 1 : 0].xm,
+                 i + 1 < L ? epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D,
+                                       e->ln ? nullptr : e->blk[save ? i + 1 : 0].xm,
                                        sh_of(i + 1, 0), sc_of(i + 1, 0), ldn, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)), rot)
-                           : epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->xmodf, e->fmod, e->fmod + D, 2 * D,
-                                       e->params[MAPDIT_P_F_GAIN]), st));
+                           : epi_resid(e->ca, e->cb_mlp, save ? b.y2 : nullptr, xmid, xout, mod + e->o_gm, ldm, T, D, e->ln ? nullptr : e->xmodf, e->fmod,
+                                       e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN]), st));
+        if (e->ln) {
+            if (i + 1 < L) TRY(ln_site(2 * i + 2, xout, sh_of(i + 1, 0), sc_of(i + 1, 0), ldn, gain_of(pidx_block(i + 1, MAPDIT_B_GAIN_MSA)), e->blk[save ? i + 1 : 0].xm));
+            else TRY(ln_site(2 * L, xout, e->fmod, e->fmod + D, 2 * D, e->params[MAPDIT_P_F_GAIN], e->xmodf));
+        }
     }
     float* xL = e->X[save ? 2 * L : (2 * L) % 3];
     // final layer                                                       (final_layer.py:53-59, dit.py:96-101)

@@ -34,6 +34,98 @@ __global__ __launch_bounds__(256) void modulate_fwd_kernel(const float* __restri
     }
 }
 
+// ---- LayerNorm in front of modulate (README.md:64 --no-use-no-layernorm: the transformer layer normalisation the snapshot disabled;
+// PARITY UNPINNED - the snapshot has no such layer; restated as upstream DiT's nn.LayerNorm(D, elementwise_affine=False, eps=1e-6)) -------
+//   xh = (x - mean) * rstd,  rstd = 1 / sqrt(var + 1e-6) (biased variance over the D features of a token);  u = modulate(xh, ...) as above.
+// One wave per token row, the row held in registers between the two sweeps (D <= 2048).  xh (fp32) and rstd are kept for the backward
+// when given (training); inference passes NULL for both.
+constexpr float LN_EPS = 1e-6f;
+constexpr int LN_MAXV = 8;                       // float4 chunks per lane: D <= 64 * 4 * 8
+__global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                            const float* __restrict__ scale, int ldmod, const float* __restrict__ gain,
+                                                            float* __restrict__ xh, float* __restrict__ rstd, bf16_t* __restrict__ out,
+                                                            long rows, int D, int T) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float g = *gain, den = mp_den(g);
+    const float ka = (1.f - g) / den, kb = g / den;
+    const int n = (int)(m / T);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane * 4 + 256 * k;
+        v[k] = c < D ? *(const float4*)(x + m * D + c) : make_float4(0, 0, 0, 0);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < D) {
+            v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+            q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+    }
+    const float r = 1.f / sqrtf(wave_sum(q) / (float)D + LN_EPS);
+    if (rstd && lane == 0) rstd[m] = r;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < D) {
+            const float4 h = make_float4(v[k].x * r, v[k].y * r, v[k].z * r, v[k].w * r);
+            if (xh) *(float4*)(xh + m * D + c) = h;
+            const float4 sc = *(const float4*)(scale + (size_t)n * ldmod + c), sh = *(const float4*)(shift + (size_t)n * ldmod + c);
+            uint2 u;
+            u.x = pack16(ka * h.x * sc.x + kb * sh.x, ka * h.y * sc.y + kb * sh.y);
+            u.y = pack16(ka * h.z * sc.z + kb * sh.z, ka * h.w * sc.w + kb * sh.w);
+            *(uint2*)(out + m * D + c) = u;
+        }
+    }
+}
+
+// Backward of the normalisation, merged with the residual stream's pass-through:  out = ca * dxo + rstd * (g - mean(g) - xh * mean(g * xh)),
+// g = grad wrt xh (what the modulate-only form of resid_mod_bwd below leaves in its dx).  dxo: fp32, or 16-bit (dxo16), or neither (the
+// final layer's site: nothing arrives from downstream).  One wave per token row.
+__global__ __launch_bounds__(256) void ln_bwd_merge_kernel(const float* __restrict__ g, const float* __restrict__ xh, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dxo, const bf16_t* __restrict__ dxo16, float ca,
+                                                         float* __restrict__ out, long rows, int D) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float4 gv[LN_MAXV], hv[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < D) {
+            gv[k] = *(const float4*)(g + m * D + c);
+            hv[k] = *(const float4*)(xh + m * D + c);
+            s1 += (gv[k].x + gv[k].y) + (gv[k].z + gv[k].w);
+            s2 += (gv[k].x * hv[k].x + gv[k].y * hv[k].y) + (gv[k].z * hv[k].z + gv[k].w * hv[k].w);
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D, r = rstd[m];
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < D) {
+            float4 o = make_float4(r * (gv[k].x - m1 - hv[k].x * m2), r * (gv[k].y - m1 - hv[k].y * m2), r * (gv[k].z - m1 - hv[k].z * m2),
+                                   r * (gv[k].w - m1 - hv[k].w * m2));
+            if (dxo) {
+                const float4 d = *(const float4*)(dxo + m * D + c);
+                o.x += ca * d.x; o.y += ca * d.y; o.z += ca * d.z; o.w += ca * d.w;
+            } else if (dxo16) {
+                const uint2 u = *(const uint2*)(dxo16 + m * D + c);
+                o.x += ca * lo16(u.x); o.y += ca * hi16(u.x); o.z += ca * lo16(u.y); o.w += ca * hi16(u.y);
+            }
+            *(float4*)(out + m * D + c) = o;
+        }
+    }
+}
+
 // ---- fused backward of  x' = mp_sum(x_up, g_up*y_up, 0.3)  ->  u = modulate(x', shift, scale, gain) -------------
 // Inputs : dxo  grad wrt the residual value x' arriving from downstream (fp32, may be null = 0), scaled by ca here
 //          dxm  grad wrt u (bf16, may be null)
@@ -465,6 +557,29 @@ extern "C" int MD_SYM(modulate_fwd)(const float* x, const float* shift, const fl
     const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
     hipLaunchKernelGGL(modulate_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, shift, scale, ldmod, gain,
                        out, total8, D, T);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int MD_SYM(ln_modulate_fwd)(const float* x, const float* shift, const float* scale, int ldmod, const float* gain, float* xhat,
+                                      float* rstd, uint16_t* out, int n_samples, int T, int D, void* stream) {
+    MD_CHECK(x && shift && scale && gain && out && n_samples > 0 && T > 0, "ln_modulate_fwd: null/empty argument");
+    MD_CHECK(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV && ldmod % 4 == 0, "ln_modulate_fwd: D=%d must be a multiple of 4 up to %d, ldmod=%d of 4", D,
+             256 * LN_MAXV, ldmod);
+    const long rows = (long)n_samples * T;
+    hipLaunchKernelGGL(ln_modulate_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, shift, scale, ldmod, gain, xhat,
+                       rstd, out, rows, D, T);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
+extern "C" int MD_SYM(ln_bwd_merge)(const float* dxhat, const float* xhat, const float* rstd, const float* dxo, const uint16_t* dxo16, float ca,
+                                   float* out, long rows, int D, void* stream) {
+    MD_CHECK(dxhat && xhat && rstd && out && rows > 0, "ln_bwd_merge: null/empty argument");
+    MD_CHECK(!(dxo && dxo16), "ln_bwd_merge: dxo and dxo16 are alternatives");
+    MD_CHECK(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV, "ln_bwd_merge: D=%d must be a multiple of 4 up to %d", D, 256 * LN_MAXV);
+    hipLaunchKernelGGL(ln_bwd_merge_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dxhat, xhat, rstd, dxo, dxo16, ca, out,
+                       rows, D);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

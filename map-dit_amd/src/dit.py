@@ -280,7 +280,7 @@ class DiT(nn.Module):
                  num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1, num_classes: int = 1000,
                  learn_sigma: bool = True, rotation_modulation: bool = False, forced_weight_normalization: bool = True,
                  mp_silu: bool = True, mp_residual: bool = True, mp_pos_enc: bool = True, mp_embedding: bool = True,
-                 weight_normalization: bool = True, cosine_attention: bool = True):
+                 weight_normalization: bool = True, cosine_attention: bool = True, no_layernorm: bool = True):
         super().__init__()
         if not learn_sigma:
             raise NotImplementedError("learn_sigma=False is not built (every reference script uses the default True)")
@@ -303,8 +303,8 @@ class DiT(nn.Module):
         # Off forms of four more README flags (README.md:62-66: --use-mp-residual, --use-mp-silu, --use-mp-pos-enc, --use-mp-embedding).
         # The snapshot hard-wires them on and holds no code for the off forms: PARITY UNPINNED - each is this build's
         # restatement of one README line with upstream DiT's form of the operation (oracle.dit_oracle.DiTConfig), held to that
-        # restatement by tests/test_mp_flags_gpu.py.  True = the snapshot's arithmetic.  The remaining three off forms (LayerNorm, biased
-        # nn.Linear, plain SDPA) name layers with parameters / kernels the snapshot does not have and stay refused (train.py).
+        # restatement by tests/test_mp_flags_gpu.py.  True = the snapshot's arithmetic.  The remaining three (below) needed kernels of their
+        # own: weight passes without normalize(), a softmax with its maximum taken out, a LayerNorm in front of modulate().
         self.mp_silu, self.mp_residual = bool(mp_silu), bool(mp_residual)
         self.mp_pos_enc, self.mp_embedding = bool(mp_pos_enc), bool(mp_embedding)
         # README.md:60 --use-weight-normalization off (unpinned like the four above): MPLinear / MPLinearChunk multiply by
@@ -312,6 +312,9 @@ class DiT(nn.Module):
         self.weight_normalization = bool(weight_normalization)
         # README.md:58 --use-cosine-attention off (unpinned): attention.py:42-43 dropped - q, k enter the scaled-dot-product attention unnormalised
         self.cosine_attention = bool(cosine_attention)
+        # README.md:64 --use-no-layernorm off (unpinned) = WITH the transformer layer normalisation: upstream DiT's LayerNorm (no affine, eps 1e-6)
+        # in front of every modulate() - both branches of every block and the final layer
+        self.no_layernorm = bool(no_layernorm)
 
         self.x_embedder = MPLinear(patch_size * patch_size * in_channels + 1, hidden_size)
         self.t_embedder = TimestepEmbedder(hidden_size)
@@ -565,7 +568,8 @@ class DiT(nn.Module):
                   class_dropout_prob=self.class_dropout_prob, num_classes=self.num_classes, learn_sigma=self.learn_sigma,
                   rotation_modulation=self.rotation_modulation, forced_weight_normalization=self.forced_weight_normalization,
                   mp_silu=self.mp_silu, mp_residual=self.mp_residual, mp_pos_enc=self.mp_pos_enc, mp_embedding=self.mp_embedding,
-                  weight_normalization=self.weight_normalization, cosine_attention=self.cosine_attention)
+                  weight_normalization=self.weight_normalization, cosine_attention=self.cosine_attention,
+                  no_layernorm=self.no_layernorm)
         new.to(device=self._pflat.device, dtype=self._pflat.dtype)
         new.load_state_dict(copy.deepcopy(self.state_dict()))
         for p_new, p_old in zip(new.parameters(), self.parameters()):

@@ -32,7 +32,7 @@ MP_FLAGS = ["cosine-attention", "weight-normalization", "forced-weight-normaliza
 # Off forms this engine builds besides --no-use-forced-weight-normalization (DiT(..., mp_silu=False) etc.; src/dit.py).  The other
 # three (--no-use-cosine-attention, --no-use-weight-normalization, --no-use-no-layernorm) name layers the snapshot does not contain
 # (plain SDPA with learnt scale, biased nn.Linear, LayerNorm) and are refused.
-BUILT_OFF_FORMS = ["mp-residual", "mp-silu", "mp-pos-enc", "mp-embedding", "weight-normalization", "cosine-attention"]
+BUILT_OFF_FORMS = ["mp-residual", "mp-silu", "mp-pos-enc", "mp-embedding", "weight-normalization", "cosine-attention", "no-layernorm"]
 
 
 def get_model(args):
@@ -115,16 +115,17 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    # --no-use-forced-weight-normalization is the one off-path the snapshot's code defines (skip the in-place rewrite); four more are
-    # built as restatements of their README lines (BUILT_OFF_FORMS, parity unpinned); the rest is refused
+    # --no-use-forced-weight-normalization is the one off-path the snapshot's code defines (skip the in-place rewrite); the other seven are
+    # built as restatements of their README lines (BUILT_OFF_FORMS, parity unpinned: the snapshot hard-wires every feature on)
     off = [f for f in MP_FLAGS if not getattr(args, "use_" + f.replace("-", "_"))
            and f != "forced-weight-normalization" and f not in BUILT_OFF_FORMS]
     if off:
-        raise NotImplementedError(f"--no-use-{off[0]}: the reference snapshot hard-wires every magnitude-preserving feature on (SURVEY F5) "
-                                  "and holds no code for this layer's off form; built off forms: --no-use-forced-weight-normalization, "
+        raise NotImplementedError(f"--no-use-{off[0]}: no off form built; built: --no-use-forced-weight-normalization, "
                                   + ", ".join("--no-use-" + f for f in BUILT_OFF_FORMS))
     if args.precision == "bf16x3" and any(not getattr(args, "use_" + f.replace("-", "_")) for f in BUILT_OFF_FORMS):
-        raise NotImplementedError("the --no-use-mp-* off forms are built for the f16 / bf16 engines, not for --precision bf16x3")
+        raise NotImplementedError("the --no-use-* off forms are built for the f16 / bf16 engines, not for --precision bf16x3")
+    if not args.use_no_layernorm and args.use_rotation_modulation:
+        raise NotImplementedError("--no-use-no-layernorm (the LayerNorm form) is built for the AdaLN modulation, not with --use-rotation-modulation")
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -57,6 +57,9 @@ class DiTConfig:
     weight_normalization: bool = True
     # README.md:58 --use-cosine-attention off (unpinned): attention.py:42-43 (normalize(q), normalize(k)) dropped, the SDPA scale unchanged
     cosine_attention: bool = True
+    # README.md:64 --use-no-layernorm off (unpinned) = WITH a LayerNorm: torch.nn.functional.layer_norm(x, (D,), eps=1e-6), no affine (upstream
+    # DiT's norm1 / norm2 / norm_final), in front of every modulate() (dit_block.py:35-36, final_layer.py:55)
+    no_layernorm: bool = True
 
     @property
     def grid(self) -> int:
@@ -83,7 +86,7 @@ class DiTConfig:
         d = asdict(self)
         if not d["rotation_modulation"]:
             del d["rotation_modulation"]
-        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention"):      # (likewise: only when switched off)
+        for k in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention", "no_layernorm"):      # (likewise: only when switched off)
             if d[k]:
                 del d[k]
         return d
@@ -412,6 +415,14 @@ class _WithFull:
         self.stored, self.full = stored, full
 
 
+def pre_norm(cfg: DiTConfig, x: Tensor) -> Tensor:
+    """What stands in front of modulate(): nothing in the snapshot ("no layernorm", dit_block.py:35-36, final_layer.py:55); with
+    ``no_layernorm=False`` (README.md:64 off form; unpinned) upstream DiT's LayerNorm without affine parameters, eps 1e-6."""
+    if getattr(cfg, "no_layernorm", True):
+        return x
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), eps=1e-6)
+
+
 def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd=_ident, trace=None) -> Tensor:
     """src/blocks/dit_block.py:32-37."""
     p = f"blocks.{i}."
@@ -424,8 +435,8 @@ def dit_block(x: Tensor, c: Tensor, sd, i: int, cfg: DiTConfig, train: bool, rnd
         mod_m = lambda v: modulate_rot(v, th_m, sc_m, sd[p + "gain_mlp"])
     else:
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
-        mod_a = lambda v: modulate(v, sh_a, sc_a, sd[p + "gain_msa"])
-        mod_m = lambda v: modulate(v, sh_m, sc_m, sd[p + "gain_mlp"])
+        mod_a = lambda v: modulate(pre_norm(cfg, v), sh_a, sc_a, sd[p + "gain_msa"])
+        mod_m = lambda v: modulate(pre_norm(cfg, v), sh_m, sc_m, sd[p + "gain_mlp"])
     # x: the stored checkpoint (site "res": identity in every shipped plan); x_full: the value the epilogue that produced it still
     # holds in fp32 - the next branch's modulate is fused into that epilogue and sees the unrounded value
     x_full = x.full if isinstance(x, _WithFull) else x
@@ -455,7 +466,7 @@ def final_layer(x: Tensor, c: Tensor, sd, cfg: DiTConfig, train: bool, rnd=_iden
     which are per-weight and order independent."""
     p = "final_layer."
     shift, scale = mp_linear(act_fn(cfg)(c), sd, p + "modulation.1.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True)).chunk(2, dim=-1)
-    x_mod = modulate(x, shift, scale, sd[p + "gain_mod"])
+    x_mod = modulate(pre_norm(cfg, x), shift, scale, sd[p + "gain_mod"])
     _rec(trace, p + "xmod", _at(rnd, "x:flin")(x_mod))
     out = mp_linear(x_mod, sd, p + "linear.weight", train, rnd, wn=getattr(cfg, "weight_normalization", True))
     _rec(trace, p + "lin", out)

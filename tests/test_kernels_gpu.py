@@ -429,6 +429,45 @@ def test_weightnorm_plain_flag(L, rows, cols, forced):
         assert torch.equal(Gs, ref)
 
 
+@pytest.mark.parametrize("N,T,D", [(2, 64, 128), (3, 16, 384), (1, 256, 1152), (2, 8, 2048)])
+def test_layernorm_modulate_and_its_backward(L, N, T, D):
+    """mapdit_ln_modulate_fwd / mapdit_ln_bwd_merge (README.md:64 off form, parity unpinned: upstream DiT's LayerNorm without affine, eps 1e-6,
+    in front of modulate) against torch.nn.functional.layer_norm + the oracle's modulate and their autograd, with the pass-through term as an
+    fp32 tensor, a 16-bit tensor, and absent."""
+    from oracle.dit_oracle import modulate
+    g = torch.Generator().manual_seed(31)
+    M = N * T
+    x = torch.randn(M, D, generator=g) * 2.0 + 0.7
+    sh, sc = torch.randn(N, D + 4, generator=g), 1.0 + 0.3 * torch.randn(N, D + 4, generator=g)
+    gain = torch.tensor(0.3)
+    xr = x.clone().requires_grad_(True)
+    xh_ref = torch.nn.functional.layer_norm(xr.view(N, T, D), (D,), eps=1e-6)
+    u_ref = modulate(xh_ref, sh[:, :D], sc[:, :D], gain)
+    xd, shd, scd, gd = x.to(DEV), sh.to(DEV), sc.to(DEV), gain.to(DEV)
+    xh, rstd = torch.zeros(M, D, device=DEV), torch.zeros(M, device=DEV)
+    out = torch.zeros(M, D, device=DEV, dtype=MODE["dt"])
+    lib = L.lib()
+    lib.ln_modulate_fwd(p(xd), p(shd), p(scd), D + 4, p(gd), p(xh), p(rstd), p(out), N, T, D, st())
+    out2 = torch.zeros_like(out)
+    lib.ln_modulate_fwd(p(xd), p(shd), p(scd), D + 4, p(gd), None, None, p(out2), N, T, D, st())          # inference: nothing kept
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert rel_err(xh.cpu().numpy(), xh_ref.detach().reshape(M, D).numpy()) < 2e-6
+    assert rel_err(rstd.cpu().numpy(), (1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)).numpy()) < 2e-6
+    assert rel_err(out.float().cpu().numpy(), u_ref.detach().reshape(M, D).numpy()) < (4e-3 if MODE["dt"] == torch.bfloat16 else 5e-4)
+    # backward of the normalisation alone, merged with ca * dxo
+    gh = torch.randn(M, D, generator=g)
+    xh_ref.backward(gh.view(N, T, D))
+    dxo = torch.randn(M, D, generator=g).to(MODE["dt"]).float()
+    ghd, d32, d16 = gh.to(DEV), dxo.to(DEV), dxo.to(DEV).to(MODE["dt"])
+    for kind in ("f32", "16", "none"):
+        o = torch.zeros(M, D, device=DEV)
+        lib.ln_bwd_merge(p(ghd), p(xh), p(rstd), p(d32) if kind == "f32" else None, p(d16) if kind == "16" else None, 0.9, p(o), M, D, st())
+        torch.cuda.synchronize()
+        want = xr.grad + (0.9 * dxo if kind != "none" else 0.0)
+        assert rel_err(o.cpu().numpy(), want.numpy()) < 1e-5, kind
+
+
 def test_weightnorm_batch_equals_single_launches(L):
     """mapdit_weightnorm_fwd_batch (one launch for every weight, device job table) against one launch per weight: bit-equal
     rewritten masters and images, for ragged row counts (rows % 4 != 0) and both output kinds."""

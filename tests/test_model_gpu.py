@@ -659,12 +659,12 @@ def test_forced_weight_normalization_off(precision, ltol, gtol):
             continue
         e = rel_err(p.grad.cpu().numpy(), gref.numpy())
         assert e < (gtol if gref.numel() >= 64 else 10 * gtol) or float(gref.norm()) < 1e-7, (k, e)
-    # the harness accepts this flag's off form (and, round 5, the four of tests/test_mp_flags_gpu.py); the layers the snapshot does not
-    # contain still refuse
+    # the harness accepts this flag's off form (and, round 5, the seven of tests/test_mp_flags_gpu.py); a combination that is not built
+    # (the LayerNorm form under rotation modulation) still refuses
     from mapdit_amd import train
     args = train.build_parser().parse_args(["--synthetic", "--results-dir", "unused", "--no-use-forced-weight-normalization",
                                             "--model", "DiT-XS/8", "--num-classes", "10"])
     args.in_channels, args.input_size = 4, 32
     assert train.get_model(args).forced_weight_normalization is False
     with pytest.raises(NotImplementedError):
-        train.main(["--synthetic", "--results-dir", "unused", "--no-use-no-layernorm", "--num-steps", "2"])
+        train.main(["--synthetic", "--results-dir", "unused", "--no-use-no-layernorm", "--use-rotation-modulation", "--num-steps", "2"])

@@ -19,7 +19,7 @@ from conftest import rel_err, sub
 from oracle import dit_oracle as O
 
 TINY = dict(depth=2, hidden_size=128, patch_size=2, input_size=16, in_channels=4, num_heads=2, num_classes=10)
-FLAGS = ["mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention"]
+FLAGS = ["mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention", "no_layernorm"]
 
 
 # ---- CPU: what each off form IS (the restatement's own invariants) -----------------------------------------------------------------------
@@ -63,15 +63,18 @@ def test_train_cli_accepts_the_built_off_forms_and_refuses_the_rest():
     from mapdit_amd import train
     p = train.build_parser()
     a = p.parse_args(["--synthetic", "--results-dir", "/tmp/x", "--no-use-mp-silu", "--no-use-mp-residual", "--no-use-mp-pos-enc", "--no-use-mp-embedding",
-                      "--no-use-weight-normalization", "--no-use-cosine-attention"])
-    assert (a.use_mp_silu, a.use_mp_residual, a.use_mp_pos_enc, a.use_mp_embedding, a.use_weight_normalization, a.use_cosine_attention) == (False,) * 6
-    assert a.use_no_layernorm
-    assert set(train.BUILT_OFF_FORMS) == {"mp-silu", "mp-residual", "mp-pos-enc", "mp-embedding", "weight-normalization", "cosine-attention"}
+                      "--no-use-weight-normalization", "--no-use-cosine-attention", "--no-use-no-layernorm"])
+    assert (a.use_mp_silu, a.use_mp_residual, a.use_mp_pos_enc, a.use_mp_embedding, a.use_weight_normalization, a.use_cosine_attention,
+            a.use_no_layernorm) == (False,) * 7 and a.use_forced_weight_normalization
+    assert set(train.BUILT_OFF_FORMS) == {"mp-silu", "mp-residual", "mp-pos-enc", "mp-embedding", "weight-normalization", "cosine-attention", "no-layernorm"}
     a.in_channels, a.input_size = 4, 32                # (main() fills these in from the data set / --synthetic)
-    assert train.get_model(a).weight_normalization is False and train.get_model(a).cosine_attention is False
-    for flag in ("no-layernorm",):
-        with pytest.raises(NotImplementedError):
-            train.main(["--synthetic", "--results-dir", "/tmp/x", f"--no-use-{flag}", "--num-steps", "1"])
+    m = train.get_model(a)
+    assert (m.weight_normalization, m.cosine_attention, m.no_layernorm) == (False,) * 3
+    # what stays refused: the off forms under the fp32-accurate engine, and the LayerNorm form under rotation modulation
+    with pytest.raises(NotImplementedError):
+        train.main(["--synthetic", "--results-dir", "/tmp/x", "--no-use-mp-silu", "--precision", "bf16x3", "--num-steps", "1"])
+    with pytest.raises(NotImplementedError):
+        train.main(["--synthetic", "--results-dir", "/tmp/x", "--no-use-no-layernorm", "--use-rotation-modulation", "--num-steps", "1"])
 
 
 def test_facade_builds_the_off_forms():
@@ -97,7 +100,7 @@ LIMITS = {  # logits, loss, gradient tensor (>= 64 entries), scalar gains (of th
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-@pytest.mark.parametrize("off", [("mp_silu",), ("mp_residual",), ("mp_pos_enc",), ("mp_embedding",), ("weight_normalization",), ("cosine_attention",), tuple(FLAGS)])
+@pytest.mark.parametrize("off", [("mp_silu",), ("mp_residual",), ("mp_pos_enc",), ("mp_embedding",), ("weight_normalization",), ("cosine_attention",), ("no_layernorm",), tuple(FLAGS)])
 def test_engine_off_forms_match_the_restatement(off, precision):
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.dit import DiT

@@ -102,7 +102,7 @@ def test_train_harness_synthetic(tmp_path):
     log = open(os.path.join(exp, "log.txt")).read()
     assert "(step=0000004) train loss:" in log and "train steps/sec:" in log
     with pytest.raises(NotImplementedError):
-        train.main(["--synthetic", "--results-dir", str(tmp_path), "--no-use-no-layernorm", "--num-steps", "2"])
+        train.main(["--synthetic", "--results-dir", str(tmp_path), "--no-use-no-layernorm", "--use-rotation-modulation", "--num-steps", "2"])
     # the fp32-accurate engine through the same harness
     exp2 = train.main(["--synthetic", "--results-dir", str(tmp_path), "--model", "DiT-XS/2", "--num-steps", "2", "--batch-size", "8",
                        "--log-every", "1", "--ckpt-every", "2", "--ema-snapshot-every", "2", "--num-classes", "10",
