@@ -256,7 +256,8 @@ def main():
     ap.add_argument("--rotation-modulation", action="store_true",
                     help="BASELINE config 3's block conditioning (README.md:1-3; not in the reference snapshot: parity unpinned)")
     ap.add_argument("--mp-off", default="", help="comma-separated off forms of the README's --use-* flags: mp_silu, mp_residual, mp_pos_enc, "
-                                                 "mp_embedding (README.md:57-66; not in the reference snapshot: parity unpinned)")
+                                                 "mp_embedding, weight_normalization, cosine_attention, no_layernorm (README.md:57-66; not in the "
+                                                 "reference snapshot: parity unpinned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -290,7 +291,8 @@ def main():
     global_batch = B * world
 
     mp_off = [f.strip() for f in args.mp_off.split(",") if f.strip()]
-    assert all(f in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding") for f in mp_off), f"--mp-off: unknown flag in {mp_off}"
+    assert all(f in ("mp_silu", "mp_residual", "mp_pos_enc", "mp_embedding", "weight_normalization", "cosine_attention", "no_layernorm")
+               for f in mp_off), f"--mp-off: unknown flag in {mp_off}"
     unpinned = bool(args.rotation_modulation or mp_off)      # configurations with no reference code behind them
 
     def timed_run(precision, steps, warmup):
@@ -398,7 +400,7 @@ def main():
             "pinned": False,
             "note": "off forms of the README's --use-* flags (README.md:57-66) are not in the reference snapshot, which hard-wires every flag "
                     "on (SURVEY F5): there is no reference output to compare with.  The engine is held to this repo's own restatement "
-                    "(oracle.dit_oracle.DiTConfig.mp_*; tests/test_mp_flags_gpu.py): parity unpinned"} if mp_off else {
+                    "(oracle.dit_oracle.DiTConfig; tests/test_mp_flags_gpu.py): parity unpinned"} if mp_off else {
             "pinned": False,
             "note": "rotation modulation is described in the reference's README but absent from its code snapshot (SURVEY F6): there "
                     "is no reference output to compare with.  The engine is held to this repo's own restatement of the README "
