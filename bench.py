@@ -387,7 +387,8 @@ def main():
         "dtype": {"bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3 (two-term split bf16 operands, fp32 accumulate and storage)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{args.model} full training step on 32x32x4 latents (fresh batch+fwd+loss+bwd+grad reduction+Adam+"
-                               f"2xEMA), all magnitude-preserving features on, {'fp16' if args.precision == 'f16' else 'bf16'} GEMM operands / "
+                               f"2xEMA), {'magnitude-preserving features OFF: ' + ', '.join(mp_off) + ' (README off forms, parity unpinned)' if mp_off else 'all magnitude-preserving features on'}, "
+                               f"{'fp16' if args.precision == 'f16' else 'bf16'} GEMM operands / "
                                "fp32 accumulate, master and residual fp32",
                    "global_batch": global_batch, "per_gpu_batch": B, "tokens_per_sample": T, "parallelism": f"dp{world}",
                    "grad_comm": r["grad_comm"],

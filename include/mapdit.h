@@ -32,8 +32,9 @@ extern "C" {
 
 /* Thread-local message of the last non-zero status returned on this thread. */
 const char* mapdit_last_error(void);
-int mapdit_abi_version(void);   /* 5: mapdit_weightnorm_bwd_slim (the Jacobian beside a GEMM on another stream); mapdit_config_t.mp_off (off forms of four
-                                 * --use-* flags), mapdit_patch_embed_fwd(out_scale), mapdit_scale_copy.  4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
+int mapdit_abi_version(void);   /* 5: mapdit_weightnorm_bwd_slim (the Jacobian beside a GEMM on another stream); mapdit_config_t.mp_off (off forms of seven
+                                 * --use-* flags: MAPDIT_OFF_*, with MAPDIT_WN_PLAIN / mapdit_wn_job_t.flags, mapdit_attn_sdpa_fwd, mapdit_heads_merge_bwd,
+                                 * mapdit_ln_modulate_fwd, mapdit_ln_bwd_merge), mapdit_patch_embed_fwd(out_scale), mapdit_scale_copy.  4: non-finite gradient guard (mapdit_grad_nonfinite_check, mapdit_adam_ema_step_guarded), mapdit_engine_set_loss_scale /
                                  * mapdit_engine_loss_scale, loss_scale must be a power of two.  3: _f16 twins; grad scale arguments (final_out_bwd, rot_coef_bwd, resid_mod_bwd_t.dgain_scale); rot_* (fused rotation);
                                  * mapdit_config_t.loss_scale.  2: cond_combine_* take table_rows; adam_ema_step_scalars; comm_* */
 
