@@ -32,7 +32,9 @@ def main():
         junk = torch.full((1 << 28,), int(os.environ["MAPDIT_TEST_POISON"]), dtype=torch.uint8, device=dev)
         del junk
     torch.manual_seed(21)
-    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7).to(dev).train()
+    import json
+    kw = json.loads(os.environ.get("MAPDIT_TEST_MODEL_KW", "{}"))        # e.g. off forms of the README flags: {"weight_normalization": false}
+    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7, **kw).to(dev).train()
     m.gemm_precision = precision
     if precision == "f16":
         m.loss_scale = 1024.0                               # (the automatic choice depends on the per-rank batch: fixed, a sample's bits do not)

@@ -417,6 +417,21 @@ def test_two_rank_sharded_weight_passes(tmp_path, precision):
     assert abs(zw3[0]["loss"] - zw3[1]["loss"]) < 1.0 and zw3[0]["refused"] == 0
 
 
+def test_two_rank_sharded_weight_passes_with_off_forms(tmp_path, monkeypatch):
+    """The README off forms that touch the weight passes and the block's structure (weight normalisation off: MAPDIT_WN_PLAIN in the sharded
+    imaging and Jacobian jobs; plain attention; the LayerNorm form) under --grad-comm zero1w, two ranks: replicas bit-identical after gather_state
+    and equal to the replicated all-reduce run of the same network up to fp32 rounding."""
+    monkeypatch.setenv("MAPDIT_TEST_MODEL_KW", '{"weight_normalization": false, "cosine_attention": false, "no_layernorm": false}')
+    ar = _run_dp(tmp_path, "ar", 2, "allreduce", "f16", steps=1)
+    zw = _run_dp(tmp_path, "zw", 2, "zero1w", "f16", steps=1)
+    for k in ("p", "m", "v", "e0", "e1"):
+        assert torch.equal(zw[0][k], zw[1][k]) and torch.isfinite(zw[0][k]).all(), k
+        assert rel_err(zw[0][k].numpy(), ar[0][k].numpy()) < 2e-5, k
+    monkeypatch.delenv("MAPDIT_TEST_MODEL_KW")
+    on = _run_dp(tmp_path, "on", 2, "allreduce", "f16", steps=1)
+    assert not torch.equal(on[0]["p"], ar[0]["p"])            # (the flags reached the workers: another network)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL with more than one rank")
 def test_two_gpu_rccl_data_parallel(tmp_path):
     """The same two-rank run with ONE GPU PER RANK and RCCL collectives (the in-place all_gather_into_tensor /
