@@ -536,7 +536,9 @@ int pick_split_k(int rows, int cols, int K, long max_slabs) {
     const int units = K / 64;
     // One full round of the chip (256 CUs x 1 workgroup of the 256^2 kernel, x 2 of the 128^2 kernel): every block
     // gets the longest possible K loop and there is no partially filled tail round.  Slab ranges may be uneven.
-    long want = (edge == 256 ? 256 : 512) / tiles;
+    // (MAPDIT_SPLITK_SLOTS128 = workgroups a split launch of the 128^2 kernel aims at, default 512 = two per CU: A/B runs, round 5)
+    static const int slots128 = [] { const char* v = getenv("MAPDIT_SPLITK_SLOTS128"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
+    long want = (edge == 256 ? 256 : slots128) / tiles;
     if (want > max_slabs) want = max_slabs;
     if (want > units / 4) want = units / 4;                             // keep >= 4 K-tiles per block
     return want < 1 ? 1 : (int)want;
