@@ -104,6 +104,20 @@ typedef struct {
 
 int mapdit_gemm_bf16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
                      const mapdit_epilogue_t* epi, void* stream);
+/* Several weight-gradient products as ONE launch (abi 5): out_i [M_i, N_i] fp32 (ldo_i) = alpha_i * A_i^T B_i with A_i [K, M_i] (lda_i), B_i [K, N_i]
+ * (ldb_i) 16-bit and the SAME K; with split_k > 1 slab z of item i lies z * slab_stride_i floats behind out_i (as MAPDIT_EPI_STORE_F32 with
+ * split_k).  For shapes whose own tiles x slabs leave the chip part empty (DiT-XL: 90 tiles x 2 of 256 CUs) while a block's gradients
+ * together fill it (250 tiles, no cut).  At most 4 items, all on the MFMA path: K % 64 == 0; M, N, lda, ldb multiples of 8; 16-byte aligned
+ * operands.  Same bits as single launches with the same split_k.  Autograd of src/basic/mp_linear.py:46 (F.linear) wrt the weight. */
+typedef struct {
+    const uint16_t* A; int lda;
+    const uint16_t* B; int ldb;
+    int M, N;
+    float* out; int ldo;
+    float alpha;
+    long slab_stride;
+} mapdit_gemm_group_item_t;
+int mapdit_gemm_group_tn_bf16(int n, const mapdit_gemm_group_item_t* items, int K, int split_k, void* stream);
 /* Edge (128 or 256) of the output tile the dispatcher picks for an [M, N] result (to size split_k). */
 int mapdit_gemm_tile_size(int M, int N);
 /* The same for a launch that will cut K (split_k > 1): such launches fill the chip through the cut, so the 256 edge is kept
@@ -551,6 +565,7 @@ int mapdit_allgather_bucket(mapdit_comm_t* comm, float* buf, long count, void* s
  * ------------------------------------------------------------------------------------------------------------ */
 int mapdit_gemm_f16(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb,
                     const mapdit_epilogue_t* epi, void* stream);
+int mapdit_gemm_group_tn_f16(int n, const mapdit_gemm_group_item_t* items, int K, int split_k, void* stream);
 int mapdit_weightnorm_fwd_f16(float* W, int rows, int cols, int forced, float out_scale, uint16_t* w_f16, float* w_f32,
                               float* inv, void* stream);
 int mapdit_weightnorm_fwd_batch_f16(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, int forced, void* stream);

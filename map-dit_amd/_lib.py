@@ -35,6 +35,10 @@ class ResidModBwd(C.Structure):
                 ("gain_partials_out", C.POINTER(ci)), ("dgain_out", vp), ("rot", ci), ("dgain_scale", cf), ("dxo_bf", vp), ("ldx", ci)]
 
 
+class GemmGroupItem(C.Structure):  # mapdit_gemm_group_item_t
+    _fields_ = [("A", vp), ("lda", ci), ("B", vp), ("ldb", ci), ("M", ci), ("N", ci), ("out", vp), ("ldo", ci), ("alpha", cf), ("slab_stride", cl)]
+
+
 class WnJob(C.Structure):          # mapdit_wn_job_t
     _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp),
                 ("w_split3", vp), ("flags", ci)]
@@ -75,6 +79,7 @@ PEEK_IDS = {name: i for i, name in enumerate(
 # name -> argtypes for every status-returning entry point of include/mapdit.h
 _SIGS = {
     "mapdit_gemm_bf16": [ci, ci, ci, ci, vp, ci, vp, ci, C.POINTER(Epilogue), vp],
+    "mapdit_gemm_group_tn_bf16": [ci, vp, ci, ci, vp],
     "mapdit_weightnorm_fwd": [vp, ci, ci, ci, cf, vp, vp, vp, vp],
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_bwd_slim": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
@@ -155,7 +160,7 @@ for _n in ("weightnorm_fwd", "weightnorm_fwd_batch", "modulate_fwd", "resid_mod_
            "qkv_merge_bwd", "attn_cos_fwd", "attn_cos_fwd_rawqk", "attn_cos_fwd_rawqk_save", "attn_cos_bwd", "attn_cos_bwd_fused", "attn_sdpa_fwd", "heads_merge_bwd", "ln_modulate_fwd", "ln_bwd_merge", "qkv_split_generic", "qkv_merge_bwd_generic",
            "attn_generic_fwd", "attn_generic_bwd", "patch_embed_fwd", "cond_combine_fwd", "cond_combine_bwd", "final_out_bwd"):
     _SIGS[f"mapdit_{_n}_f16"] = _SIGS[f"mapdit_{_n}"]
-for _b, _h in (("gemm_bf16", "gemm_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),
+for _b, _h in (("gemm_bf16", "gemm_f16"), ("gemm_group_tn_bf16", "gemm_group_tn_f16"), ("f32_to_bf16", "f32_to_f16"), ("f32_to_bf16_2d", "f32_to_f16_2d"),
                ("mpsilu_to_bf16", "mpsilu_to_f16")):
     _SIGS[f"mapdit_{_h}"] = _SIGS[f"mapdit_{_b}"]
 # entry points that do not return a status

@@ -42,6 +42,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 #define MD_SYM(name) mapdit_##name##_f16
 #define MD_TU(name) name##_f16
 #define MD_SYM_GEMM mapdit_gemm_f16
+#define MD_SYM_GEMM_GROUP mapdit_gemm_group_tn_f16
 #define MD_SYM_F32_TO_16 mapdit_f32_to_f16
 #define MD_SYM_F32_TO_16_2D mapdit_f32_to_f16_2d
 #define MD_SYM_MPSILU_TO_16 mapdit_mpsilu_to_f16
@@ -49,6 +50,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 #define MD_SYM(name) mapdit_##name
 #define MD_TU(name) name
 #define MD_SYM_GEMM mapdit_gemm_bf16
+#define MD_SYM_GEMM_GROUP mapdit_gemm_group_tn_bf16
 #define MD_SYM_F32_TO_16 mapdit_f32_to_bf16
 #define MD_SYM_F32_TO_16_2D mapdit_f32_to_bf16_2d
 #define MD_SYM_MPSILU_TO_16 mapdit_mpsilu_to_bf16

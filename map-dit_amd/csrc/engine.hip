@@ -77,6 +77,12 @@ struct mapdit_engine {
     bool ln = false;
     std::vector<float*> XH, rstd;
     float *ln_g = nullptr, *ln_s = nullptr;
+    // Round 5: the three large weight gradients of a block (fc2, fc1, QKV) as ONE launch when that fills the chip better than a launch each
+    // (mapdit_gemm_group_tn_*; DiT-XL: 250 tiles uncut against 180 + 180 + 210 workgroups).  linear_dw queues them; the QKV one flushes.
+    struct PendingDw { int pidx; const bf16_t* dy; int ld_dy; const bf16_t* x; int ld_x; float alpha; };
+    std::vector<PendingDw> dw_pending;
+    int dw_group_K = -1, dw_group_split = 0;       // the decision for reduction length dw_group_K: 0 = a launch each, s >= 1 = grouped with s slabs
+    bf16_t* dy2 = nullptr;                         // grad of the attention branch output (dy keeps the MLP branch's until the group is flushed)
     bool sdpa = false;         // MAPDIT_OFF_COSINE_ATTN: q, k go into the attention unnormalised (raw head-major epilogue, mapdit_attn_sdpa_fwd, unfused backward)
     int wn_plain = 0;          // MAPDIT_WN_PLAIN under MAPDIT_OFF_WEIGHT_NORM: OR-ed into the flags of every linear's weight pass
     bool f16 = false;                     // MAPDIT_PREC_F16: every 16-bit operand is IEEE fp16 (the _f16 entry points), else bf16
@@ -366,6 +372,7 @@ size_t carve(mapdit_engine* e, void* base) {
         e->gain_part = cv.take<float>((size_t)8 * N * (D / 128));      // x8: the row-split form of resid_mod_bwd (small batches)
         e->rmb_part = cv.take<float>((size_t)8 * N * 3 * D);
         e->dy = cv.take<bf16_t>(M * D);
+        e->dy2 = cv.take<bf16_t>(M * D);
         e->dh = cv.take<bf16_t>(M * Hm);
         e->dxm = cv.take<bf16_t>(M * D);
         e->dO = cv.take<bf16_t>(M * D);
@@ -675,8 +682,77 @@ int side_join(mapdit_engine* e, void* st) {
     return g_claim(e, 1, st);
 }
 
+// Decides, for reduction length K, whether a block's fc2 / fc1 / QKV weight gradients run as one grouped launch: all three on the 256^2 MFMA
+// path, their tiles together within one round of the chip, the slabs within G, and the grouped launch's K per workgroup at least 15 % below the
+// sum of the three launches' (each cut by pick_split_k).  MAPDIT_DW_GROUP=0: never; =2: whenever feasible (A/B).  Returns the slab count or 0.
+int dw_group_split(mapdit_engine* e, int K) {
+    if (e->dw_group_K == K) return e->dw_group_split;
+    e->dw_group_K = K;
+    e->dw_group_split = 0;
+    static const int mode = [] { const char* v = getenv("MAPDIT_DW_GROUP"); return v ? atoi(v) : 1; }();
+    if (mode == 0 || K % 64 != 0 || e->shard_world > 1 || e->side_jac || e->cfg.precision == MAPDIT_PREC_BF16X3) return 0;
+    const int which[3] = {MAPDIT_B_FC2, MAPDIT_B_FC1, MAPDIT_B_QKV};
+    long tiles = 0, elems = 0;
+    double separate = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const WeightImg& w = e->wimg[pidx_block(0, which[k])];
+        if (w.rows % 8 != 0 || w.cols % 8 != 0 || mapdit_gemm_tile_size_k(w.rows, w.cols, K, 1) != 256) return 0;
+        tiles += (long)cdiv(w.rows, 256) * cdiv(w.cols, 256);
+        elems += (long)w.rows * w.cols;
+        separate += (double)K / pick_split_k(w.rows, w.cols, K, e->G_cap / ((long)w.rows * w.cols));
+    }
+    if (tiles > 256) return 0;
+    long s = 256 / tiles;
+    if (s > (K / 64) / 4) s = (K / 64) / 4;
+    if (s < 1 || elems * s > e->G_cap) return 0;
+    if (mode != 2 && (double)K / s > 0.85 * separate) return 0;
+    e->dw_group_split = (int)s;
+    return e->dw_group_split;
+}
+
+int dw_group_flush(mapdit_engine* e, int K, void* st) {
+    const int S = e->dw_group_split;
+    mapdit_gemm_group_item_t items[4];
+    float* outs[4];
+    long off = 0;
+    const int n = (int)e->dw_pending.size();
+    for (int k = 0; k < n; ++k) {
+        const mapdit_engine::PendingDw& q = e->dw_pending[k];
+        const WeightImg& w = e->wimg[q.pidx];
+        outs[k] = e->G + off;
+        items[k] = mapdit_gemm_group_item_t{q.dy, q.ld_dy, q.x, q.ld_x, w.rows, w.cols, outs[k], w.cols, q.alpha * e->ginv, (long)w.rows * w.cols};
+        off += (long)w.rows * w.cols * S;
+    }
+    TRY(g_claim(e, 0, st));
+    TRY((e->f16 ? mapdit_gemm_group_tn_f16 : mapdit_gemm_group_tn_bf16)(n, items, K, S, st));
+    for (int k = 0; k < n; ++k) {
+        const mapdit_engine::PendingDw& q = e->dw_pending[k];
+        const WeightImg& w = e->wimg[q.pidx];
+        TRY(mapdit_weightnorm_bwd(e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain, st));
+    }
+    e->dw_pending.clear();
+    return MAPDIT_OK;
+}
+
 int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf16_t* x, int ld_x, int K, float alpha, void* st) {
     const WeightImg& w = e->wimg[pidx];
+    if (pidx >= MAPDIT_NUM_GLOBAL && e->grads[pidx]) {
+        const int which = (pidx - MAPDIT_NUM_GLOBAL) % MAPDIT_NUM_BLOCK;
+        if ((which == MAPDIT_B_FC2 || which == MAPDIT_B_FC1 || which == MAPDIT_B_QKV) && dw_group_split(e, K) > 0) {
+            e->dw_pending.push_back(mapdit_engine::PendingDw{pidx, dy, ld_dy, x, ld_x, alpha});
+            if (which != MAPDIT_B_QKV) return MAPDIT_OK;      // (the block's backward reaches fc2, fc1, then QKV: the last one launches)
+            if (e->dw_pending.size() == 3) return dw_group_flush(e, K, st);
+            // (a block entered half-way cannot happen - stages are whole blocks - but never leave a gradient unwritten: a launch each)
+            std::vector<mapdit_engine::PendingDw> rest;
+            rest.swap(e->dw_pending);
+            const int keep = e->dw_group_split;
+            e->dw_group_split = 0;
+            int rc = MAPDIT_OK;
+            for (const auto& q : rest) if (rc == MAPDIT_OK) rc = linear_dw(e, q.pidx, q.dy, q.ld_dy, q.x, q.ld_x, K, q.alpha, st);
+            e->dw_group_split = keep;
+            return rc;
+        }
+    }
     // Few output tiles, very long K (= tokens): cut K into slabs so the launch fills the chip; the slabs are summed,
     // in a fixed order, by the weight-norm backward that consumes G anyway.
     const long slab = (long)w.rows * w.cols;
@@ -933,6 +1009,7 @@ extern "C" int mapdit_engine_set_shard(mapdit_engine_t* e, int rank, int world) 
     MD_CHECK(e && world >= 1 && rank >= 0 && rank < world, "engine_set_shard: bad rank %d of %d", rank, world);
     MD_CHECK(e->train && e->cfg.precision != MAPDIT_PREC_BF16X3, "engine_set_shard: a training engine in bf16 / f16 precision");
     e->shard_rank = rank; e->shard_world = world;
+    e->dw_group_K = -1;                                    // (the grouped weight-gradient launch is not taken with sharded weight passes: decide again)
     e->sharded.assign(e->params.size(), 0);
     if (world > 1)
         for (int i = 0; i < e->cfg.depth; ++i)
@@ -1439,6 +1516,7 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
     auto W = [&](int idx) { return e->wimg[idx].img; };
     auto G = [&](int idx) { return e->grads[idx]; };
     if (stage_from == 0) {
+    e->dw_pending.clear();
     // fp16: the whole backward runs on gradients multiplied by a power of two (mapdit_config_t.loss_scale) so that the 16-bit
     // activation gradients sit in fp16's normal range; each parameter gradient is divided by it where it is written (the dW GEMMs'
     // alpha, the weight-norm Jacobian's scale, the gain partials).  bf16 has fp32's exponent range: scale 1.
@@ -1509,16 +1587,16 @@ extern "C" int mapdit_engine_backward_stages(mapdit_engine_t* e, const float* do
             a.x = e->X[2 * i + 1]; a.shift = sh_m; a.scale = sc_m;
             a.gain = e->rot ? e->zero_gain : e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]; a.ldmod = ldn;
             a.dshift = dmod + e->o_shm; a.dscale = dmod + e->o_scm; a.ldd = ldm; a.dgain_part = e->gain_part;
-            a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
+            a.y_up = b.y; a.g_up = mod + e->o_ga; a.ldg_up = ldm; a.dy_up = e->dy2; a.dg_up = dmod + e->o_ga; a.ldd_up = ldm;
             if (e->dx16) a.dx_bf = e->DXb16; else a.dx = e->DXb;
             a.n_samples = N; a.T = T; a.D = D; a.ca = e->ca; a.cb = e->cb_attn;       // (the residual above: this block's attention branch)
             const RotBwd rb{mod + e->o_shm, mod + e->o_scm, dmod + e->o_shm, dmod + e->o_scm, e->params[pidx_block(i, MAPDIT_B_GAIN_MLP)]};
             TRY(dx_resid_mod_bwd(e, M, Hm, e->dh, Hm, W(pidx_block(i, MAPDIT_B_FC1)), a, G(pidx_block(i, MAPDIT_B_GAIN_MLP)), st,
                                  e->rot ? &rb : nullptr));
         }
-        // attention branch: dy now holds the grad of the attention branch output y_i
-        TRY(gemm16(e, MAPDIT_NN, M, D, D, e->dy, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
-        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy, D, b.o, D, M, 1.f, st));
+        // attention branch: dy2 holds the grad of the attention branch output y_i (its own buffer: dy may still wait for the grouped launch)
+        TRY(gemm16(e, MAPDIT_NN, M, D, D, e->dy2, D, W(pidx_block(i, MAPDIT_B_PROJ)), D, epi_bf16(e->dO, D), st));
+        TRY(linear_dw(e, pidx_block(i, MAPDIT_B_PROJ), e->dy2, D, b.o, D, M, 1.f, st));
         if (e->sdpa) {               // the unfused backward knows nothing of a normalisation: p = exp(s - lse); then the head merge alone
             TRY(DT_FN(e, mapdit_attn_cos_bwd)(b.qn, b.kn, b.v, e->dO, b.o, b.lse, e->delta, e->dqn, e->dkn, e->dv, N, T, H, e->hd, st));
             TRY(DT_FN(e, mapdit_heads_merge_bwd)(e->dqn, e->dkn, e->dv, N, T, H, e->hd, e->dqkv, st));

@@ -1538,6 +1538,34 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma256_kernel(GemmP p, Epi epi) 
     }
 }
 
+// ---- round 5: SEVERAL weight-gradient GEMMs (TN, fp32 store, same reduction length) as ONE launch ---------------------------------
+// A weight gradient is cut along K until its tiles fill the chip once (pick_split_k); DiT-XL's shapes do not divide: [4608, 1152] = 90 tiles
+// of 256^2 x 2 slabs = 180 workgroups on 256 CUs, [3456, 1152] = 70 x 3 = 210.  The three large gradients of a block together are 250 tiles:
+// one launch, no cut at all - every workgroup runs the whole reduction of one tile, the chip is 98 % full instead of 70-82 %, and the
+// Jacobians that follow read one slab instead of two or three.  A workgroup finds its problem by its tile index; inside the problem the
+// tile order (band-major, XCD remap) is the single launch's.
+constexpr int GROUP_MAX = 4;
+struct GroupArgs {
+    GemmP p[GROUP_MAX];
+    EpiStoreF32 e[GROUP_MAX];
+    int first[GROUP_MAX + 1];      // first[i] = virtual workgroups (tiles x split_k) of the problems before i; first[n] = all
+    int n;
+};
+__global__ __launch_bounds__(512, 2) void gemm_mfma256_group_kernel(GroupArgs g) {
+#ifdef MAPDIT_GEMM_STAMPS
+    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES + (2 * STAMP_TILES * STAMP_POINTS + 8) * 8];
+#else
+    __shared__ __attribute__((aligned(16))) char smem[SMEM2_BYTES];
+#endif
+    const int total = g.first[g.n];
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        int i = 0;
+        while (i + 1 < g.n && v >= g.first[i + 1]) ++i;
+        gemm256_tile<OP_KMAJ, OP_KMAJ, EpiStoreF32, false, 2, false>(g.p[i], g.e[i], smem, v - g.first[i], g.first[i + 1] - g.first[i]);
+        __syncthreads();
+    }
+}
+
 // ---- round 4: the same K loop with a WAVE-PRIVATE epilogue and the next tile's prologue under it -----------------------------
 // Where a 256x256x768 tile's time went in the kernel above: fill 4.3 k cycles + K loop 34.4 k + epilogue
 // 9.2 k (bf16 store) ... 22 k (SiLU + derivative), the matrix pipe idle outside the K loop.  Two things change here, the K loop
@@ -2610,6 +2638,35 @@ void mapdit_set_error(const char* fmt, ...) {
 extern "C" const char* mapdit_last_error(void) { return g_err; }
 extern "C" int mapdit_abi_version(void) { return 5; }
 #endif
+
+// Several TN products out_i[M_i, N_i] (fp32, split_k slabs slab_stride_i apart) = alpha_i * A_i^T B_i over the SAME K rows, one launch of the
+// 256^2 kernel (gemm_mfma256_group_kernel).  Every item must be on the MFMA path (K % 64 == 0, M_i, N_i, lda_i, ldb_i multiples of 8,
+// 16-byte aligned operands); the same accumulation order as a single launch with the same split_k: the same bits.
+extern "C" int MD_SYM_GEMM_GROUP(int n, const mapdit_gemm_group_item_t* items, int K, int split_k, void* stream) {
+    MD_CHECK(items && n >= 1 && n <= GROUP_MAX, "gemm_group: 1..%d items", GROUP_MAX);
+    MD_CHECK(K > 0 && K % BKT == 0 && split_k >= 1 && split_k <= K / BKT, "gemm_group: K=%d must be a multiple of 64 and split_k=%d <= K / 64", K, split_k);
+    GroupArgs g{};
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const mapdit_gemm_group_item_t& it = items[i];
+        MD_CHECK(it.A && it.B && it.out && it.M > 0 && it.N > 0, "gemm_group: item %d: null / empty", i);
+        MD_CHECK(it.M % 8 == 0 && it.N % 8 == 0 && it.lda % 8 == 0 && it.ldb % 8 == 0 && it.lda >= it.M && it.ldb >= it.N && it.ldo >= it.N && it.ldo % 4 == 0 &&
+                 !(((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.out) & 15),
+                 "gemm_group: item %d is not on the MFMA path (M, N, lda, ldb multiples of 8; 16-byte aligned operands)", i);
+        MD_CHECK(split_k == 1 || it.slab_stride >= (long)it.M * it.ldo, "gemm_group: item %d: slab_stride too small", i);
+        GemmP& p = g.p[i];
+        p.A = (const bf16_t*)it.A; p.B = (const bf16_t*)it.B; p.lda = it.lda; p.ldb = it.ldb; p.M = it.M; p.N = it.N; p.K = K;
+        p.tiles_n = cdiv(it.N, BN2); p.tiles = cdiv(it.M, BM2) * p.tiles_n; p.split_k = split_k; p.phases = 2; p.n_off = 0; p.stagger = 0;
+        long band = (long)(2.5 * 1024 * 1024) / ((long)BN2 * (K / split_k) * 2);          // as launch(): the B sub-panel of a band within the L2
+        if (band < 4 || band > p.tiles_n) band = p.tiles_n;
+        p.band = (int)band;
+        g.e[i] = EpiStoreF32{it.out, it.ldo, it.alpha, 0, it.slab_stride};
+        g.first[i + 1] = g.first[i] + p.tiles * split_k;
+    }
+    hipLaunchKernelGGL(gemm_mfma256_group_kernel, dim3(g.first[n]), dim3(512), 0, (hipStream_t)stream, g);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
 
 extern "C" int MD_SYM_GEMM(int layout, int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B,
                                 int ldb, const mapdit_epilogue_t* e, void* stream) {

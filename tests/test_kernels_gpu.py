@@ -22,7 +22,7 @@ DEV = "cuda"
 # Every test of this file runs twice: on the bf16 entry points and on their IEEE fp16 twins (mapdit.h, "16-bit operand format").
 # MODE["dt"] is the torch dtype of the 16-bit tensors of the current pass; the library view maps a call to its _f16 form.
 MODE = {"dt": torch.bfloat16, "f16": False}
-_F16_NAMES = {"gemm_bf16": "gemm_f16", "f32_to_bf16": "f32_to_f16", "f32_to_bf16_2d": "f32_to_f16_2d", "mpsilu_to_bf16": "mpsilu_to_f16"}
+_F16_NAMES = {"gemm_bf16": "gemm_f16", "gemm_group_tn_bf16": "gemm_group_tn_f16", "f32_to_bf16": "f32_to_f16", "f32_to_bf16_2d": "f32_to_f16_2d", "mpsilu_to_bf16": "mpsilu_to_f16"}
 
 
 class _F16Calls:
@@ -239,6 +239,34 @@ def _split_k_case(L, rows, cols, K, S):
     with pytest.raises(L.MapditError):                      # more slabs than 64-wide K-tiles
         run_gemm(L, 2, to_bf(dy), to_bf(x), L.EPI_STORE_F32, rows, cols, K, out=p(slabs), ldo=cols, alpha=1.0,
                  split_k=K // 64 + 1, slab_stride=rows * cols)
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_gemm_group_equals_single_launches(L, S):
+    """mapdit_gemm_group_tn_*: the three large weight gradients of a DiT-XL block ([4608, 1152], [1152, 4608], [3456, 1152]: 90 + 90 + 70 tiles of
+    256^2, ragged fifth tile column) plus a small fourth item as ONE launch == one launch each with the same split_k, bit for bit; and the sum
+    of the slabs == the product."""
+    import numpy as np
+    K = 512
+    shapes = [(4608, 1152), (1152, 4608), (3456, 1152), (256, 264)]
+    dys = [to_bf(bf16_exact(K, r, seed=40 + i)) for i, (r, c) in enumerate(shapes)]
+    xs = [to_bf(bf16_exact(K, c, seed=50 + i)) for i, (r, c) in enumerate(shapes)]
+    single = [torch.full((S, r, c), float("nan"), device=DEV) for r, c in shapes]
+    for (r, c), dy, x, o in zip(shapes, dys, xs, single):
+        run_gemm(L, 2, dy, x, L.EPI_STORE_F32, r, c, K, out=p(o), ldo=c, alpha=0.5, split_k=S, slab_stride=r * c)
+    grouped = [torch.full((S, r, c), float("nan"), device=DEV) for r, c in shapes]
+    items = (L.GemmGroupItem * len(shapes))()
+    for i, ((r, c), dy, x, o) in enumerate(zip(shapes, dys, xs, grouped)):
+        items[i] = L.GemmGroupItem(A=p(dy), lda=r, B=p(x), ldb=c, M=r, N=c, out=p(o), ldo=c, alpha=0.5, slab_stride=r * c)
+    L.lib().gemm_group_tn_bf16(len(shapes), C.cast(items, C.c_void_p), K, S, st())
+    torch.cuda.synchronize()
+    for (r, c), dy, x, a, b in zip(shapes, dys, xs, single, grouped):
+        assert torch.equal(a, b), (r, c)
+        ref = 0.5 * (dy.float().double().t() @ x.float().double()).float()
+        assert rel_err(b.sum(0).cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    with pytest.raises(L.MapditError):                      # an item off the MFMA path (M % 8 != 0) is refused, nothing is launched
+        items[3] = L.GemmGroupItem(A=p(dys[3]), lda=256, B=p(xs[3]), ldb=264, M=250, N=264, out=p(grouped[3]), ldo=264, alpha=1.0, slab_stride=256 * 264)
+        L.lib().gemm_group_tn_bf16(len(shapes), C.cast(items, C.c_void_p), K, S, st())
 
 
 def test_gemm_identity_asymmetric(L):

@@ -390,6 +390,35 @@ def test_side_stream_jacobians_give_the_same_bits(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_grouped_weight_gradient_launch_equals_single_launches(tmp_path, precision):
+    """Round 5: at DiT-XL's width and 64 samples the fc2 / fc1 / QKV weight gradients of a block run as ONE launch without a K cut (250 tiles
+    against 180 + 180 + 210 workgroups: engine.hip dw_group_split).  Same products, another summation order (one slab instead of two or three):
+    every gradient equals the launch-each run (MAPDIT_DW_GROUP=0) to fp32 rounding, the grouped weights' gradients are NOT the same bits (the
+    grouped path did run), everything else is."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        out = tmp_path / f"g{mode}.pt"
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "dw_group_worker.py"), str(out), precision], cwd=root,
+                           env=dict(os.environ, MAPDIT_DW_GROUP=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = torch.load(out, weights_only=False)
+    assert res["1"]["loss"] == res["0"]["loss"]
+    differ = 0
+    for k, g1 in res["1"]["grads"].items():
+        g0 = res["0"]["grads"][k]
+        grouped = any(s in k for s in ("mlp.net.0.weight", "mlp.net.2.weight", "qkv_proj.weight")) and k.startswith("blocks.")
+        if grouped:
+            differ += int(not torch.equal(g0, g1))
+            assert rel_err(g1.numpy(), g0.numpy()) < 2e-6, k
+        else:
+            assert torch.equal(g0, g1), k
+    assert differ >= 4, "the grouped launch did not run (same bits everywhere)"
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_two_rank_sharded_weight_passes(tmp_path, precision):
     """--grad-comm zero1w / zero1w-bf16 (round 5): two ranks (gloo collectives, both on this box's GPU), the rows of every block linear
     split between them - each rank rewrites / images, differentiates (Jacobian), steps (Adam + EMA) ITS rows only; raw weight gradients are
