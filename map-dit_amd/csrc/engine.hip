@@ -682,9 +682,13 @@ int side_join(mapdit_engine* e, void* st) {
     return g_claim(e, 1, st);
 }
 
-// Decides, for reduction length K, whether a block's fc2 / fc1 / QKV weight gradients run as one grouped launch: all three on the 256^2 MFMA
-// path, their tiles together within one round of the chip, the slabs within G, and the grouped launch's K per workgroup at least 15 % below the
-// sum of the three launches' (each cut by pick_split_k).  MAPDIT_DW_GROUP=0: never; =2: whenever feasible (A/B).  Returns the slab count or 0.
+// Decides, for reduction length K, whether a block's fc2 / fc1 / QKV weight gradients run as one grouped launch of the 256^2 kernel: all three
+// MFMA-eligible, their tiles together within one round of the chip, the slabs within G, and the grouped launch at least 10 % cheaper than a
+// launch each by a small cost model in 256^2 K-tile times per CU - a 256^2 launch: its K-tiles per workgroup + 8 (fill + fp32 epilogue); a 128^2
+// launch (two workgroups per CU, ~20 % more time per flop): 0.6 x its K-tiles per workgroup + 5.  Fitted on, and checked against, same-box
+// A/B runs (profiles/r05_xl2_grouped_dw_ab.log, r05_b2_grouped_dw_by_batch.log): DiT-XL/2 at 64 / 32 samples 0.72 / 0.70 (-3.6 % / -4.7 % of
+// the step), DiT-B/2 at 32 samples 0.84 (-3 %), at 64: 1.08 (no difference), at 128 / 256: 1.16 / 1.2 (+2.2 % / +2.7 % when forced).
+// MAPDIT_DW_GROUP=0: never; =2: whenever feasible (A/B).  Returns the slab count or 0.
 int dw_group_split(mapdit_engine* e, int K) {
     if (e->dw_group_K == K) return e->dw_group_split;
     e->dw_group_K = K;
@@ -692,20 +696,22 @@ int dw_group_split(mapdit_engine* e, int K) {
     static const int mode = [] { const char* v = getenv("MAPDIT_DW_GROUP"); return v ? atoi(v) : 1; }();
     if (mode == 0 || K % 64 != 0 || e->shard_world > 1 || e->side_jac || e->cfg.precision == MAPDIT_PREC_BF16X3) return 0;
     const int which[3] = {MAPDIT_B_FC2, MAPDIT_B_FC1, MAPDIT_B_QKV};
+    const double nkt = K / 64;
     long tiles = 0, elems = 0;
     double separate = 0.0;
     for (int k = 0; k < 3; ++k) {
         const WeightImg& w = e->wimg[pidx_block(0, which[k])];
-        if (w.rows % 8 != 0 || w.cols % 8 != 0 || mapdit_gemm_tile_size_k(w.rows, w.cols, K, 1) != 256) return 0;
+        if (w.rows % 8 != 0 || w.cols % 8 != 0 || w.rows < 512 || w.cols < 256) return 0;
         tiles += (long)cdiv(w.rows, 256) * cdiv(w.cols, 256);
         elems += (long)w.rows * w.cols;
-        separate += (double)K / pick_split_k(w.rows, w.cols, K, e->G_cap / ((long)w.rows * w.cols));
+        const int si = pick_split_k(w.rows, w.cols, K, e->G_cap / ((long)w.rows * w.cols));
+        separate += mapdit_gemm_tile_size_k(w.rows, w.cols, K, 1) == 256 ? nkt / si + 8.0 : 0.6 * nkt / si + 5.0;
     }
     if (tiles > 256) return 0;
     long s = 256 / tiles;
     if (s > (K / 64) / 4) s = (K / 64) / 4;
     if (s < 1 || elems * s > e->G_cap) return 0;
-    if (mode != 2 && (double)K / s > 0.85 * separate) return 0;
+    if (mode != 2 && nkt / s + 8.0 > 0.9 * separate) return 0;
     e->dw_group_split = (int)s;
     return e->dw_group_split;
 }
