@@ -81,6 +81,7 @@ struct mapdit_engine {
     // (mapdit_gemm_group_tn_*; DiT-XL: 250 tiles uncut against 180 + 180 + 210 workgroups).  linear_dw queues them; the QKV one flushes.
     struct PendingDw { int pidx; const bf16_t* dy; int ld_dy; const bf16_t* x; int ld_x; float alpha; };
     std::vector<PendingDw> dw_pending;
+    int dw_group_n = 3;                            // 3: fc2, fc1, QKV; 4: the attention projection too (when all four fit in one round: DiT-B, not DiT-XL)
     int dw_group_K = -1, dw_group_split = 0;       // the decision for reduction length dw_group_K: 0 = a launch each, s >= 1 = grouped with s slabs
     bf16_t* dy2 = nullptr;                         // grad of the attention branch output (dy keeps the MLP branch's until the group is flushed)
     bool sdpa = false;         // MAPDIT_OFF_COSINE_ATTN: q, k go into the attention unnormalised (raw head-major epilogue, mapdit_attn_sdpa_fwd, unfused backward)
@@ -695,25 +696,32 @@ int dw_group_split(mapdit_engine* e, int K) {
     e->dw_group_split = 0;
     static const int mode = [] { const char* v = getenv("MAPDIT_DW_GROUP"); return v ? atoi(v) : 1; }();
     if (mode == 0 || K % 64 != 0 || e->shard_world > 1 || e->side_jac || e->cfg.precision == MAPDIT_PREC_BF16X3) return 0;
-    const int which[3] = {MAPDIT_B_FC2, MAPDIT_B_FC1, MAPDIT_B_QKV};
+    const int which[4] = {MAPDIT_B_FC2, MAPDIT_B_FC1, MAPDIT_B_QKV, MAPDIT_B_PROJ};
     const double nkt = K / 64;
-    long tiles = 0, elems = 0;
-    double separate = 0.0;
-    for (int k = 0; k < 3; ++k) {
-        const WeightImg& w = e->wimg[pidx_block(0, which[k])];
-        if (w.rows % 8 != 0 || w.cols % 8 != 0 || w.rows < 512 || w.cols < 256) return 0;
-        tiles += (long)cdiv(w.rows, 256) * cdiv(w.cols, 256);
-        elems += (long)w.rows * w.cols;
-        const int si = pick_split_k(w.rows, w.cols, K, e->G_cap / ((long)w.rows * w.cols));
-        separate += mapdit_gemm_tile_size_k(w.rows, w.cols, K, 1) == 256 ? nkt / si + 8.0 : 0.6 * nkt / si + 5.0;
+    // the three large gradients, or all four of the block when those fit in one round too (the projection's 9 tiles of DiT-B ride along in CUs
+    // the launch leaves idle anyway; DiT-XL: 250 + 25 tiles do not fit)
+    for (int n = 4; n >= 3; --n) {
+        long tiles = 0, elems = 0;
+        double separate = 0.0;
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            const WeightImg& w = e->wimg[pidx_block(0, which[k])];
+            if (w.rows % 8 != 0 || w.cols % 8 != 0 || w.rows < 512 || w.cols < 256) { ok = false; break; }
+            tiles += (long)cdiv(w.rows, 256) * cdiv(w.cols, 256);
+            elems += (long)w.rows * w.cols;
+            const int si = pick_split_k(w.rows, w.cols, K, e->G_cap / ((long)w.rows * w.cols));
+            separate += mapdit_gemm_tile_size_k(w.rows, w.cols, K, 1) == 256 ? nkt / si + 8.0 : 0.6 * nkt / si + 5.0;
+        }
+        if (!ok || tiles > 256) continue;
+        long s = 256 / tiles;
+        if (s > (K / 64) / 4) s = (K / 64) / 4;
+        if (s < 1 || elems * s > e->G_cap) continue;
+        if (mode != 2 && nkt / s + 8.0 > 0.9 * separate) continue;
+        e->dw_group_split = (int)s;
+        e->dw_group_n = n;
+        return e->dw_group_split;
     }
-    if (tiles > 256) return 0;
-    long s = 256 / tiles;
-    if (s > (K / 64) / 4) s = (K / 64) / 4;
-    if (s < 1 || elems * s > e->G_cap) return 0;
-    if (mode != 2 && nkt / s + 8.0 > 0.9 * separate) return 0;
-    e->dw_group_split = (int)s;
-    return e->dw_group_split;
+    return 0;
 }
 
 int dw_group_flush(mapdit_engine* e, int K, void* st) {
@@ -744,10 +752,11 @@ int linear_dw(mapdit_engine* e, int pidx, const bf16_t* dy, int ld_dy, const bf1
     const WeightImg& w = e->wimg[pidx];
     if (pidx >= MAPDIT_NUM_GLOBAL && e->grads[pidx]) {
         const int which = (pidx - MAPDIT_NUM_GLOBAL) % MAPDIT_NUM_BLOCK;
-        if ((which == MAPDIT_B_FC2 || which == MAPDIT_B_FC1 || which == MAPDIT_B_QKV) && dw_group_split(e, K) > 0) {
+        if ((which == MAPDIT_B_FC2 || which == MAPDIT_B_FC1 || which == MAPDIT_B_QKV || which == MAPDIT_B_PROJ) && dw_group_split(e, K) > 0 &&
+            (which != MAPDIT_B_PROJ || e->dw_group_n == 4)) {
             e->dw_pending.push_back(mapdit_engine::PendingDw{pidx, dy, ld_dy, x, ld_x, alpha});
-            if (which != MAPDIT_B_QKV) return MAPDIT_OK;      // (the block's backward reaches fc2, fc1, then QKV: the last one launches)
-            if (e->dw_pending.size() == 3) return dw_group_flush(e, K, st);
+            if (which != MAPDIT_B_QKV) return MAPDIT_OK;      // (the block's backward reaches fc2, fc1, the projection, then QKV: the last one launches)
+            if ((int)e->dw_pending.size() == e->dw_group_n) return dw_group_flush(e, K, st);
             // (a block entered half-way cannot happen - stages are whole blocks - but never leave a gradient unwritten: a launch each)
             std::vector<mapdit_engine::PendingDw> rest;
             rest.swap(e->dw_pending);

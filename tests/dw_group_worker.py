@@ -1,6 +1,6 @@
 """Worker of tests/test_train_gpu.py::test_grouped_weight_gradient_launch_equals_single_launches: one training forward + backward of a two-block
-DiT at DiT-XL's width (hidden 1152, 16 heads) on 64 samples (16,384 tokens: the shape at which a block's fc2 / fc1 / QKV weight gradients run as
-one grouped launch); writes the flat gradient buffer to argv[1].  MAPDIT_DW_GROUP (read once per process by the library) selects the path."""
+DiT at DiT-XL's width (hidden 1152, 16 heads) on 64 samples (16,384 tokens: a block's fc2 / fc1 / QKV weight gradients run as one grouped
+launch) or at DiT-B's (768, 12 heads) on 32 samples (all four of the block's gradients do); writes the flat gradient buffer to argv[1].  MAPDIT_DW_GROUP (read once per process by the library) selects the path."""
 import os
 import sys
 
@@ -14,9 +14,10 @@ def main():
     import mapdit_amd  # noqa: F401
     from mapdit_amd.diffusion import create_diffusion
     from mapdit_amd.src.dit import DiT
-    out, precision = sys.argv[1], sys.argv[2]
+    out, precision, width = sys.argv[1], sys.argv[2], sys.argv[3]
     torch.manual_seed(5)
-    m = DiT(depth=2, hidden_size=1152, patch_size=2, input_size=32, in_channels=4, num_heads=16, num_classes=10).to("cuda").train()
+    hidden, heads, n = (1152, 16, 64) if width == "xl" else (768, 12, 32)       # DiT-XL at 64 samples | DiT-B at 32 (the projection rides along)
+    m = DiT(depth=2, hidden_size=hidden, patch_size=2, input_size=32, in_channels=4, num_heads=heads, num_classes=10).to("cuda").train()
     m.gemm_precision = precision
     m.y_embedder.token_drop = lambda labels, force_drop_ids=None: labels
     with torch.no_grad():
@@ -24,7 +25,6 @@ def main():
             if "gain_" in k:
                 p.fill_(0.25)
     g = torch.Generator().manual_seed(6)
-    n = 64
     x, y = torch.randn(n, 4, 32, 32, generator=g).cuda(), torch.randint(0, 10, (n,), generator=g).cuda()
     t, noise = torch.randint(0, 1000, (n,), generator=g).cuda(), torch.randn(n, 4, 32, 32, generator=g).cuda()
     loss = create_diffusion("").training_losses(m, x, t, dict(y=y), noise=noise)["loss"].mean()
