@@ -695,7 +695,7 @@ int dw_group_split(mapdit_engine* e, int K) {
     e->dw_group_K = K;
     e->dw_group_split = 0;
     static const int mode = [] { const char* v = getenv("MAPDIT_DW_GROUP"); return v ? atoi(v) : 1; }();
-    if (mode == 0 || K % 64 != 0 || e->shard_world > 1 || e->side_jac || e->cfg.precision == MAPDIT_PREC_BF16X3) return 0;
+    if (mode == 0 || K % 64 != 0 || e->side_jac || e->cfg.precision == MAPDIT_PREC_BF16X3) return 0;
     const int which[4] = {MAPDIT_B_FC2, MAPDIT_B_FC1, MAPDIT_B_QKV, MAPDIT_B_PROJ};
     const double nkt = K / 64;
     // the three large gradients, or all four of the block when those fit in one round too (the projection's 9 tiles of DiT-B ride along in CUs
@@ -742,7 +742,10 @@ int dw_group_flush(mapdit_engine* e, int K, void* st) {
     for (int k = 0; k < n; ++k) {
         const mapdit_engine::PendingDw& q = e->dw_pending[k];
         const WeightImg& w = e->wimg[q.pidx];
-        TRY(mapdit_weightnorm_bwd(e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain, st));
+        if (e->shard_world > 1 && e->sharded[q.pidx])      // sharded weight passes: the RAW sum leaves for the reduce-scatter (as linear_dw's own path)
+            TRY(mapdit_reduce_slabs(e->grads[q.pidx], outs[k], S, (long)w.rows * w.cols, (long)w.rows * w.cols, st));
+        else
+            TRY(mapdit_weightnorm_bwd(e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain, st));
     }
     e->dw_pending.clear();
     return MAPDIT_OK;
