@@ -166,6 +166,13 @@ int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nslabs, long sl
  * slab), which become dW; job.out_scale as above; first_block = running sum of ceil(rows / 4).  The Jacobians of a rank's rows under
  * sharded weight passes (mapdit_engine_jacobian_shard). */
 int mapdit_weightnorm_bwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, void* stream);
+/* Up to four weights' Jacobians, each over its own slabs, in ONE launch (abi 5; behind mapdit_gemm_group_tn_*): per item the arguments of
+ * mapdit_weightnorm_bwd (flags: bit 0 accumulate, MAPDIT_WN_PLAIN); vector path only (cols, ldg, slab_stride multiples of 4, 16-byte aligned).
+ * The same bits as a launch each. */
+typedef struct {
+    const float* W; float* G; int ldg; int nslabs; long slab_stride; float* dW; int rows, cols; float out_scale; int flags;
+} mapdit_wn_bwd_item_t;
+int mapdit_weightnorm_bwd_group(int n, const mapdit_wn_bwd_item_t* items, void* stream);
 /* The same pass, same bits, in 48 registers per lane and no LDS: the form to launch on a second stream while a weight-gradient GEMM
  * (two 228-register waves per SIMD) occupies the CUs - the engine runs the Jacobian of weight i beside the GEMM of weight i + 1
  * (autograd of src/basic/mp_linear.py:38-46 needs the whole row of G: it cannot be the GEMM's epilogue). */

@@ -39,6 +39,11 @@ class GemmGroupItem(C.Structure):  # mapdit_gemm_group_item_t
     _fields_ = [("A", vp), ("lda", ci), ("B", vp), ("ldb", ci), ("M", ci), ("N", ci), ("out", vp), ("ldo", ci), ("alpha", cf), ("slab_stride", cl)]
 
 
+class WnBwdItem(C.Structure):      # mapdit_wn_bwd_item_t
+    _fields_ = [("W", vp), ("G", vp), ("ldg", ci), ("nslabs", ci), ("slab_stride", cl), ("dW", vp), ("rows", ci), ("cols", ci), ("out_scale", cf),
+                ("flags", ci)]
+
+
 class WnJob(C.Structure):          # mapdit_wn_job_t
     _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("out_scale", cf), ("first_block", ci), ("w_bf16", vp), ("w_f32", vp),
                 ("w_split3", vp), ("flags", ci)]
@@ -84,6 +89,7 @@ _SIGS = {
     "mapdit_weightnorm_bwd": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_bwd_slim": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_bwd_batch": [vp, ci, ci, vp],
+    "mapdit_weightnorm_bwd_group": [ci, vp, vp],
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],

@@ -739,14 +739,24 @@ int dw_group_flush(mapdit_engine* e, int K, void* st) {
     }
     TRY(g_claim(e, 0, st));
     TRY((e->f16 ? mapdit_gemm_group_tn_f16 : mapdit_gemm_group_tn_bf16)(n, items, K, S, st));
+    mapdit_wn_bwd_item_t jac[4];
+    int njac = 0;
     for (int k = 0; k < n; ++k) {
         const mapdit_engine::PendingDw& q = e->dw_pending[k];
         const WeightImg& w = e->wimg[q.pidx];
         if (e->shard_world > 1 && e->sharded[q.pidx])      // sharded weight passes: the RAW sum leaves for the reduce-scatter (as linear_dw's own path)
             TRY(mapdit_reduce_slabs(e->grads[q.pidx], outs[k], S, (long)w.rows * w.cols, (long)w.rows * w.cols, st));
         else
-            TRY(mapdit_weightnorm_bwd(e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain, st));
+            jac[njac++] = mapdit_wn_bwd_item_t{e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain};
     }
+    // the group's Jacobians as one launch too (vector path: the weights' columns are multiples of 8 here)
+    bool vec = true;
+    for (int k = 0; k < njac; ++k) vec = vec && jac[k].cols % 4 == 0 && !(((uintptr_t)jac[k].W | (uintptr_t)jac[k].G | (uintptr_t)jac[k].dW) & 15);
+    if (njac > 0 && vec) TRY(mapdit_weightnorm_bwd_group(njac, jac, st));
+    else
+        for (int k = 0; k < njac; ++k)
+            TRY(mapdit_weightnorm_bwd(jac[k].W, jac[k].G, jac[k].ldg, jac[k].nslabs, jac[k].slab_stride, jac[k].dW, jac[k].rows, jac[k].cols, jac[k].out_scale,
+                                      jac[k].flags, st));
     e->dw_pending.clear();
     return MAPDIT_OK;
 }

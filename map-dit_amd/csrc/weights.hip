@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_batch_kernel(const mapdit_
                              j.flags & MAPDIT_WN_PLAIN);
 }
 
+// Up to four weights' Jacobians, each over its own split-K slabs, in ONE launch (round 5: behind the grouped weight-gradient launch of gemm.hip;
+// the items arrive by value as kernel arguments - no device table).  The same row function as weightnorm_bwd_kernel<true>: the same bits.
+struct WnBwdGroup {
+    const float* W[4]; float* G[4]; float* dW[4];
+    int rows[4], cols[4], ldg[4], nslabs[4], flags[4], first[5];
+    long slab[4];
+    float scale[4];
+    int n;
+};
+__global__ __launch_bounds__(256) void weightnorm_bwd_group_kernel(WnBwdGroup g) {
+    const int blk = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && blk >= g.first[i + 1]) ++i;
+    weightnorm_bwd_row<true>(g.W[i], g.G[i], g.ldg[i], g.nslabs[i], g.slab[i], g.dW[i], (blk - g.first[i]) * 4 + (threadIdx.x >> 6), g.rows[i], g.cols[i],
+                             g.scale[i], g.flags[i]);
+}
+
 // The same pass for a SIDE STREAM (round 5): the engine runs the Jacobian of weight i beside the weight-gradient GEMM of weight i + 1.
 // A GEMM workgroup holds two 228-register waves per SIMD (464 of the 512 registers per lane after the allocation granule), so a
 // co-resident wave may own 48 registers and no LDS (tools/overlap_probe.py: a streaming kernel that fits beside the persistent GEMM hides
@@ -456,6 +473,24 @@ extern "C" int mapdit_weightnorm_bwd(const float* W, float* G, int ldg, int nsla
 #endif
 
 #if MAPDIT_DT == 0
+extern "C" int mapdit_weightnorm_bwd_group(int n, const mapdit_wn_bwd_item_t* items, void* stream) {
+    MD_CHECK(items && n >= 1 && n <= 4, "weightnorm_bwd_group: 1..4 items");
+    WnBwdGroup g{};
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const mapdit_wn_bwd_item_t& it = items[i];
+        MD_CHECK(it.W && it.G && it.dW && it.rows > 0 && it.cols > 0 && it.ldg >= it.cols && it.nslabs >= 1, "weightnorm_bwd_group: item %d: null / empty", i);
+        MD_CHECK(it.cols % 4 == 0 && it.ldg % 4 == 0 && it.slab_stride % 4 == 0 && !(((uintptr_t)it.W | (uintptr_t)it.G | (uintptr_t)it.dW) & 15),
+                 "weightnorm_bwd_group: item %d needs 16-byte aligned rows (cols, ldg, slab_stride multiples of 4)", i);
+        g.W[i] = it.W; g.G[i] = it.G; g.dW[i] = it.dW; g.rows[i] = it.rows; g.cols[i] = it.cols; g.ldg[i] = it.ldg; g.nslabs[i] = it.nslabs;
+        g.flags[i] = it.flags; g.slab[i] = it.slab_stride; g.scale[i] = it.out_scale;
+        g.first[i + 1] = g.first[i] + (it.rows + 3) / 4;
+    }
+    hipLaunchKernelGGL(weightnorm_bwd_group_kernel, dim3(g.first[n]), dim3(256), 0, (hipStream_t)stream, g);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+
 extern "C" int mapdit_weightnorm_bwd_batch(const mapdit_wn_job_t* jobs_dev, int njobs, int total_blocks, void* stream) {
     MD_CHECK(jobs_dev && njobs > 0 && total_blocks > 0, "weightnorm_bwd_batch: null/empty argument");
     hipLaunchKernelGGL(weightnorm_bwd_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);

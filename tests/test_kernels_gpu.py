@@ -496,6 +496,31 @@ def test_layernorm_modulate_and_its_backward(L, N, T, D):
         assert rel_err(o.cpu().numpy(), want.numpy()) < 1e-5, kind
 
 
+def test_weightnorm_bwd_group_equals_single_launches(L):
+    """mapdit_weightnorm_bwd_group (up to four weights, each over its own slabs, one launch) == a launch each, bit for bit - with the accumulate and
+    MAPDIT_WN_PLAIN bits per item and ragged row counts."""
+    shapes = [(768, 3072, 2, 0), (3072, 768, 3, 1), (2304, 768, 1, L.WN_PLAIN), (10, 768, 2, 0)]
+    g = torch.Generator().manual_seed(9)
+    Ws = [torch.randn(r, c, generator=g).to(DEV) for r, c, _, _ in shapes]
+    Gs = [torch.randn(S, r, c, generator=g) for r, c, S, _ in shapes]
+    outs = {}
+    for which in ("single", "group"):
+        Gd = [x.to(DEV).contiguous() for x in Gs]
+        dWs = [torch.full((r, c), 0.5, device=DEV) for r, c, _, _ in shapes]
+        if which == "single":
+            for W, G_, d, (r, c, S, fl) in zip(Ws, Gd, dWs, shapes):
+                L.lib().weightnorm_bwd(p(W), p(G_), c, S, r * c, p(d), r, c, 1.25, fl, st())
+        else:
+            items = (L.WnBwdItem * len(shapes))()
+            for i, (W, G_, d, (r, c, S, fl)) in enumerate(zip(Ws, Gd, dWs, shapes)):
+                items[i] = L.WnBwdItem(W=p(W), G=p(G_), ldg=c, nslabs=S, slab_stride=r * c, dW=p(d), rows=r, cols=c, out_scale=1.25, flags=fl)
+            L.lib().weightnorm_bwd_group(len(shapes), C.cast(items, C.c_void_p), st())
+        torch.cuda.synchronize()
+        outs[which] = [d.cpu() for d in dWs] + [x[0].cpu() for x in Gd]      # (slab 0 holds the summed slabs afterwards)
+    for a, b in zip(outs["single"], outs["group"]):
+        assert torch.equal(a, b)
+
+
 def test_weightnorm_batch_equals_single_launches(L):
     """mapdit_weightnorm_fwd_batch (one launch for every weight, device job table) against one launch per weight: bit-equal
     rewritten masters and images, for ragged row counts (rows % 4 != 0) and both output kinds."""
