@@ -318,6 +318,8 @@ int mapdit_sum_slabs(float* acc, const float* slabs, int nslabs, long slab_strid
 /* out[i] = sum over the slabs, in slab order (abi 5): a weight gradient's split-K partial sums added up WITHOUT the weight-norm Jacobian
  * (data parallelism with sharded weight passes: the raw sums are reduce-scattered, the Jacobian runs on the rows a rank owns). */
 int mapdit_reduce_slabs(float* out, const float* slabs, int nslabs, long slab_stride, long n, void* stream);
+/* The same for up to four buffers with the same slab count in ONE launch (abi 5; host arrays of n entries): behind mapdit_gemm_group_tn_*. */
+int mapdit_reduce_slabs_group(int n, float* const* outs, const float* const* slabs, const long* slab_strides, const long* ns, int nslabs, void* stream);
 /* out[i] = sum over nchunks bf16 vectors chunk_stride elements apart, accumulated in fp32 in chunk order (abi 5): the receiving side
  * of a 16-bit gradient exchange - every rank's bf16 copy of the rows this rank owns (all-to-all), summed here in fp32. */
 int mapdit_sum_bf16_chunks(float* out, const uint16_t* chunks, int nchunks, long chunk_stride, long n, void* stream);

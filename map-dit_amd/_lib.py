@@ -90,6 +90,7 @@ _SIGS = {
     "mapdit_weightnorm_bwd_slim": [vp, vp, ci, ci, cl, vp, ci, ci, cf, ci, vp],
     "mapdit_weightnorm_bwd_batch": [vp, ci, ci, vp],
     "mapdit_weightnorm_bwd_group": [ci, vp, vp],
+    "mapdit_reduce_slabs_group": [ci, vp, vp, vp, vp, ci, vp],
     "mapdit_weightnorm_fwd_batch": [vp, ci, ci, ci, vp],
     "mapdit_adam_ema_step": [vp, vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, vp],
     "mapdit_adam_ema_step_scalars": [vp, vp, vp, vp, vp, vp, cl, C.POINTER(AdamScalars), cf, cf, cf, vp],

@@ -733,22 +733,29 @@ int dw_group_flush(mapdit_engine* e, int K, void* st) {
     for (int k = 0; k < n; ++k) {
         const mapdit_engine::PendingDw& q = e->dw_pending[k];
         const WeightImg& w = e->wimg[q.pidx];
-        outs[k] = e->G + off;
+        // (sharded weight passes, no K cut: the raw sum IS the launch's result - straight into the gradient buffer, no reduction pass)
+        const bool direct = S == 1 && e->shard_world > 1 && e->sharded[q.pidx] && !((uintptr_t)e->grads[q.pidx] & 15);
+        outs[k] = direct ? e->grads[q.pidx] : e->G + off;
         items[k] = mapdit_gemm_group_item_t{q.dy, q.ld_dy, q.x, q.ld_x, w.rows, w.cols, outs[k], w.cols, q.alpha * e->ginv, (long)w.rows * w.cols};
-        off += (long)w.rows * w.cols * S;
+        if (!direct) off += (long)w.rows * w.cols * S;
     }
     TRY(g_claim(e, 0, st));
     TRY((e->f16 ? mapdit_gemm_group_tn_f16 : mapdit_gemm_group_tn_bf16)(n, items, K, S, st));
     mapdit_wn_bwd_item_t jac[4];
-    int njac = 0;
+    int njac = 0, nred = 0;
+    float* red_out[4]; const float* red_in[4]; long red_stride[4], red_n[4];
     for (int k = 0; k < n; ++k) {
         const mapdit_engine::PendingDw& q = e->dw_pending[k];
         const WeightImg& w = e->wimg[q.pidx];
-        if (e->shard_world > 1 && e->sharded[q.pidx])      // sharded weight passes: the RAW sum leaves for the reduce-scatter (as linear_dw's own path)
-            TRY(mapdit_reduce_slabs(e->grads[q.pidx], outs[k], S, (long)w.rows * w.cols, (long)w.rows * w.cols, st));
-        else
+        if (e->shard_world > 1 && e->sharded[q.pidx]) {    // sharded weight passes: the RAW sum leaves for the reduce-scatter (as linear_dw's own path)
+            if (outs[k] != e->grads[q.pidx]) {
+                red_out[nred] = e->grads[q.pidx]; red_in[nred] = outs[k]; red_stride[nred] = (long)w.rows * w.cols; red_n[nred] = (long)w.rows * w.cols;
+                ++nred;
+            }
+        } else
             jac[njac++] = mapdit_wn_bwd_item_t{e->params[q.pidx], outs[k], w.cols, S, (long)w.rows * w.cols, e->grads[q.pidx], w.rows, w.cols, 1.f, e->wn_plain};
     }
+    if (nred > 0) TRY(mapdit_reduce_slabs_group(nred, red_out, red_in, red_stride, red_n, S, st));
     // the group's Jacobians as one launch too (vector path: the weights' columns are multiples of 8 here)
     bool vec = true;
     for (int k = 0; k < njac; ++k) vec = vec && jac[k].cols % 4 == 0 && !(((uintptr_t)jac[k].W | (uintptr_t)jac[k].G | (uintptr_t)jac[k].dW) & 15);

@@ -483,6 +483,22 @@ __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __rest
     }
     *(float4*)(out + 4 * i) = a;
 }
+// The same for up to four buffers in one launch (items by value; a block = 1,024 elements of one item): behind the grouped weight-gradient launch
+// under sharded weight passes.
+struct ReduceGroup { float* out[4]; const float* slabs[4]; long stride[4], n4[4]; int first[5]; int nslabs, n; };
+__global__ void reduce_slabs_group_kernel(ReduceGroup g) {
+    int k = 0;
+    while (k + 1 < g.n && (int)blockIdx.x >= g.first[k + 1]) ++k;
+    const long i = (long)(blockIdx.x - g.first[k]) * blockDim.x + threadIdx.x;
+    if (i >= g.n4[k]) return;
+    const float* sl = g.slabs[k];
+    float4 a = *(const float4*)(sl + 4 * i);
+    for (int s = 1; s < g.nslabs; ++s) {
+        const float4 t = *(const float4*)(sl + (size_t)s * g.stride[k] + 4 * i);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *(float4*)(g.out[k] + 4 * i) = a;
+}
 // out[i] = sum_c bf16 chunks[c*stride + i] accumulated in fp32, in chunk order (8 elements per thread): the receiving side of a 16-bit
 // gradient exchange (every rank's bf16 copy of the rows this rank owns, summed in fp32)
 __global__ void sum_bf16_chunks_kernel(float* __restrict__ out, const unsigned short* __restrict__ chunks, int nchunks, long stride, long n8) {
@@ -531,6 +547,21 @@ extern "C" int mapdit_reduce_slabs(float* out, const float* slabs, int nslabs, l
     MD_CHECK(out && slabs && nslabs >= 1 && n > 0 && n % 4 == 0 && slab_stride % 4 == 0 && ((((uintptr_t)out | (uintptr_t)slabs) & 15) == 0),
              "reduce_slabs: bad argument (n and slab_stride multiples of 4, 16-byte aligned buffers)");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, slabs, nslabs, slab_stride, n / 4);
+    MD_LAUNCH_CHECK();
+    return MAPDIT_OK;
+}
+extern "C" int mapdit_reduce_slabs_group(int n, float* const* outs, const float* const* slabs, const long* slab_strides, const long* ns, int nslabs,
+                                         void* stream) {
+    MD_CHECK(outs && slabs && slab_strides && ns && n >= 1 && n <= 4 && nslabs >= 1, "reduce_slabs_group: bad argument (1..4 items)");
+    ReduceGroup g{};
+    g.n = n; g.nslabs = nslabs;
+    for (int k = 0; k < n; ++k) {
+        MD_CHECK(outs[k] && slabs[k] && ns[k] > 0 && ns[k] % 4 == 0 && slab_strides[k] % 4 == 0 && ((((uintptr_t)outs[k] | (uintptr_t)slabs[k]) & 15) == 0),
+                 "reduce_slabs_group: item %d: n and slab_stride multiples of 4, 16-byte aligned buffers", k);
+        g.out[k] = outs[k]; g.slabs[k] = slabs[k]; g.stride[k] = slab_strides[k]; g.n4[k] = ns[k] / 4;
+        g.first[k + 1] = g.first[k] + (int)cdiv(ns[k] / 4, 256);
+    }
+    hipLaunchKernelGGL(reduce_slabs_group_kernel, dim3(g.first[n]), dim3(256), 0, (hipStream_t)stream, g);
     MD_LAUNCH_CHECK();
     return MAPDIT_OK;
 }

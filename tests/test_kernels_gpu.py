@@ -521,6 +521,23 @@ def test_weightnorm_bwd_group_equals_single_launches(L):
         assert torch.equal(a, b)
 
 
+def test_reduce_slabs_group_equals_single_launches(L):
+    """mapdit_reduce_slabs_group == mapdit_reduce_slabs per buffer, bit for bit."""
+    sizes, S = [768 * 3072, 3072 * 768, 2304 * 768, 768 * 768], 2
+    g = torch.Generator().manual_seed(10)
+    slabs = [torch.randn(S, n, generator=g).to(DEV) for n in sizes]
+    single = [torch.zeros(n, device=DEV) for n in sizes]
+    group = [torch.zeros(n, device=DEV) for n in sizes]
+    for o, sl, n in zip(single, slabs, sizes):
+        L.lib().reduce_slabs(p(o), p(sl), S, n, n, st())
+    arr = lambda ty, vals: (ty * len(vals))(*vals)
+    L.lib().reduce_slabs_group(len(sizes), C.cast(arr(C.c_void_p, [p(o) for o in group]), C.c_void_p), C.cast(arr(C.c_void_p, [p(s_) for s_ in slabs]), C.c_void_p),
+                               C.cast(arr(C.c_long, sizes), C.c_void_p), C.cast(arr(C.c_long, sizes), C.c_void_p), S, st())
+    torch.cuda.synchronize()
+    for a, b, sl in zip(single, group, slabs):
+        assert torch.equal(a, b) and torch.equal(a, sl[0] + sl[1])
+
+
 def test_weightnorm_batch_equals_single_launches(L):
     """mapdit_weightnorm_fwd_batch (one launch for every weight, device job table) against one launch per weight: bit-equal
     rewritten masters and images, for ragged row counts (rows % 4 != 0) and both output kinds."""
