@@ -32,7 +32,7 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1),
                      r["Queue_Id"], int(r["VGPR_Count"])))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if "adam_ema_kernel" in r[2]]
+    adam = [i for i, r in enumerate(rows) if "adam_ema_kernel" in r[2] or "adam_ema_ranges_kernel" in r[2]]
     # optimiser launches of one step may be several (EMA ranges): step boundary = gap of > 50 dispatches between adam launches
     bounds = [adam[0]] + [adam[j] for j in range(1, len(adam)) if adam[j] - adam[j - 1] > 50]
     if len(bounds) < k + 1:
