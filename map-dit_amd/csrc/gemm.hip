@@ -757,6 +757,78 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p, Epi epi) {
     }
 }
 
+// ---- round 5: the same kernel on 64 x 128 tiles, for results of FEW 128^2 tiles --------------------------------------------------
+// DiT-XL's width leaves a 128-column strip behind the 256^2 tiles of its first 1024 columns ([16384, 128] at 64 samples: 128 workgroups of the
+// kernel above on 256 CUs, K up to 4608: 45-85 us at ~200 TFLOP/s, 141 launches = 10 % of the DiT-XL/2 step).  Half the rows per workgroup =
+// twice the workgroups; the four waves sit side by side (64 rows x 32 columns each), the A tile is 64 rows (staged by waves 0 and 1), the B
+// tile the same 128 columns.  Every output element is accumulated by the same MFMA steps in the same K order as above: the same bits.
+// A row-major only (NT / NN: what the strips are), K a multiple of 64.
+template <int BK, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_mfma64_kernel(GemmP p, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (tile / p.tiles_n) * 64, n0 = (tile % p.tiles_n) * BN;
+    const int nk = p.K / BKT;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) stage_tile<OP_ROW, false>(p.A, p.lda, m0, p.M, 0, p.K, smem, wave, lane);
+    stage_tile<BK, false>(p.B, p.ldb, n0, p.N, 0, p.K, smem + TILE_BYTES, wave, lane);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();
+        char* cur = smem + (t & 1) * BUF_BYTES;
+        if (t + 1 < nk) {
+            char* nxt = smem + ((t + 1) & 1) * BUF_BYTES;
+            if (wave < 2) stage_tile<OP_ROW, false>(p.A, p.lda, m0, p.M, (t + 1) * BKT, p.K, nxt, wave, lane);
+            stage_tile<BK, false>(p.B, p.ldb, n0, p.N, (t + 1) * BKT, p.K, nxt + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<OP_ROW>(cur, i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BK>(cur + TILE_BYTES, wave * 32 + j * 16, ks, lane);
+            if (BK == OP_KMAJ) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = i * 16 + (lane & 15);
+            const int n = wave * 32 + j * 16 + 4 * (lane >> 4);
+            *(f32x4_t*)(cs + m * CS_LD + n) = acc[i][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = (tid >> 4) + 16 * it, col = (tid & 15) * 8;
+        const int gm = m0 + row, gn = n0 + col;
+        if (gm < p.M && gn < p.N) {
+            float v[8];
+            *(f32x4_t*)(v) = *(const f32x4_t*)(cs + row * CS_LD + col);
+            *(f32x4_t*)(v + 4) = *(const f32x4_t*)(cs + row * CS_LD + col + 4);
+            epi(gm, gn + p.n_off, v, 0);
+        }
+    }
+}
+
 // ---- the large-tile kernel: 256x256x64, 8 waves (2 M x 4 N, 128x64 per wave), one workgroup per CU ---------------
 // Staggered schedule after the guide's "256^2 8-phase template", written against explicit hazard rules.  The DEFAULT loop
 // runs TWO phases per K-tile (one 64-row half of the wave's output, 32 MFMAs, per phase; see the comment at the loop): with
@@ -2595,6 +2667,20 @@ int launch(int layout, int M, int N, int K, const bf16_t* A, int lda, const bf16
             }
         }
     } else if (mfma) {
+        // Round 5: few 128^2 tiles (DiT-XL's 128-column strips: 128 or fewer workgroups on 256 CUs) -> 64-row tiles, twice the workgroups, the
+        // same bits (gemm_mfma64_kernel).  For the epilogues the strips carry.  MAPDIT_GEMM_TILE64=0 switches it off (A/B).
+        if constexpr (std::is_same<Epi, EpiResid>::value || std::is_same<Epi, EpiStoreBf16>::value) {
+            static const bool t64_env = [] { const char* v = getenv("MAPDIT_GEMM_TILE64"); return !(v && v[0] == '0'); }();
+            const long t128 = (long)cdiv(M, BM) * cdiv(N, BN);
+            if (t64_env && !a_kmaj && !ktail && split_k == 1 && t128 <= 160 && M >= 256) {
+                GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, 1, 0, 4, n_off, 0};
+                p.tiles = cdiv(M, 64) * p.tiles_n;
+                if (layout == MAPDIT_NT) hipLaunchKernelGGL((gemm_mfma64_kernel<OP_ROW, Epi>), dim3(p.tiles), dim3(256), 0, st, p, epi);
+                else hipLaunchKernelGGL((gemm_mfma64_kernel<OP_KMAJ, Epi>), dim3(p.tiles), dim3(256), 0, st, p, epi);
+                MD_LAUNCH_CHECK();
+                return MAPDIT_OK;
+            }
+        }
         GemmP p{A, B, lda, ldb, M, N, K, cdiv(N, BN), 0, split_k, 0, 4, n_off, 0};
         p.tiles = cdiv(M, BM) * p.tiles_n;
         const int grid = p.tiles * split_k;

@@ -269,6 +269,23 @@ def test_gemm_group_equals_single_launches(L, S):
         L.lib().gemm_group_tn_bf16(len(shapes), C.cast(items, C.c_void_p), K, S, st())
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 2304), (16384, 128, 1152), (1000, 256, 512), (320, 384, 64)])
+def test_gemm_64_row_tiles_give_the_128_kernel_s_bits(L, layout, M, N, K):
+    """Results of few 128^2 tiles with a 16-bit store or RESID epilogue run on 64 x 128 tiles (gemm_mfma64_kernel: DiT-XL's 128-column strips): every
+    element is accumulated by the same MFMA steps in the same K order, so a STORE_BF16 result == the fp32 result of the 128^2 kernel (STORE_F32
+    never takes the 64-row form) rounded to the operand format, bit for bit; ragged M included."""
+    a = bf16_exact(M, K, seed=71)
+    b = bf16_exact(N, K, seed=72) if layout == 0 else bf16_exact(K, N, seed=72)
+    f32 = torch.zeros(M, N, device=DEV)
+    run_gemm(L, layout, to_bf(a), to_bf(b), L.EPI_STORE_F32, M, N, K, out=p(f32), ldo=N, alpha=1.0)
+    o16 = torch.zeros(M, N, device=DEV, dtype=MODE["dt"])
+    run_gemm(L, layout, to_bf(a), to_bf(b), L.EPI_STORE_BF16, M, N, K, out=p(o16), ldo=N, alpha=1.0)
+    assert torch.equal(o16, f32.to(MODE["dt"]))
+    ref = (a.double() @ (b.double().t() if layout == 0 else b.double())).float()
+    assert rel_err(f32.cpu().numpy(), ref.numpy()) < 2e-6
+
+
 def test_gemm_identity_asymmetric(L):
     """A = I with an asymmetric B: output must be B^T exactly (guide: catches row/col swaps)."""
     N, K = 128, 128
