@@ -34,7 +34,12 @@ def main():
     torch.manual_seed(21)
     import json
     kw = json.loads(os.environ.get("MAPDIT_TEST_MODEL_KW", "{}"))        # e.g. off forms of the README flags: {"weight_normalization": false}
-    m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7, **kw).to(dev).train()
+    dit_kw = json.loads(os.environ.get("MAPDIT_TEST_DIT_KW", "{}"))      # a model outside the named ones, e.g. {"depth": 2, "hidden_size": 768, "num_heads": 12}
+    if dit_kw:
+        from mapdit_amd.src.dit import DiT
+        m = DiT(patch_size=2, in_channels=4, input_size=32, num_classes=7, **dit_kw, **kw).to(dev).train()
+    else:
+        m = DIT_MODELS["DiT-XS/2"](in_channels=4, input_size=32, num_classes=7, **kw).to(dev).train()
     m.gemm_precision = precision
     if precision == "f16":
         m.loss_scale = 1024.0                               # (the automatic choice depends on the per-rank batch: fixed, a sample's bits do not)
@@ -48,7 +53,7 @@ def main():
     red.attach(opt)
     diff = create_diffusion("")
     g = torch.Generator().manual_seed(22)
-    n = 16
+    n = int(os.environ.get("MAPDIT_TEST_BATCH", "16"))
     lo, hi = parallel.shard_batch(n, rank, world)
     # MAPDIT_TEST_OVERFLOW="rank:step": that rank's loss is blown up in that step (fp16: its gradients overflow) - the non-finite
     # guard must refuse the step on EVERY rank

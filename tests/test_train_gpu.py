@@ -449,6 +449,27 @@ def test_two_rank_sharded_weight_passes(tmp_path, precision):
     assert abs(zw3[0]["loss"] - zw3[1]["loss"]) < 1.0 and zw3[0]["refused"] == 0
 
 
+def test_two_rank_runs_with_the_grouped_weight_gradient_launch(tmp_path, monkeypatch):
+    """Two ranks of 32 samples each on a two-block model of DiT-B's width: at that shape every block's four weight gradients leave in ONE grouped
+    launch inside the block's backward stage (engine.hip dw_group_split), so the per-stage all-reduce / reduce-scatter of the reducers must still see
+    final gradient slices: replicas bit-identical, the three exchanges agree (all-reduce == ZeRO-1 bit for bit, sharded weight passes to fp32
+    rounding), and the two-rank step equals the launch-each run (MAPDIT_DW_GROUP=0) to summation order."""
+    monkeypatch.setenv("MAPDIT_TEST_DIT_KW", '{"depth": 2, "hidden_size": 768, "num_heads": 12}')
+    monkeypatch.setenv("MAPDIT_TEST_BATCH", "64")
+    ar = _run_dp(tmp_path, "ar", 2, "allreduce", "f16", steps=1)
+    z1 = _run_dp(tmp_path, "z1", 2, "zero1", "f16", steps=1)
+    zw = _run_dp(tmp_path, "zw", 2, "zero1w", "f16", steps=1)
+    for k in ("p", "m", "v", "e0", "e1"):
+        assert torch.equal(ar[0][k], ar[1][k]) and torch.equal(zw[0][k], zw[1][k]), k
+        assert torch.equal(z1[0][k], ar[0][k]), k
+        assert rel_err(zw[0][k].numpy(), ar[0][k].numpy()) < 2e-5, k
+    monkeypatch.setenv("MAPDIT_DW_GROUP", "0")
+    each = _run_dp(tmp_path, "each", 2, "allreduce", "f16", steps=1)
+    assert not torch.equal(each[0]["g"], ar[0]["g"]), "the grouped launch did not run at this shape"
+    for k in ("g", "p", "m"):
+        assert rel_err(each[0][k].numpy(), ar[0][k].numpy()) < 2e-5, k
+
+
 def test_two_rank_sharded_weight_passes_with_off_forms(tmp_path, monkeypatch):
     """The README off forms that touch the weight passes and the block's structure (weight normalisation off: MAPDIT_WN_PLAIN in the sharded
     imaging and Jacobian jobs; plain attention; the LayerNorm form) under --grad-comm zero1w, two ranks: replicas bit-identical after gather_state
